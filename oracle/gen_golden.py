@@ -1,0 +1,292 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own lib/Helpers.py.
+
+Runs only in the build container (needs /root/reference, which never travels).  The reference
+source is imported from where it lies; nothing of it is copied into this repository -- the
+fixtures hold inputs and outputs only.
+
+Provenance of every fixture (recorded in each file's `provenance` field):
+  * `reference`      : produced by reference code that touches only NumPy/SciPy
+                       (triangulate_point(s), get_extrinsics, read_camera_params).
+  * `reference+cvstub`: produced by the reference's control flow, with the two OpenCV primitives it
+                       calls -- cv.computeCorrespondEpilines (Helpers.py:207) and cv.projectPoints
+                       (Helpers.py:133) -- supplied by the closed-form NumPy stand-ins below, because
+                       cv2 is not installed here.
+
+Usage:  python oracle/gen_golden.py            (writes tests/golden/)
+"""
+import copy
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+
+# ---- closed-form stand-ins for the two cv2 calls made by lib/Helpers.py -------------------------
+def _epilines(points, which, F):
+    pts = np.asarray(points, np.float32).reshape(-1, 2)
+    f = np.asarray(F, np.float64)
+    if which == 2:
+        f = f.T
+    out = np.zeros((len(pts), 1, 3), np.float32)
+    for i, (x, y) in enumerate(pts):
+        x, y = float(x), float(y)
+        a = f[0, 0] * x + f[0, 1] * y + f[0, 2]
+        b = f[1, 0] * x + f[1, 1] * y + f[1, 2]
+        c = f[2, 0] * x + f[2, 1] * y + f[2, 2]
+        nu = a * a + b * b
+        nu = 1.0 / np.sqrt(nu) if nu else 1.0
+        out[i, 0] = (np.float32(a * nu), np.float32(b * nu), np.float32(c * nu))
+    return out
+
+
+def _project_points(obj, R, t, K, dist):
+    obj = np.asarray(obj)
+    out_t = np.float32 if obj.dtype == np.float32 else np.float64
+    P = obj.astype(np.float64).reshape(-1, 3)
+    R = np.asarray(R, np.float64).reshape(3, 3)
+    t = np.asarray(t, np.float64).reshape(3)
+    K = np.asarray(K, np.float64)
+    k = np.zeros(5)
+    d = np.asarray(dist, np.float64).ravel()
+    k[: len(d)] = d[:5]
+    res = np.zeros((len(P), 1, 2), out_t)
+    for i, (X, Y, Z) in enumerate(P):
+        x = R[0, 0] * X + R[0, 1] * Y + R[0, 2] * Z + t[0]
+        y = R[1, 0] * X + R[1, 1] * Y + R[1, 2] * Z + t[1]
+        z = R[2, 0] * X + R[2, 1] * Y + R[2, 2] * Z + t[2]
+        z = 1.0 / z if z else 1.0
+        x *= z
+        y *= z
+        r2 = x * x + y * y
+        r4 = r2 * r2
+        r6 = r4 * r2
+        a1 = 2 * x * y
+        a2 = r2 + 2 * x * x
+        a3 = r2 + 2 * y * y
+        cdist = 1 + k[0] * r2 + k[1] * r4 + k[4] * r6
+        xd = x * cdist + k[2] * a1 + k[3] * a2
+        yd = y * cdist + k[2] * a3 + k[3] * a1
+        res[i, 0] = (xd * K[0, 0] + K[0, 2], yd * K[1, 1] + K[1, 2])
+    return res, None
+
+
+def load_reference():
+    stub = types.ModuleType("cv2")
+    stub.computeCorrespondEpilines = _epilines
+    stub.projectPoints = _project_points
+    sys.modules["cv2"] = stub
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    os.chdir(REF)  # the reference opens ./jsons/... relative to the CWD
+    import lib.Helpers as H  # noqa: E402
+
+    return H
+
+
+def poses_arrays(poses):
+    return (np.stack([np.asarray(p["R"], float) for p in poses]),
+            np.stack([np.asarray(p["t"], float).reshape(3) for p in poses]))
+
+
+def params_arrays(params):
+    return (np.stack([np.asarray(p["intrinsic_matrix"], float) for p in params]),
+            np.stack([np.asarray(p["distortion_coef"], float) for p in params]))
+
+
+def pack_lists(lists, max_pts):
+    """[C] lists of [x,y] -> (pts [C,max_pts,2] float64, counts [C])"""
+    C = len(lists)
+    pts = np.zeros((C, max_pts, 2))
+    cnt = np.zeros(C, np.int32)
+    for c, l in enumerate(lists):
+        l = [p for p in l if p[0] is not None]
+        cnt[c] = len(l)
+        if l:
+            pts[c, : len(l)] = np.asarray(l, float)
+    return pts, cnt
+
+
+def run_corr(H, lists, poses, params, Fs, obj_count):
+    H.camera_params = np.array(params)
+    H.Fs = [np.asarray(F).tolist() for F in Fs]
+    arg = copy.deepcopy(lists)
+    obj, img = H.find_point_correspondance_and_object_points(arg, poses, obj_count)
+    return np.asarray(obj, float), np.asarray(img), arg
+
+
+def save_corr(name, H, lists, poses, params, Fs, obj_count, note):
+    obj, img, mutated = run_corr(H, lists, poses, params, Fs, obj_count)
+    max_pts = max(1, max(len(l) for l in lists))
+    pts, cnt = pack_lists(lists, max_pts)
+    R, t = poses_arrays(poses)
+    K, dist = params_arrays(params)
+    had_sentinel = np.array([any(p[0] is None for p in l) for l in lists])
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"), pts=pts, counts=cnt, had_sentinel=had_sentinel, R=R, t=t, K=K, dist=dist,
+        F=np.asarray(Fs, float).reshape(-1, 3, 3), obj_count=obj_count,
+        out_obj=obj, out_img=img.astype(float), out_img_is_int=np.array(img.dtype.kind in "iu"),
+        out_obj_shape=np.array(obj.shape), out_img_shape=np.array(img.shape),
+        mutated_counts=np.array([len(l) for l in mutated]),
+        provenance="reference+cvstub: lib/Helpers.py:178-280 run in the build container; " + note)
+    print(f"{name}: obj {obj.shape} img {img.shape}")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    H = load_reference()
+    from mocapv2_amd.synth import Scene, MILD_DIST  # noqa: E402
+
+    # ---- K1: bundled DLT known-answer --------------------------------------------------------
+    poses, _ = H.get_extrinsics()
+    with open("jsons/image_points.json") as f:
+        ip = np.array(json.load(f))  # [54][2][2]
+    with open("jsons/after_ba_objects.json") as f:
+        expected = np.array(json.load(f))
+    with open("jsons/camera-params-in.json") as f:
+        params = json.load(f)
+    with open("jsons/fundamentals.json") as f:
+        Fs_b = json.load(f)
+    H.camera_params = None
+    got = H.triangulate_points(ip, poses)
+    assert np.abs(got - expected).max() < 1e-12
+    R, t = poses_arrays(poses)
+    K, dist = params_arrays(params)
+    # reprojection errors of the same 54 groups (cv.projectPoints stand-in)
+    errs = H.calculate_reprojection_errors(ip, got, poses)
+    # K2: epipolar distances of the 54 pairs under fundamentals.json[0] (expression of Helpers.py:217)
+    dists = []
+    for (p0, p1) in ip:
+        a, b, c = _epilines(np.array([p0], np.float32), 1, np.array(Fs_b[0]))[0, 0].tolist()
+        pts1 = np.array([p1])
+        dists.append((np.abs(a * pts1[:, 0] + b * pts1[:, 1] + c) / np.sqrt(a ** 2 + b ** 2))[0])
+    np.savez_compressed(
+        os.path.join(OUT, "k1_bundled.npz"), image_points=ip, R=R, t=t, K=K, dist=dist,
+        F=np.asarray(Fs_b, float), objects_json=expected, objects_ref=got, reproj_mse=errs,
+        epi_dist=np.array(dists),
+        provenance="reference: lib/Helpers.py:87-99 on jsons/image_points.json + after_ba_extrinsics.json "
+                   "(= jsons/after_ba_objects.json to 3e-15); reproj_mse/epi_dist: reference+cvstub")
+    print("k1_bundled: max|ref-json| =", np.abs(got - expected).max(), " epi max", max(dists))
+
+    # triangulate_point with None entries (intrinsics indexed by position after removal, Helpers.py:50-61)
+    sc = Scene(4, dist=MILD_DIST)
+    rng = np.random.default_rng(7)
+    mk = sc.markers(rng, 6)
+    cents = sc.centroids(mk)
+    prm4 = copy.deepcopy(sc.camera_params)
+    for c in range(4):  # make the intrinsics differ per camera so the quirk is visible
+        prm4[c]["intrinsic_matrix"][0][0] += 10.0 * c
+        prm4[c]["intrinsic_matrix"][1][1] += 7.0 * c
+    H.camera_params = np.array(prm4)
+    groups, outs = [], []
+    masks = [(1, 1, 1, 1), (0, 1, 1, 1), (1, 0, 1, 1), (1, 1, 0, 0), (0, 0, 1, 1), (1, 0, 0, 0), (0, 0, 0, 0)]
+    for m, msk in enumerate(masks):
+        g = [[int(cents[c][m % 6][0]), int(cents[c][m % 6][1])] if msk[c] else [None, None] for c in range(4)]
+        r = H.triangulate_point(g, sc.poses)
+        outs.append([np.nan] * 3 if r[0] is None else list(r))
+        groups.append([[np.nan, np.nan] if p[0] is None else p for p in g])
+    R4, t4 = poses_arrays(sc.poses)
+    K4, d4 = params_arrays(prm4)
+    np.savez_compressed(os.path.join(OUT, "tri_none.npz"), groups=np.array(groups, float), R=R4, t=t4, K=K4,
+                        dist=d4, out=np.array(outs, float),
+                        provenance="reference: lib/Helpers.py:43-84 with [None,None] entries (NaN here)")
+    print("tri_none:", np.array(outs).shape)
+
+    # ---- correspondence cases ------------------------------------------------------------------
+    # C=2, bundled calibration: frames made of subsets of the 54 captured pairs, camera-1 order shuffled
+    rng = np.random.default_rng(11)
+    for k, (lo, hi) in enumerate([(0, 6), (6, 16), (16, 24), (30, 54)]):
+        sel = ip[lo:hi]
+        l0 = [[int(p[0][0]), int(p[0][1])] for p in sel]
+        l1 = [[int(p[1][0]), int(p[1][1])] for p in sel]
+        perm = rng.permutation(len(l1))
+        l1 = [l1[i] for i in perm]
+        save_corr(f"corr_c2_bundled_{k}", H, [l0, l1], poses, params, Fs_b, 4,
+                  f"bundled pairs {lo}:{hi}, jsons/fundamentals.json")
+    # float-valued points (the dtype of jsons/image_points.json) -> float outputs
+    sel = ip[0:5]
+    save_corr("corr_c2_bundled_float", H, [[list(map(float, p[0])) for p in sel], [list(map(float, p[1])) for p in sel]],
+              poses, params, Fs_b, 2, "float inputs")
+
+    def synth_case(name, C, M, seed, obj_count, dist=MILD_DIST, jitter=0.0, shuffle=True, drop=None, extra=0):
+        sc = Scene(C, dist=dist)
+        rng = np.random.default_rng(seed)
+        mk = sc.markers(rng, M)
+        cents = sc.centroids(mk, rng, jitter)
+        lists = []
+        for c in range(C):
+            l = [[int(x), int(y)] for x, y in cents[c]]
+            if drop and c in drop:
+                l = l[: max(0, len(l) - drop[c])]
+            for _ in range(extra):
+                l.append([int(rng.integers(0, 1920)), int(rng.integers(0, 1080))])
+            if shuffle:
+                l = [l[i] for i in rng.permutation(len(l))]
+            lists.append(l)
+        save_corr(name, H, lists, sc.poses, sc.camera_params, sc.Fs, obj_count, f"synthetic ring C={C} M={M} seed={seed}")
+
+    synth_case("corr_c3_m4", 3, 4, 101, 3)
+    synth_case("corr_c6_m8", 6, 8, 102, 8, jitter=0.7)
+    synth_case("corr_c6_m8_objcount0", 6, 8, 103, 0)
+    synth_case("corr_c6_m8_big_objcount", 6, 8, 104, 50)
+    synth_case("corr_c6_m32", 6, 32, 105, 32, jitter=0.5)
+    synth_case("corr_c4_m12_clutter", 4, 12, 106, 12, jitter=1.0, extra=5)
+    synth_case("corr_c4_m6_dropped", 4, 6, 107, 6, drop={2: 3, 3: 1})
+
+    # edge cases: sentinel lists, empty cameras, no matches at all
+    sc = Scene(3, dist=MILD_DIST)
+    rng = np.random.default_rng(9)
+    cents = sc.centroids(sc.markers(rng, 3))
+    L = [[[int(x), int(y)] for x, y in cents[c]] for c in range(3)]
+    save_corr("corr_edge_sentinel_cam1", H, [L[0], [[None, None]], L[2]], sc.poses, sc.camera_params, sc.Fs, 2,
+              "camera 1 returned the [[None,None]] sentinel")
+    save_corr("corr_edge_sentinel_cam0", H, [[[None, None]], L[1], L[2]], sc.poses, sc.camera_params, sc.Fs, 2,
+              "camera 0 returned the sentinel")
+    save_corr("corr_edge_all_empty", H, [[[None, None]], [[None, None]], [[None, None]]], sc.poses,
+              sc.camera_params, sc.Fs, 2, "all cameras empty")
+    far = [[[5, 5]], [[1900, 1000]], [[10, 1070]]]
+    save_corr("corr_edge_no_match", H, far, sc.poses, sc.camera_params, sc.Fs, 1, "no candidate within 10 px")
+    save_corr("corr_edge_one_marker", H, [[L[0][0]], [L[1][0]], [L[2][0]]], sc.poses, sc.camera_params, sc.Fs, 0,
+              "a single marker")
+
+    # ---- bundle-adjustment residual vector (Helpers.py:158-167) -----------------------------------
+    H.camera_params = np.array(params)
+    captured = {}
+
+    def capture(fun, x0, **kw):
+        captured["fun"], captured["x0"] = fun, np.array(x0)
+
+        class R_:
+            x = np.array(x0)
+
+        return R_()
+
+    orig = H.optimize.least_squares
+    H.optimize.least_squares = capture
+    try:
+        with open("jsons/before_ba_extrinsics.json") as f:
+            before = json.load(f)
+        for p in before:
+            p["R"], p["t"] = np.array(p["R"]), np.array(p["t"])
+        H.bundle_adjustment(ip, before)
+    finally:
+        H.optimize.least_squares = orig
+    x0 = captured["x0"]
+    rng = np.random.default_rng(5)
+    xs = [x0, x0 + rng.normal(0, 1e-3, x0.shape), x0 + rng.normal(0, 1e-2, x0.shape)]
+    res = [np.asarray(captured["fun"](x)) for x in xs]
+    np.savez_compressed(os.path.join(OUT, "ba_residuals.npz"), image_points=ip, params=np.array(xs),
+                        residuals=np.array(res), K=K, dist=dist,
+                        provenance="reference+cvstub: residual_function of lib/Helpers.py:161-167 captured through "
+                                   "a patched scipy.optimize.least_squares, before_ba_extrinsics.json start")
+    print("ba_residuals:", np.array(res).shape, np.array(res).dtype)
+
+
+if __name__ == "__main__":
+    main()

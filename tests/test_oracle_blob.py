@@ -1,0 +1,175 @@
+"""Self-consistency of the blob oracle (oracle/blob_oracle.c).  No reference fixture pins this half
+(parity unpinned); these checks stand in for it: independent SciPy formulations,
+analytic properties of the border-following polygons, and the literal-vs-separable filter forms."""
+import numpy as np
+import pytest
+from scipy import ndimage
+
+import oracle
+from mocapv2_amd.synth import MILD_DIST, Scene
+
+
+def rand_img(rng, H, W, bright=0.3):
+    img = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    img[rng.random((H, W)) < bright] = 255
+    return img
+
+
+def blobs_mask(rng, H, W, n=6, rmin=3, rmax=14, holes=True):
+    yy, xx = np.mgrid[0:H, 0:W]
+    m = np.zeros((H, W), bool)
+    for _ in range(n):
+        cx, cy, r = rng.uniform(0, W), rng.uniform(0, H), rng.uniform(rmin, rmax)
+        m |= (xx - cx) ** 2 + (yy - cy) ** 2 <= r * r
+        if holes and rng.random() < 0.5:
+            m &= ~((xx - cx) ** 2 + (yy - cy) ** 2 <= (r * 0.5) ** 2)
+    return (m * 255).astype(np.uint8)
+
+
+def test_box_blur_matches_scipy_and_fast_form():
+    rng = np.random.default_rng(1)
+    for H, W in [(1, 1), (3, 7), (17, 33), (64, 50)]:
+        img = rand_img(rng, H, W)
+        lit = oracle.box_blur(img)
+        fast = oracle.box_blur(img, fast=True)
+        assert np.array_equal(lit, fast)
+        s = ndimage.uniform_filter(img.astype(np.float64), 5, mode="constant") * 25
+        c = ndimage.uniform_filter(np.ones((H, W)), 5, mode="constant") * 25
+        assert np.array_equal(lit, np.floor(np.rint(s) / np.rint(c)).astype(np.uint8))
+
+
+def test_blur_threshold_is_integer_test():
+    rng = np.random.default_rng(2)
+    img = rand_img(rng, 40, 60, bright=0.6)
+    binary = oracle.threshold(oracle.box_blur(img))
+    s = np.rint(ndimage.uniform_filter(img.astype(np.float64), 5, mode="constant") * 25).astype(np.int64)
+    c = np.rint(ndimage.uniform_filter(np.ones(img.shape), 5, mode="constant") * 25).astype(np.int64)
+    assert np.array_equal(binary != 0, s >= 217 * c)
+
+
+def test_median_matches_scipy_and_majority():
+    rng = np.random.default_rng(3)
+    img = rand_img(rng, 31, 47)
+    assert np.array_equal(oracle.median5(img), ndimage.median_filter(img, size=5, mode="nearest"))
+    b = ((rng.random((31, 47)) < 0.5) * 255).astype(np.uint8)
+    assert np.array_equal(oracle.median5(b), oracle.median5(b, majority=True))
+    assert np.array_equal(oracle.image_filter(img, 0), oracle.image_filter(img, 2))
+    assert np.array_equal(oracle.image_filter(img, 1), oracle.threshold(ndimage.median_filter(img, size=5, mode="nearest")))
+
+
+def test_undistort_identity_and_shift():
+    rng = np.random.default_rng(4)
+    img = rand_img(rng, 48, 64)
+    K = np.array([[50.0, 0, 32], [0, 50.0, 24], [0, 0, 1]])
+    assert np.array_equal(oracle.undistort(img, K, np.zeros(5)), img)
+    iu, iv = oracle.undistort_map(48, 64, K, np.zeros(5))
+    xx, yy = np.meshgrid(np.arange(64), np.arange(48))
+    assert np.array_equal(iu, xx * 32) and np.array_equal(iv, yy * 32)
+    # the map of a distorted camera agrees with the closed form before quantisation
+    iu, iv = oracle.undistort_map(48, 64, K, np.array(MILD_DIST))
+    x, y = (xx - 32) / 50.0, (yy - 24) / 50.0
+    r2 = x * x + y * y
+    k1, k2, p1, p2, k3 = MILD_DIST
+    kr = 1 + ((k3 * r2 + k2) * r2 + k1) * r2
+    u = 50 * (x * kr + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)) + 32
+    v = 50 * (y * kr + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y) + 24
+    assert np.abs(iu - u * 32).max() <= 0.5 + 1e-6 and np.abs(iv - v * 32).max() <= 0.5 + 1e-6
+
+
+def test_remap_is_bilinear():
+    rng = np.random.default_rng(5)
+    img = rand_img(rng, 20, 30)
+    K = np.array([[40.0, 0, 15], [0, 40.0, 10], [0, 0, 1]])
+    d = np.array(MILD_DIST) * 3
+    iu, iv = oracle.undistort_map(20, 30, K, d)
+    out = oracle.undistort(img, K, d)
+    pad = np.zeros((24, 34))
+    pad[2:22, 2:32] = img
+    sx, sy, a, b = iu >> 5, iv >> 5, (iu & 31) / 32.0, (iv & 31) / 32.0
+    ok = (sx >= -2) & (sx < 31) & (sy >= -2) & (sy < 21)
+    sxc, syc = np.clip(sx, -2, 30) + 2, np.clip(sy, -2, 20) + 2
+    ref = (pad[syc, sxc] * (1 - a) * (1 - b) + pad[syc, sxc + 1] * a * (1 - b) + pad[syc + 1, sxc] * (1 - a) * b
+           + pad[syc + 1, sxc + 1] * a * b)
+    assert np.abs(out.astype(float) - ref)[ok].max() <= 0.5 + 1e-9
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_contours_vs_labelling(seed):
+    rng = np.random.default_rng(seed)
+    H, W = 60, 90
+    mask = blobs_mask(rng, H, W) if seed % 2 else ((rng.random((H, W)) < 0.45) * 255).astype(np.uint8)
+    cs = oracle.find_contours(mask, with_points=True)
+    fg = mask != 0
+    n_fg = ndimage.label(fg, structure=np.ones((3, 3)))[1]
+    pad = np.pad(~fg, 1, constant_values=True)
+    n_bg = ndimage.label(pad)[1]  # 4-connected background, padded so the outside is one component
+    assert sum(1 for c in cs if not c["is_hole"]) == n_fg
+    assert sum(1 for c in cs if c["is_hole"]) == n_bg - 1
+    lab = ndimage.label(fg, structure=np.ones((3, 3)))[0]
+    for i, c in enumerate(cs):
+        # origin: outer border starts at the raster-first pixel of its component
+        if not c["is_hole"]:
+            ys, xs = np.nonzero(lab == lab[c["oy"], c["ox"]])
+            assert (c["oy"], c["ox"]) == (ys[0], xs[ys == ys[0]].min())
+            assert c["a00"] <= 0 or c["npts"] <= 2  # outer borders run counter-clockwise on screen -> negative a00 here
+        # a parent's nesting type always differs
+        if c["parent_order"] >= 0:
+            assert cs[c["parent_order"]]["is_hole"] != c["is_hole"]
+            assert c["parent_order"] < i
+        else:
+            assert not c["is_hole"]
+        # the polygon is closed and its vertices are foreground pixels
+        p = c["points"]
+        assert len(p) == c["npts"] and np.all(fg[p[:, 1], p[:, 0]])
+
+
+def test_contour_order_is_reverse_raster_for_simple_blobs():
+    mask = np.zeros((60, 80), np.uint8)
+    for (y, x) in [(5, 50), (5, 10), (30, 30), (50, 60), (50, 5)]:
+        mask[y:y + 6, x:x + 7] = 255
+    cs = oracle.find_contours(mask)
+    assert [(c["oy"], c["ox"]) for c in cs] == [(50, 60), (50, 5), (30, 30), (5, 50), (5, 10)]
+    for c in cs:  # 7x6 rectangle: polygon through pixel centres is 6x5, perimeter 22
+        assert c["area"] == 30.0 and c["perimeter"] == 22.0 and c["npts"] == 4
+
+
+def test_picks_theorem_and_hole_nesting():
+    yy, xx = np.mgrid[0:80, 0:80]
+    ring = ((xx - 40) ** 2 + (yy - 40) ** 2 <= 30 ** 2) & ~((xx - 40) ** 2 + (yy - 40) ** 2 <= 15 ** 2)
+    dot = (xx - 40) ** 2 + (yy - 40) ** 2 <= 5 ** 2
+    cs = oracle.find_contours(((ring | dot) * 255).astype(np.uint8))
+    assert [c["is_hole"] for c in cs] == [0, 1, 0] and [c["parent_order"] for c in cs] == [-1, 0, 1]
+    # Pick: area of the outer polygon = interior lattice points + boundary/2 - 1
+    disc = (xx - 40) ** 2 + (yy - 40) ** 2 <= 30 ** 2
+    assert cs[0]["area"] == disc.sum() - cs[0]["steps"] / 2 - 1
+    assert cs[2]["area"] == dot.sum() - cs[2]["steps"] / 2 - 1
+
+
+def test_find_dot_on_synthetic_frame():
+    sc = Scene(2, width=640, height=360, dist=MILD_DIST)
+    rng = np.random.default_rng(4)
+    mk = sc.markers(rng, 5, extent=1.0)
+    img = sc.render(rng, mk, 0, radius_range=(16, 20), salt=0.001)
+    pts, mask = oracle.find_dot(img, sc.K, sc.dist, return_mask=True)
+    assert len(pts) == 5
+    from mocapv2_amd.synth import ZERO_DIST, project
+    ideal = project(mk, sc.poses[0], sc.K, ZERO_DIST)
+    for p in pts:
+        assert np.min(np.hypot(*(ideal - np.array(p)).T)) < 1.5
+    # top-level blobs come out in reverse raster order of their first pixel
+    cs = [c for c in oracle.find_contours(mask) if c["kept"]]
+    assert [[c["cx"], c["cy"]] for c in cs] == pts
+    starts = [(c["oy"], c["ox"]) for c in cs]
+    assert starts == sorted(starts, reverse=True)
+    # nothing detected -> empty
+    assert oracle.find_dot(np.zeros((50, 50), np.uint8)) == []
+
+
+def test_demosaic_interior():
+    rng = np.random.default_rng(6)
+    b = rng.integers(0, 256, (8, 10), dtype=np.uint8)
+    out = oracle.demosaic(b)
+    y, x = 2, 2  # blue site
+    assert out[y, x, 0] == b[y, x]
+    assert out[y, x, 1] == (int(b[y, x - 1]) + b[y, x + 1] + b[y - 1, x] + b[y + 1, x]) // 4
+    assert out[0, 0, 2] == int(b[1, 1]) // 4  # border taps read 0, divisor stays 4
