@@ -1,0 +1,447 @@
+// abi.hip -- the C-ABI of libmocap_hip.so (declared in include/mocap_hip.h): argument checks, the per-GPU
+// context (undistort tables, camera table, scratch), kernel launches.  No compute happens on the host.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string.h>
+#include <math.h>
+#include <string>
+#include <vector>
+#include <mutex>
+#include "../../include/mocap_hip.h"
+#include "kernels.h"
+
+using namespace mocap;
+
+static_assert(sizeof(mocap_contour) == sizeof(ContourRec), "debug record layout");
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                         \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess) return fail(MOCAP_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));        \
+    } while (0)
+
+struct EvPair { hipEvent_t a, b; };
+
+struct mocap_ctx {
+    int device, W, H, n_slots, wpr;
+    mocap_blob_params prm;
+    uint32_t* maps;           // [n_slots][H][W]
+    uint32_t* map_flags;      // [n_slots] device
+    std::vector<int> slot_state; // 0 unset, 1 identity, 2 remap
+    uint32_t* mask; size_t mask_images;
+    CameraTable* cams; int n_cam, n_F;
+    double* scratch; size_t scratch_elems;
+    bool profiling;
+    std::vector<EvPair> ev[3];
+    std::mutex mu;
+};
+
+static int set_device(mocap_ctx* c) { HIP_TRY(hipSetDevice(c->device)); return 0; }
+
+extern "C" {
+
+int mocap_abi_version(void) { return MOCAP_ABI_VERSION; }
+const char* mocap_last_error(void) { return g_err.c_str(); }
+
+int mocap_ctx_create(int device_id, int width, int height, int n_slots, mocap_ctx_t* out)
+{
+    if (!out || width < 1 || height < 1 || width > 32767 || height > 32767 || n_slots < 1 || n_slots > 64)
+        return fail(MOCAP_E_INVALID, "mocap_ctx_create: bad geometry %dx%d slots=%d", width, height, n_slots);
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) return fail(MOCAP_E_HIP, "mocap_ctx_create: no HIP device %d (%d visible)", device_id, ndev);
+    HIP_TRY(hipSetDevice(device_id));
+    mocap_ctx* c = new mocap_ctx();
+    c->device = device_id; c->W = width; c->H = height; c->n_slots = n_slots; c->wpr = (width + 31) / 32;
+    c->prm = mocap_blob_params{5, 5, 255 * 0.85, 500.0, 0.5};
+    c->maps = nullptr; c->map_flags = nullptr; c->mask = nullptr; c->mask_images = 0;
+    c->cams = nullptr; c->n_cam = 0; c->n_F = 0; c->scratch = nullptr; c->scratch_elems = 0; c->profiling = false;
+    c->slot_state.assign(n_slots, 0);
+    hipError_t e = hipMalloc(&c->map_flags, sizeof(uint32_t) * n_slots);
+    if (e == hipSuccess) e = hipMemset(c->map_flags, 0, sizeof(uint32_t) * n_slots);
+    if (e == hipSuccess) e = hipMalloc(&c->cams, sizeof(CameraTable));
+    if (e == hipSuccess) e = hipMemset(c->cams, 0, sizeof(CameraTable));
+    if (e != hipSuccess) {
+        mocap_ctx_destroy(c);
+        return fail(MOCAP_E_HIP, "mocap_ctx_create: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return MOCAP_OK;
+}
+
+int mocap_ctx_destroy(mocap_ctx_t c)
+{
+    if (!c) return MOCAP_OK;
+    (void)hipSetDevice(c->device);
+    for (auto& v : c->ev) for (auto& p : v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    if (c->maps) (void)hipFree(c->maps);
+    if (c->map_flags) (void)hipFree(c->map_flags);
+    if (c->mask) (void)hipFree(c->mask);
+    if (c->cams) (void)hipFree(c->cams);
+    if (c->scratch) (void)hipFree(c->scratch);
+    delete c;
+    return MOCAP_OK;
+}
+
+int mocap_sync(mocap_ctx_t c, void* stream)
+{
+    if (!c) return fail(MOCAP_E_INVALID, "null context");
+    if (set_device(c)) return MOCAP_E_HIP;
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return MOCAP_OK;
+}
+
+int mocap_set_blob_params(mocap_ctx_t c, const mocap_blob_params* p)
+{
+    if (!c || !p) return fail(MOCAP_E_INVALID, "null argument");
+    if (p->ksize != 5 || p->median != 5)
+        return fail(MOCAP_E_UNSUPPORTED, "only the reference's 5x5 blur and 5x5 median are implemented (got %d, %d)", p->ksize, p->median);
+    if (!(p->thresh == p->thresh)) return fail(MOCAP_E_INVALID, "thresh is NaN");
+    c->prm = *p;
+    return MOCAP_OK;
+}
+
+int mocap_set_undistort(mocap_ctx_t c, int slot, const double K[9], const double dist[5], int* identity_out)
+{
+    if (!c || !K || !dist) return fail(MOCAP_E_INVALID, "null argument");
+    if (slot < 0 || slot >= c->n_slots) return fail(MOCAP_E_INVALID, "slot %d out of range", slot);
+    if (set_device(c)) return MOCAP_E_HIP;
+    std::lock_guard<std::mutex> lk(c->mu);
+    size_t per = (size_t)c->H * c->W;
+    if (!c->maps) HIP_TRY(hipMalloc(&c->maps, sizeof(uint32_t) * per * c->n_slots));
+    MapArgs m;
+    memcpy(m.K, K, sizeof(m.K));
+    memcpy(m.dist, dist, sizeof(m.dist));
+    m.H = c->H; m.W = c->W;
+    m.map = c->maps + per * slot;
+    m.flags = c->map_flags + slot;
+    HIP_TRY(hipMemset(m.flags, 0, sizeof(uint32_t)));
+    launch_undistort_map(m, 0);
+    HIP_TRY(hipGetLastError());
+    uint32_t flags = 0;
+    HIP_TRY(hipMemcpy(&flags, m.flags, sizeof(flags), hipMemcpyDeviceToHost));
+    if (flags & 2u) {
+        c->slot_state[slot] = 0;
+        return fail(MOCAP_E_UNSUPPORTED, "undistort displacement exceeds +-1024 px for slot %d", slot);
+    }
+    c->slot_state[slot] = (flags & 1u) ? 2 : 1;
+    if (identity_out) *identity_out = c->slot_state[slot] == 1;
+    return MOCAP_OK;
+}
+
+int mocap_set_cameras(mocap_ctx_t c, int n, const double* K, const double* dist, const double* R, const double* t)
+{
+    if (!c || !K || !dist || !R || !t) return fail(MOCAP_E_INVALID, "null argument");
+    if (n < 1 || n > 32) return fail(MOCAP_E_INVALID, "camera count %d not in 1..32", n);
+    if (set_device(c)) return MOCAP_E_HIP;
+    HIP_TRY(hipMemcpy(&c->cams->K[0][0], K, sizeof(double) * 9 * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(&c->cams->dist[0][0], dist, sizeof(double) * 5 * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(&c->cams->R[0][0], R, sizeof(double) * 9 * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(&c->cams->t[0][0], t, sizeof(double) * 3 * n, hipMemcpyHostToDevice));
+    c->n_cam = n;
+    return MOCAP_OK;
+}
+
+int mocap_set_fundamentals(mocap_ctx_t c, int n, const double* F)
+{
+    if (!c || (n > 0 && !F)) return fail(MOCAP_E_INVALID, "null argument");
+    if (n < 0 || n > 31) return fail(MOCAP_E_INVALID, "fundamental matrix count %d not in 0..31", n);
+    if (set_device(c)) return MOCAP_E_HIP;
+    if (n) HIP_TRY(hipMemcpy(&c->cams->F[0][0], F, sizeof(double) * 9 * n, hipMemcpyHostToDevice));
+    c->n_F = n;
+    return MOCAP_OK;
+}
+
+// ---- profiling -------------------------------------------------------------------------------------------------
+static void prof_begin(mocap_ctx* c, int which, hipStream_t s, EvPair& p, bool& on)
+{
+    on = c->profiling;
+    if (!on) return;
+    if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) { on = false; return; }
+    (void)hipEventRecord(p.a, s);
+    (void)which;
+}
+static void prof_end(mocap_ctx* c, int which, hipStream_t s, EvPair& p, bool on)
+{
+    if (!on) return;
+    (void)hipEventRecord(p.b, s);
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->ev[which].push_back(p);
+}
+
+int mocap_profile_enable(mocap_ctx_t c, int on)
+{
+    if (!c) return fail(MOCAP_E_INVALID, "null context");
+    c->profiling = on != 0;
+    return MOCAP_OK;
+}
+
+int mocap_profile_read(mocap_ctx_t c, double* fms, int* fn, double* cms, int* cn, double* gms, int* gn)
+{
+    if (!c) return fail(MOCAP_E_INVALID, "null context");
+    if (set_device(c)) return MOCAP_E_HIP;
+    double ms[3] = {0, 0, 0};
+    int cnt[3] = {0, 0, 0};
+    std::lock_guard<std::mutex> lk(c->mu);
+    for (int w = 0; w < 3; w++) {
+        for (auto& p : c->ev[w]) {
+            HIP_TRY(hipEventSynchronize(p.b));
+            float f = 0;
+            HIP_TRY(hipEventElapsedTime(&f, p.a, p.b));
+            ms[w] += f; cnt[w]++;
+            (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b);
+        }
+        c->ev[w].clear();
+    }
+    if (fms) *fms = ms[0]; if (fn) *fn = cnt[0];
+    if (cms) *cms = ms[1]; if (cn) *cn = cnt[1];
+    if (gms) *gms = ms[2]; if (gn) *gn = cnt[2];
+    return MOCAP_OK;
+}
+
+// ---- blob stage ------------------------------------------------------------------------------------------------
+static int check_frames(mocap_ctx* c, const void* frames, int n_images, int cam_mod, size_t image_stride, int pitch)
+{
+    if (!c || !frames) return fail(MOCAP_E_INVALID, "null argument");
+    if (n_images < 1) return fail(MOCAP_E_INVALID, "n_images = %d", n_images);
+    if (cam_mod < 1 || cam_mod > c->n_slots) return fail(MOCAP_E_INVALID, "cam_mod %d not in 1..%d", cam_mod, c->n_slots);
+    if (pitch < c->W) return fail(MOCAP_E_INVALID, "pitch %d < width %d", pitch, c->W);
+    if (n_images > 1 && image_stride < (size_t)pitch * (c->H - 1) + c->W) return fail(MOCAP_E_INVALID, "image_stride too small");
+    for (int s = 0; s < cam_mod; s++)
+        if (c->slot_state[s] == 0) return fail(MOCAP_E_STATE, "mocap_set_undistort was not called for slot %d", s);
+    return 0;
+}
+
+static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mod, size_t image_stride, int pitch,
+                      uint32_t* mask, hipStream_t s)
+{
+    FilterArgs a;
+    a.src = (const uint8_t*)frames; a.image_stride = image_stride; a.pitch = pitch; a.H = c->H; a.W = c->W;
+    a.aligned4 = (((uintptr_t)frames | (uintptr_t)pitch | (uintptr_t)image_stride) & 3) == 0;
+    a.mask = mask; a.words_per_row = c->wpr; a.map = c->maps; a.cam_mod = cam_mod;
+    a.n_images = n_images; a.n_steps = (n_images + cam_mod - 1) / cam_mod;
+    double ft = floor(c->prm.thresh);
+    a.thr_mul = ft < -1.0 ? 0 : (ft > 255.0 ? 256 : (int)ft + 1);
+    a.n_strips = (c->W + 239) / 240;
+    // four waves per workgroup, each sliding over rows_per_chunk rows (+8 halo rows)
+    int rows = 135;
+    if (c->H < 4 * 32) rows = (c->H + 3) / 4 > 8 ? (c->H + 3) / 4 : 8;
+    a.rows_per_chunk = rows;
+    a.n_cgroups = (c->H + 4 * rows - 1) / (4 * rows);
+    bool remap = false;
+    for (int sl = 0; sl < cam_mod; sl++) remap |= c->slot_state[sl] == 2;
+    EvPair p; bool on;
+    prof_begin(c, 0, s, p, on);
+    launch_filter_mask(a, remap, s);
+    prof_end(c, 0, s, p, on);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int run_contours(mocap_ctx* c, const uint32_t* mask, int n_images, int32_t* out_xy, int32_t* out_count,
+                        int max_blobs, mocap_contour* dbg, int32_t* dbg_count, int dbg_cap, hipStream_t s)
+{
+    ContourArgs a;
+    a.mask = mask; a.words_per_row = c->wpr; a.H = c->H; a.W = c->W; a.n_images = n_images;
+    a.out_xy = out_xy; a.out_count = out_count; a.max_blobs = max_blobs;
+    a.min_area = c->prm.min_area; a.min_circ = c->prm.min_circ;
+    a.dbg = (ContourRec*)dbg; a.dbg_count = dbg_count; a.dbg_cap = dbg_cap;
+    long long ms = 4LL * c->H * c->W + 16;
+    a.max_steps = ms > (1 << 22) ? (1 << 22) : (int)ms;
+    EvPair p; bool on;
+    prof_begin(c, 1, s, p, on);
+    launch_contours(a, s);
+    prof_end(c, 1, s, p, on);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int ensure_mask(mocap_ctx* c, int n_images)
+{
+    if ((size_t)n_images <= c->mask_images) return 0;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if ((size_t)n_images <= c->mask_images) return 0;
+    if (c->mask) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c->mask)); c->mask = nullptr; c->mask_images = 0; }
+    size_t bytes = sizeof(uint32_t) * (size_t)n_images * c->H * c->wpr;
+    HIP_TRY(hipMalloc(&c->mask, bytes));
+    HIP_TRY(hipMemset(c->mask, 0, bytes));
+    c->mask_images = n_images;
+    return 0;
+}
+
+int mocap_filter_mask(mocap_ctx_t c, const void* frames, int n_images, int cam_mod, size_t image_stride, int pitch,
+                      uint32_t* mask_dev, void* stream)
+{
+    int rc = check_frames(c, frames, n_images, cam_mod, image_stride, pitch);
+    if (rc) return rc;
+    if (!mask_dev) return fail(MOCAP_E_INVALID, "null mask");
+    if (set_device(c)) return MOCAP_E_HIP;
+    return run_filter(c, frames, n_images, cam_mod, image_stride, pitch, mask_dev, (hipStream_t)stream);
+}
+
+int mocap_contours_from_mask(mocap_ctx_t c, const uint32_t* mask_dev, int n_images, int32_t* out_xy, int32_t* out_count,
+                             int max_blobs, mocap_contour* dbg, int32_t* dbg_count, int dbg_cap, void* stream)
+{
+    if (!c || !mask_dev || !out_xy || !out_count) return fail(MOCAP_E_INVALID, "null argument");
+    if (n_images < 1 || max_blobs < 1) return fail(MOCAP_E_INVALID, "n_images=%d max_blobs=%d", n_images, max_blobs);
+    if ((dbg != nullptr) != (dbg_count != nullptr) || (dbg && dbg_cap < 1)) return fail(MOCAP_E_INVALID, "inconsistent debug buffers");
+    if (set_device(c)) return MOCAP_E_HIP;
+    return run_contours(c, mask_dev, n_images, out_xy, out_count, max_blobs, dbg, dbg_count, dbg_cap, (hipStream_t)stream);
+}
+
+int mocap_blob_centroids(mocap_ctx_t c, const void* frames, int n_images, int cam_mod, size_t image_stride, int pitch,
+                         int32_t* out_xy, int32_t* out_count, int max_blobs, void* stream)
+{
+    int rc = check_frames(c, frames, n_images, cam_mod, image_stride, pitch);
+    if (rc) return rc;
+    if (!out_xy || !out_count || max_blobs < 1) return fail(MOCAP_E_INVALID, "bad output arguments");
+    if (set_device(c)) return MOCAP_E_HIP;
+    if ((rc = ensure_mask(c, n_images))) return rc;
+    if ((rc = run_filter(c, frames, n_images, cam_mod, image_stride, pitch, c->mask, (hipStream_t)stream))) return rc;
+    return run_contours(c, c->mask, n_images, out_xy, out_count, max_blobs, nullptr, nullptr, 0, (hipStream_t)stream);
+}
+
+int mocap_undistort_u8(mocap_ctx_t c, int slot, const void* src, void* dst, int spitch, int dpitch, void* stream)
+{
+    if (!c || !src || !dst) return fail(MOCAP_E_INVALID, "null argument");
+    if (slot < 0 || slot >= c->n_slots || c->slot_state[slot] == 0) return fail(MOCAP_E_STATE, "undistort slot %d not set", slot);
+    if (spitch < c->W || dpitch < c->W) return fail(MOCAP_E_INVALID, "pitch < width");
+    if (set_device(c)) return MOCAP_E_HIP;
+    launch_undistort((const uint8_t*)src, (uint8_t*)dst, c->H, c->W, spitch, dpitch, c->maps + (size_t)slot * c->H * c->W, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return MOCAP_OK;
+}
+
+int mocap_image_filter_u8(mocap_ctx_t c, const void* src, void* dst, int spitch, int dpitch, int order, int slot, void* stream)
+{
+    if (!c || !src || !dst) return fail(MOCAP_E_INVALID, "null argument");
+    if (order != 0 && order != 1) return fail(MOCAP_E_INVALID, "order must be 0 (image_filter_gpu) or 1 (image_filter_cpu)");
+    if (spitch < c->W || dpitch < c->W) return fail(MOCAP_E_INVALID, "pitch < width");
+    if (slot >= c->n_slots || (slot >= 0 && c->slot_state[slot] == 0)) return fail(MOCAP_E_STATE, "undistort slot %d not set", slot);
+    if (set_device(c)) return MOCAP_E_HIP;
+    hipStream_t s = (hipStream_t)stream;
+    double ft = floor(c->prm.thresh);
+    int ithresh = ft < -1.0 ? -1 : (ft > 255.0 ? 255 : (int)ft);
+    if (order == 1) {
+        const uint8_t* in = (const uint8_t*)src;
+        int ip = spitch;
+        if (slot >= 0 && c->slot_state[slot] == 2) { // undistort into dst, then filter in a second buffer
+            return fail(MOCAP_E_UNSUPPORTED, "image_filter_cpu order with undistortion: call mocap_undistort_u8 first");
+        }
+        launch_median5(in, (uint8_t*)dst, c->H, c->W, ip, dpitch, ithresh, 1, s);
+        HIP_TRY(hipGetLastError());
+        return MOCAP_OK;
+    }
+    int rc = ensure_mask(c, 1);
+    if (rc) return rc;
+    // the fused kernel with a one-image batch; slot < 0 = no undistortion
+    FilterArgs a;
+    a.src = (const uint8_t*)src; a.image_stride = 0; a.pitch = spitch; a.H = c->H; a.W = c->W;
+    a.aligned4 = (((uintptr_t)src | (uintptr_t)spitch) & 3) == 0;
+    a.mask = c->mask; a.words_per_row = c->wpr; a.cam_mod = 1; a.n_images = 1; a.n_steps = 1;
+    a.map = slot >= 0 ? c->maps + (size_t)slot * c->H * c->W : nullptr;
+    a.thr_mul = ithresh + 1;
+    a.n_strips = (c->W + 239) / 240;
+    int rows = 135;
+    if (c->H < 4 * 32) rows = (c->H + 3) / 4 > 8 ? (c->H + 3) / 4 : 8;
+    a.rows_per_chunk = rows;
+    a.n_cgroups = (c->H + 4 * rows - 1) / (4 * rows);
+    launch_filter_mask(a, slot >= 0 && c->slot_state[slot] == 2, s);
+    HIP_TRY(hipGetLastError());
+    launch_mask_expand(c->mask, c->wpr, (uint8_t*)dst, c->H, c->W, dpitch, s);
+    HIP_TRY(hipGetLastError());
+    return MOCAP_OK;
+}
+
+int mocap_box_blur_u8(mocap_ctx_t c, const void* src, void* dst, int H, int W, int spitch, int dpitch, int ksize, void* stream)
+{
+    if (!c || !src || !dst) return fail(MOCAP_E_INVALID, "null argument");
+    if (H < 1 || W < 1 || spitch < W || dpitch < W || ksize < 1 || ksize > 31) return fail(MOCAP_E_INVALID, "bad geometry");
+    if (set_device(c)) return MOCAP_E_HIP;
+    launch_box_blur((const uint8_t*)src, (uint8_t*)dst, H, W, spitch, dpitch, ksize, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return MOCAP_OK;
+}
+
+int mocap_demosaic_u8(mocap_ctx_t c, const void* bayer, void* bgr, int H, int W, int spitch, void* stream)
+{
+    if (!c || !bayer || !bgr) return fail(MOCAP_E_INVALID, "null argument");
+    if (H < 1 || W < 1 || spitch < W) return fail(MOCAP_E_INVALID, "bad geometry");
+    if (set_device(c)) return MOCAP_E_HIP;
+    launch_demosaic((const uint8_t*)bayer, (uint8_t*)bgr, H, W, spitch, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return MOCAP_OK;
+}
+
+// ---- geometry stage --------------------------------------------------------------------------------------------
+int mocap_correspond(mocap_ctx_t c, const void* pts, const int32_t* counts, int pts_f64, int T, int C, int P, double cutoff,
+                     int max_groups, double* root_xyz, double* root_err, double* root_grp, int32_t* root_idx,
+                     int32_t* order, int32_t* n_roots, void* stream)
+{
+    if (!c || !pts || !counts || !root_xyz || !root_err || !root_grp || !root_idx || !order || !n_roots)
+        return fail(MOCAP_E_INVALID, "null argument");
+    if (T < 1 || C < 1 || C > 32 || P < 1 || P > 255 || max_groups < 1) return fail(MOCAP_E_INVALID, "T=%d C=%d P=%d max_groups=%d", T, C, P, max_groups);
+    if (c->n_cam < C) return fail(MOCAP_E_STATE, "mocap_set_cameras: %d cameras set, %d needed", c->n_cam, C);
+    if (c->n_F < C - 1) return fail(MOCAP_E_STATE, "mocap_set_fundamentals: %d matrices set, %d needed", c->n_F, C - 1);
+    if (set_device(c)) return MOCAP_E_HIP;
+    size_t need = (size_t)T * P * max_groups;
+    if (need > c->scratch_elems) {
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (c->scratch) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c->scratch)); c->scratch = nullptr; c->scratch_elems = 0; }
+        HIP_TRY(hipMalloc(&c->scratch, sizeof(double) * need));
+        c->scratch_elems = need;
+    }
+    CorrArgs a;
+    a.cams = c->cams; a.pts = pts; a.counts = counts; a.pts_f64 = pts_f64; a.T = T; a.C = C; a.P = P;
+    a.cutoff = cutoff; a.max_groups = max_groups; a.root_xyz = root_xyz; a.root_err = root_err; a.root_grp = root_grp;
+    a.root_idx = root_idx; a.order = order; a.n_roots = n_roots; a.scratch = c->scratch;
+    EvPair p; bool on;
+    prof_begin(c, 2, (hipStream_t)stream, p, on);
+    launch_correspond(a, (hipStream_t)stream);
+    prof_end(c, 2, (hipStream_t)stream, p, on);
+    HIP_TRY(hipGetLastError());
+    return MOCAP_OK;
+}
+
+int mocap_triangulate_batch(mocap_ctx_t c, const double* pts, const uint8_t* valid, int N, int C, int compact_k, double* xyz,
+                            int32_t* ok, void* stream)
+{
+    if (!c || !pts || !valid || !xyz || !ok) return fail(MOCAP_E_INVALID, "null argument");
+    if (N < 1 || C < 1 || C > 32) return fail(MOCAP_E_INVALID, "N=%d C=%d", N, C);
+    if (c->n_cam < C) return fail(MOCAP_E_STATE, "mocap_set_cameras: %d cameras set, %d needed", c->n_cam, C);
+    if (set_device(c)) return MOCAP_E_HIP;
+    TriArgs a{c->cams, pts, valid, N, C, compact_k, xyz, ok};
+    launch_triangulate(a, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return MOCAP_OK;
+}
+
+int mocap_reproject_batch(mocap_ctx_t c, const double* pts, const uint8_t* valid, const double* xyz, int N, int C, int compact_k,
+                          double* mse, int32_t* ok, void* stream)
+{
+    if (!c || !pts || !valid || !xyz || !mse || !ok) return fail(MOCAP_E_INVALID, "null argument");
+    if (N < 1 || C < 1 || C > 32) return fail(MOCAP_E_INVALID, "N=%d C=%d", N, C);
+    if (c->n_cam < C) return fail(MOCAP_E_STATE, "mocap_set_cameras: %d cameras set, %d needed", c->n_cam, C);
+    if (set_device(c)) return MOCAP_E_HIP;
+    ReprojArgs a{c->cams, pts, valid, xyz, N, C, compact_k, mse, ok};
+    launch_reproject(a, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return MOCAP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,404 @@
+// geom.hip -- epipolar correspondence, batched N-view DLT triangulation and reprojection error (FP64).
+//
+// Replaces, per time step, reference lib/Helpers.py:178-280 (find_point_correspondance_and_object_points)
+// and its callees triangulate_point(s) (:43-99) and calculate_reprojection_error(s) (:102-143), including
+// the two OpenCV primitives they use (cv.computeCorrespondEpilines :207, cv.projectPoints :133).
+// The library is built with -ffp-contract=off: every product and sum below is a separately rounded FP64
+// (or, where the reference rounds to float32, FP32) operation, as in the NumPy/OpenCV path.
+//
+// Work decomposition: one workgroup per time step.  (root, camera) pairs are scored one per lane; the
+// candidate groups of all roots of the time step (the reference's cartesian expansion) are flattened into one
+// index space and triangulated one group per lane; per-root error means use NumPy's pairwise summation order.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kernels.h"
+
+namespace mocap {
+
+namespace {
+
+constexpr int MAXM = 8; // candidate matches kept per (root, camera)
+
+__device__ double np_block_sum(const double* a, int n)
+{ // numpy pairwise_sum for n <= 128
+    if (n < 8) {
+        double r = 0.;
+        for (int i = 0; i < n; i++) r += a[i];
+        return r;
+    }
+    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+        r0 += a[i]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3];
+        r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; i++) res += a[i];
+    return res;
+}
+
+__device__ double np_pairwise_sum(const double* a, int n)
+{ // the recursion of numpy's pairwise_sum, unrolled onto an explicit stack
+    if (n <= 128) return np_block_sum(a, n);
+    int off[32], len[32], stage[32];
+    double left[32];
+    int sp = 0;
+    double ret = 0.;
+    off[0] = 0; len[0] = n; stage[0] = 0; sp = 1;
+    while (sp > 0) {
+        int t = sp - 1;
+        if (stage[t] == 0) {
+            if (len[t] <= 128) { ret = np_block_sum(a + off[t], len[t]); sp--; continue; }
+            int n2 = len[t] / 2; n2 -= n2 % 8;
+            stage[t] = 1;
+            off[sp] = off[t]; len[sp] = n2; stage[sp] = 0; sp++;
+        } else if (stage[t] == 1) {
+            int n2 = len[t] / 2; n2 -= n2 % 8;
+            left[t] = ret;
+            stage[t] = 2;
+            off[sp] = off[t] + n2; len[sp] = len[t] - n2; stage[sp] = 0; sp++;
+        } else {
+            ret = left[t] + ret;
+            sp--;
+        }
+    }
+    return ret;
+}
+
+// cv.computeCorrespondEpilines for one float32 point
+__device__ void epiline(const double* F, float xf, float yf, float line[3])
+{
+    double x = xf, y = yf;
+    double a = F[0] * x + F[1] * y + F[2];
+    double b = F[3] * x + F[4] * y + F[5];
+    double c = F[6] * x + F[7] * y + F[8];
+    double nu = a * a + b * b;
+    nu = nu ? 1. / sqrt(nu) : 1.;
+    a *= nu; b *= nu; c *= nu;
+    line[0] = (float)a; line[1] = (float)b; line[2] = (float)c;
+}
+
+__device__ double epi_distance(const float line[3], double x, double y)
+{ // reference lib/Helpers.py:217
+    double a = line[0], b = line[1], c = line[2];
+    return fabs(a * x + b * y + c) / sqrt(a * a + b * b);
+}
+
+// eigenvector of the smallest eigenvalue of a symmetric 4x4 (cyclic Jacobi); same rotations as the oracle
+__device__ void smallest_eigvec4(double B[4][4], double v[4])
+{
+    double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0, diag = 0;
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            diag += B[p][p] * B[p][p];
+#pragma unroll
+            for (int q = p + 1; q < 4; q++) off += B[p][q] * B[p][q];
+        }
+        if (off == 0.0 || off <= 1e-40 * diag) break;
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int q = p + 1; q < 4; q++) {
+                double apq = B[p][q];
+                if (apq == 0.0) continue;
+                double theta = (B[q][q] - B[p][p]) / (2.0 * apq);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    double bkp = B[k][p], bkq = B[k][q];
+                    B[k][p] = c * bkp - s * bkq;
+                    B[k][q] = s * bkp + c * bkq;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    double bpk = B[p][k], bqk = B[q][k];
+                    B[p][k] = c * bpk - s * bqk;
+                    B[q][k] = s * bpk + c * bqk;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - s * vkq;
+                    V[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    int m = 0;
+    double best = B[0][0];
+#pragma unroll
+    for (int k = 1; k < 4; k++)
+        if (B[k][k] < best) { best = B[k][k]; m = k; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = m == 0 ? V[k][0] : (m == 1 ? V[k][1] : (m == 2 ? V[k][2] : V[k][3]));
+}
+
+struct DltAcc {
+    double B[4][4];
+    __device__ void clear()
+    {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) B[j][k] = 0.;
+    }
+    // rows  y*P[2]-P[1]  and  P[0]-x*P[2]  of the DLT system, P = K @ [R|t]  (reference lib/Helpers.py:58-73)
+    __device__ void add(const double* K, const double* R, const double* t, double x, double y)
+    {
+        double P[12];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                double s = 0;
+#pragma unroll
+                for (int k = 0; k < 3; k++) s += K[3 * r + k] * (c < 3 ? R[3 * k + c] : t[k]);
+                P[4 * r + c] = s;
+            }
+        double r0[4], r1[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            r0[k] = y * P[8 + k] - P[4 + k];
+            r1[k] = P[k] - x * P[8 + k];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) B[j][k] += r0[j] * r0[k] + r1[j] * r1[k];
+    }
+    __device__ void solve(double X[3])
+    {
+        double v[4];
+        smallest_eigvec4(B, v);
+        X[0] = v[0] / v[3]; X[1] = v[1] / v[3]; X[2] = v[2] / v[3];
+    }
+};
+
+// cv.projectPoints for one float32 object point; squared pixel errors against (px,py)
+__device__ void reproj_sq(const double* K, const double* d, const double* R, const double* t, const float Xf[3],
+                          double px, double py, double& ex, double& ey)
+{
+    double X = Xf[0], Y = Xf[1], Z = Xf[2];
+    double x = R[0] * X + R[1] * Y + R[2] * Z + t[0];
+    double y = R[3] * X + R[4] * Y + R[5] * Z + t[1];
+    double z = R[6] * X + R[7] * Y + R[8] * Z + t[2];
+    z = z ? 1. / z : 1;
+    x *= z; y *= z;
+    double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
+    double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
+    double cdist = 1 + d[0] * r2 + d[1] * r4 + d[4] * r6;
+    double xd = x * cdist + d[2] * a1 + d[3] * a2;
+    double yd = y * cdist + d[2] * a3 + d[3] * a1;
+    float u = (float)(xd * K[0] + K[2]), v = (float)(yd * K[4] + K[5]);
+    double dx = px - (double)u, dy = py - (double)v;
+    ex = dx * dx; ey = dy * dy;
+}
+
+template <typename PT>
+__device__ __forceinline__ void load_pt(const void* base, size_t idx, double& x, double& y)
+{
+    const PT* p = (const PT*)base + 2 * idx;
+    x = (double)p[0]; y = (double)p[1];
+}
+
+} // namespace
+
+template <typename PT>
+__global__ __launch_bounds__(256) void correspond_kernel(CorrArgs a)
+{
+    extern __shared__ unsigned char smem[];
+    const int C = a.C, P = a.P, t = blockIdx.x, tid = threadIdx.x;
+    // LDS carve: nm[P][C] (u8), midx[P][C][MAXM] (u8), G[P] (int), goff[P+1] (int), slot[P] (int)
+    uint8_t* nm = smem;
+    uint8_t* midx = nm + P * C;
+    int* G = (int*)(((uintptr_t)(midx + (size_t)P * C * MAXM) + 7) & ~(uintptr_t)7);
+    int* goff = G + P;
+    int* slot = goff + P + 1;
+    __shared__ int s_err, s_nout;
+
+    const CameraTable* cams = a.cams;
+    const int32_t* cnt = a.counts + (size_t)t * C;
+    const size_t pbase = (size_t)t * C * P;
+    const int n0 = cnt[0] < P ? cnt[0] : P;
+    if (tid == 0) { s_err = 0; s_nout = 0; }
+    __syncthreads();
+
+    // ---- phase 1: per (root, camera) candidate lists, sorted by distance to the epipolar line -----------
+    for (int w = tid; w < n0 * (C - 1); w += blockDim.x) {
+        int j = w / (C - 1), i = 1 + w % (C - 1);
+        double rx, ry;
+        load_pt<PT>(a.pts, pbase + j, rx, ry);
+        float line[3];
+        epiline(cams->F[i - 1], (float)rx, (float)ry, line);
+        double md[MAXM];
+        int mi[MAXM], k = 0, ni = cnt[i] < P ? cnt[i] : P;
+        bool over = false;
+        for (int p = 0; p < ni; p++) {
+            double x, y;
+            load_pt<PT>(a.pts, pbase + (size_t)i * P + p, x, y);
+            double d = epi_distance(line, x, y);
+            if (d < a.cutoff) {
+                if (k == MAXM) { over = true; break; }
+                int q = k++; // stable insertion by distance
+                while (q > 0 && md[q - 1] > d) { md[q] = md[q - 1]; mi[q] = mi[q - 1]; q--; }
+                md[q] = d; mi[q] = p;
+            }
+        }
+        if (over) atomicMax(&s_err, 1);
+        nm[j * C + i] = (uint8_t)k;
+        for (int q = 0; q < k; q++) midx[((size_t)j * C + i) * MAXM + q] = (uint8_t)mi[q];
+    }
+    __syncthreads();
+    // ---- group counts and offsets ---------------------------------------------------------------------------
+    for (int j = tid; j < n0; j += blockDim.x) {
+        long g = C >= 2 ? 1 : 0;
+        for (int i = 1; i < C; i++) {
+            g *= nm[j * C + i];
+            if (g > a.max_groups) { atomicMax(&s_err, 1); g = 0; break; }
+        }
+        G[j] = (int)g;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0, no = 0;
+        for (int j = 0; j < n0; j++) {
+            goff[j] = acc; acc += G[j];
+            slot[j] = G[j] > 0 ? no++ : -1;
+        }
+        goff[n0] = acc;
+        s_nout = no;
+    }
+    __syncthreads();
+    if (s_err) {
+        if (tid == 0) a.n_roots[t] = CORR_ERR_GROUPS;
+        return;
+    }
+    // ---- phase 2: one candidate group per lane: DLT + reprojection error --------------------------------
+    const int total = goff[n0];
+    for (int w = tid; w < total; w += blockDim.x) {
+        int lo = 0, hi = n0 - 1; // root owning flat group index w
+        while (lo < hi) {
+            int mid = (lo + hi + 1) >> 1;
+            if (goff[mid] <= w) lo = mid; else hi = mid - 1;
+        }
+        while (G[lo] == 0) lo++; // skip dead roots sharing the offset
+        int j = lo, g = w - goff[j], rem = g;
+        double gx[32], gy[32];
+        load_pt<PT>(a.pts, pbase + j, gx[0], gy[0]);
+        DltAcc acc;
+        acc.clear();
+        acc.add(cams->K[0], cams->R[0], cams->t[0], gx[0], gy[0]);
+        for (int i = 1; i < C; i++) { // camera 1 is the fastest-varying digit (reference lib/Helpers.py:239-245)
+            int n_i = nm[j * C + i], dgt = rem % n_i;
+            rem /= n_i;
+            int p = midx[((size_t)j * C + i) * MAXM + dgt];
+            load_pt<PT>(a.pts, pbase + (size_t)i * P + p, gx[i], gy[i]);
+            acc.add(cams->K[i], cams->R[i], cams->t[i], gx[i], gy[i]);
+        }
+        double X[3];
+        acc.solve(X);
+        float Xf[3] = {(float)X[0], (float)X[1], (float)X[2]};
+        double e[64];
+        for (int i = 0; i < C; i++) reproj_sq(cams->K[i], cams->dist[i], cams->R[i], cams->t[i], Xf, gx[i], gy[i], e[2 * i], e[2 * i + 1]);
+        double mse = np_block_sum(e, 2 * C) / (double)(2 * C);
+        a.scratch[((size_t)t * P + j) * a.max_groups + g] = mse;
+        if (g == 0) {
+            int o = slot[j];
+            size_t ro = (size_t)t * P + o;
+            a.root_xyz[ro * 3] = X[0]; a.root_xyz[ro * 3 + 1] = X[1]; a.root_xyz[ro * 3 + 2] = X[2];
+            for (int i = 0; i < C; i++) { a.root_grp[(ro * C + i) * 2] = gx[i]; a.root_grp[(ro * C + i) * 2 + 1] = gy[i]; }
+            a.root_idx[ro] = j;
+        }
+    }
+    __syncthreads(); // scratch is read back by other lanes of this workgroup
+    __threadfence_block();
+    // ---- phase 3: per-root mean over its groups (NumPy pairwise order), then argsort ---------------------
+    for (int j = tid; j < n0; j += blockDim.x) {
+        if (G[j] == 0) continue;
+        const double* e = a.scratch + ((size_t)t * P + j) * a.max_groups;
+        a.root_err[(size_t)t * P + slot[j]] = np_pairwise_sum(e, G[j]) / (double)G[j];
+    }
+    __syncthreads();
+    __threadfence_block();
+    const int nout = s_nout;
+    for (int o = tid; o < nout; o += blockDim.x) {
+        double eo = a.root_err[(size_t)t * P + o];
+        int rank = 0;
+        for (int q = 0; q < nout; q++) {
+            double eq = a.root_err[(size_t)t * P + q];
+            rank += (eq < eo) || (eq == eo && q < o);
+        }
+        a.order[(size_t)t * P + rank] = o;
+    }
+    if (tid == 0) a.n_roots[t] = nout;
+}
+
+// triangulate_point over a batch (reference lib/Helpers.py:43-84): invalid entries dropped, fewer than two
+// left -> not triangulated; with compact_k the intrinsics are taken by position after the drop (:59-61)
+__global__ void triangulate_kernel(TriArgs a)
+{
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= a.N) return;
+    const CameraTable* cams = a.cams;
+    DltAcc acc;
+    acc.clear();
+    int m = 0;
+    for (int c = 0; c < a.C; c++) {
+        if (!a.valid[(size_t)n * a.C + c]) continue;
+        int ki = a.compact_k ? m : c;
+        acc.add(cams->K[ki], cams->R[c], cams->t[c], a.pts[((size_t)n * a.C + c) * 2], a.pts[((size_t)n * a.C + c) * 2 + 1]);
+        m++;
+    }
+    if (m <= 1) { a.ok[n] = 0; return; }
+    double X[3];
+    acc.solve(X);
+    a.xyz[3 * n] = X[0]; a.xyz[3 * n + 1] = X[1]; a.xyz[3 * n + 2] = X[2];
+    a.ok[n] = 1;
+}
+
+// calculate_reprojection_error over a batch (reference lib/Helpers.py:113-143)
+__global__ void reproject_kernel(ReprojArgs a)
+{
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= a.N) return;
+    const CameraTable* cams = a.cams;
+    float Xf[3] = {(float)a.xyz[3 * n], (float)a.xyz[3 * n + 1], (float)a.xyz[3 * n + 2]};
+    double e[64];
+    int m = 0;
+    for (int c = 0; c < a.C; c++) {
+        if (!a.valid[(size_t)n * a.C + c]) continue;
+        int ki = a.compact_k ? m : c;
+        reproj_sq(cams->K[ki], cams->dist[ki], cams->R[c], cams->t[c], Xf, a.pts[((size_t)n * a.C + c) * 2],
+                  a.pts[((size_t)n * a.C + c) * 2 + 1], e[2 * m], e[2 * m + 1]);
+        m++;
+    }
+    if (m <= 1) { a.ok[n] = 0; return; }
+    a.mse[n] = np_block_sum(e, 2 * m) / (double)(2 * m);
+    a.ok[n] = 1;
+}
+
+size_t correspond_smem_bytes(int P, int C)
+{
+    return (size_t)P * C + (size_t)P * C * MAXM + 8 + sizeof(int) * (3 * (size_t)P + 2);
+}
+
+void launch_correspond(const CorrArgs& a, hipStream_t s)
+{
+    size_t sm = correspond_smem_bytes(a.P, a.C);
+    if (a.pts_f64)
+        hipLaunchKernelGGL(correspond_kernel<double>, dim3(a.T), dim3(256), sm, s, a);
+    else
+        hipLaunchKernelGGL(correspond_kernel<int32_t>, dim3(a.T), dim3(256), sm, s, a);
+}
+void launch_triangulate(const TriArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(triangulate_kernel, dim3((a.N + 63) / 64), dim3(64), 0, s, a);
+}
+void launch_reproject(const ReprojArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(reproject_kernel, dim3((a.N + 63) / 64), dim3(64), 0, s, a);
+}
+
+} // namespace mocap

@@ -1,0 +1,119 @@
+// kernels.h -- internal launch interface between the C-ABI (abi.hip) and the HIP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mocap {
+
+struct FilterArgs {
+    const uint8_t* src;   // images, image_stride bytes apart, rows `pitch` bytes apart
+    size_t image_stride;
+    int pitch, H, W;
+    int aligned4;         // src base, pitch and image_stride are multiples of 4
+    uint32_t* mask;       // [n_images][H][words_per_row], bit b of word k = pixel 32k+b
+    int words_per_row;
+    const uint32_t* map;  // [cam_mod][H][W] packed (dx | dy<<16) in 1/32 px (remap variant only)
+    int cam_mod;          // undistort slot of image n = n % cam_mod
+    int n_images, n_steps; // n_steps = ceil(n_images / cam_mod)
+    int thr_mul;          // floor(thresh)+1: blurred > thresh  <=>  S >= thr_mul * taps
+    int rows_per_chunk, n_strips, n_cgroups;
+};
+
+struct MapArgs {
+    double K[9], dist[5];
+    int H, W;
+    uint32_t* map;   // [H][W]
+    uint32_t* flags; // bit0: map is not the identity, bit1: displacement not representable
+};
+
+// one border found by the contour kernel (also the debug record compared with the oracle in tests)
+struct ContourRec {
+    int32_t key;       // raster index (y*(W+1)+x) of the scan position that discovers the border
+    int32_t is_hole;
+    int32_t sx, sy;    // first border pixel
+    int32_t npts;      // CHAIN_APPROX_SIMPLE vertex count
+    int32_t steps;
+    int64_t a00, a10, a01;
+    double area, perimeter;
+    int32_t kept, cx, cy;
+    int32_t link;      // rec index of the border owning the crack left of the start (-1 frame), see kernel
+    int32_t parent;    // rec index of the parent border, -1 = frame
+    int32_t order;     // position among the kept contours in cv.findContours order, -1 if not kept
+};
+
+struct ContourArgs {
+    const uint32_t* mask;
+    int words_per_row, H, W, n_images;
+    int32_t* out_xy;     // [n_images][max_blobs][2]
+    int32_t* out_count;  // [n_images]  number of image points (may exceed max_blobs: truncated), <0 = error
+    int max_blobs;
+    double min_area, min_circ;
+    ContourRec* dbg;     // optional [n_images][dbg_cap]
+    int32_t* dbg_count;  // optional [n_images]
+    int dbg_cap;
+    int max_steps;
+};
+
+enum { BLOB_ERR_CANDIDATES = -2, BLOB_ERR_CONTOURS = -3, BLOB_ERR_STEPS = -4, BLOB_ERR_DEPTH = -5 };
+
+void launch_filter_mask(const FilterArgs& a, bool remap, hipStream_t s);
+void launch_undistort_map(const MapArgs& m, hipStream_t s);
+void launch_contours(const ContourArgs& a, hipStream_t s);
+void launch_box_blur(const uint8_t* src, uint8_t* dst, int H, int W, int sp, int dp, int ksize, hipStream_t s);
+void launch_undistort(const uint8_t* src, uint8_t* dst, int H, int W, int sp, int dp, const uint32_t* map, hipStream_t s);
+void launch_mask_expand(const uint32_t* mask, int wpr, uint8_t* dst, int H, int W, int dp, hipStream_t s);
+void launch_median5(const uint8_t* src, uint8_t* dst, int H, int W, int sp, int dp, int ithresh, int apply, hipStream_t s);
+void launch_demosaic(const uint8_t* bayer, uint8_t* bgr, int H, int W, int sp, hipStream_t s);
+
+// ---- geometry ----
+struct CameraTable {           // device-resident, written by mocap_set_cameras / mocap_set_fundamentals
+    double K[32][9], dist[32][5], R[32][9], t[32][3];
+    double F[31][9];           // F[i-1]: camera-0 pixel -> epipolar line in camera i
+    int n_cam, n_F;
+};
+
+struct CorrArgs {
+    const CameraTable* cams;
+    const void* pts;           // [T][C][P][2] int32 or float64
+    const int32_t* counts;     // [T][C]
+    int pts_f64;
+    int T, C, P;               // P = capacity per camera
+    double cutoff;
+    int max_groups;            // per root
+    // per time step, per camera-0 root
+    double* root_xyz;          // [T][P][3]
+    double* root_err;          // [T][P]  mean reprojection error over the root's groups
+    double* root_grp;          // [T][P][C][2] first group
+    int32_t* root_idx;         // [T][P]  camera-0 index of the j-th surviving root
+    int32_t* order;            // [T][P]  argsort(root_err)
+    int32_t* n_roots;          // [T]  (<0 = error)
+    double* scratch;           // [T][P][max_groups] per-group errors
+};
+
+struct TriArgs {
+    const CameraTable* cams;
+    const double* pts;         // [N][C][2]
+    const uint8_t* valid;      // [N][C]
+    int N, C;
+    int compact_k;             // intrinsics indexed by position after dropping invalid entries (reference quirk)
+    double* xyz;               // [N][3]
+    int32_t* ok;               // [N] 1 = triangulated
+};
+
+struct ReprojArgs {
+    const CameraTable* cams;
+    const double* pts;         // [N][C][2]
+    const uint8_t* valid;      // [N][C]
+    const double* xyz;         // [N][3]
+    int N, C, compact_k;
+    double* mse;               // [N]
+    int32_t* ok;               // [N]
+};
+
+enum { CORR_ERR_GROUPS = -2 };
+
+void launch_correspond(const CorrArgs& a, hipStream_t s);
+void launch_triangulate(const TriArgs& a, hipStream_t s);
+void launch_reproject(const ReprojArgs& a, hipStream_t s);
+
+} // namespace mocap

@@ -1,0 +1,248 @@
+"""Host side of the hot path: a thin object over the C-ABI context.
+
+PyTorch is used only as the device allocator / stream provider (tensors are passed to the library as raw
+pointers); no torch operator touches the data.  Mirrors what the reference's callers do around
+lib.ImageOperations._find_dot and lib.Helpers.find_point_correspondance_and_object_points
+(reference RealtimeTracking_FLIR.py:95-143,157-209) for whole batches of frames.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _abi
+
+MAX_BLOBS = 128       # centroid record capacity per camera image
+REC_INTS = 2 + 2 * MAX_BLOBS  # int32 record: count, pad, xy[MAX_BLOBS][2]
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dbl(a, n):
+    a = np.ascontiguousarray(a, np.float64).reshape(-1)
+    assert a.size == n, (a.size, n)
+    return a, a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class MocapContext:
+    """One GPU, one image geometry.  Not a singleton: one per camera thread or per process is fine."""
+
+    def __init__(self, width, height, n_slots=1, device=0):
+        self.lib = _abi.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("mocapv2_amd needs a ROCm GPU (torch.cuda.is_available() is False); no CPU fallback")
+        self.device = torch.device("cuda", device)
+        self.width, self.height, self.n_slots = int(width), int(height), int(n_slots)
+        h = C.c_void_p()
+        _abi.check(self.lib.mocap_ctx_create(device, self.width, self.height, self.n_slots, C.byref(h)))
+        self._h = h
+        self._cam_key = None
+        self._f_key = None
+        self._und_key = {}
+        self.identity = {}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.mocap_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- set-up -------------------------------------------------------------------------------------------
+    def set_blob_params(self, thresh=255 * 0.85, min_area=500.0, min_circ=0.5, ksize=5, median=5):
+        p = _abi.BlobParams(ksize, median, thresh, min_area, min_circ)
+        _abi.check(self.lib.mocap_set_blob_params(self._h, C.byref(p)))
+
+    def set_undistort(self, slot, K, dist):
+        K, Kp = _dbl(K, 9)
+        d, dp = _dbl(dist, 5)
+        key = K.tobytes() + d.tobytes()
+        if self._und_key.get(slot) == key:
+            return self.identity[slot]
+        ident = C.c_int(0)
+        _abi.check(self.lib.mocap_set_undistort(self._h, slot, Kp, dp, C.byref(ident)))
+        self._und_key[slot] = key
+        self.identity[slot] = bool(ident.value)
+        return self.identity[slot]
+
+    def set_cameras(self, K, dist, R, t):
+        n = len(K)
+        K, Kp = _dbl(K, 9 * n)
+        d, dp = _dbl(dist, 5 * n)
+        R, Rp = _dbl(R, 9 * n)
+        t, tp = _dbl(t, 3 * n)
+        key = K.tobytes() + d.tobytes() + R.tobytes() + t.tobytes()
+        if key != self._cam_key:
+            _abi.check(self.lib.mocap_set_cameras(self._h, n, Kp, dp, Rp, tp))
+            self._cam_key = key
+        self.n_cam = n
+
+    def set_fundamentals(self, F):
+        F = np.ascontiguousarray(F, np.float64).reshape(-1, 9)
+        key = F.tobytes()
+        if key != self._f_key:
+            _abi.check(self.lib.mocap_set_fundamentals(self._h, len(F), F.ctypes.data_as(C.POINTER(C.c_double))))
+            self._f_key = key
+
+    def sync(self):
+        _abi.check(self.lib.mocap_sync(self._h, _stream()))
+
+    # ---- blob stage ------------------------------------------------------------------------------------------
+    def _frames(self, frames):
+        assert frames.is_cuda and frames.dtype == torch.uint8
+        assert frames.shape[-2:] == (self.height, self.width), (frames.shape, self.height, self.width)
+        assert frames.stride(-1) == 1
+        n = int(np.prod(frames.shape[:-2])) if frames.dim() > 2 else 1
+        pitch = frames.stride(-2)
+        flat = frames.reshape(n, self.height, self.width) if frames.is_contiguous() else frames
+        assert flat.dim() == 3
+        stride = flat.stride(0) if n > 1 else pitch * self.height
+        return flat, n, stride, pitch
+
+    def blob_centroids(self, frames, cam_mod=1, max_blobs=MAX_BLOBS, out_xy=None, out_count=None):
+        """_find_dot over uint8 frames [..., H, W] resident on the GPU (image n uses undistort slot n % cam_mod).
+        Returns (xy int32 [n, max_blobs, 2], count int32 [n]) device tensors."""
+        flat, n, stride, pitch = self._frames(frames)
+        if out_xy is None:
+            out_xy = torch.empty((n, max_blobs, 2), dtype=torch.int32, device=self.device)
+        if out_count is None:
+            out_count = torch.empty((n,), dtype=torch.int32, device=self.device)
+        _abi.check(self.lib.mocap_blob_centroids(self._h, _ptr(flat), n, cam_mod, stride, pitch, _ptr(out_xy),
+                                                 _ptr(out_count), max_blobs, _stream()))
+        return out_xy, out_count
+
+    def filter_mask(self, frames, cam_mod=1, mask=None):
+        flat, n, stride, pitch = self._frames(frames)
+        wpr = (self.width + 31) // 32
+        if mask is None:
+            mask = torch.zeros((n, self.height, wpr), dtype=torch.int32, device=self.device)
+        _abi.check(self.lib.mocap_filter_mask(self._h, _ptr(flat), n, cam_mod, stride, pitch, _ptr(mask), _stream()))
+        return mask
+
+    def contours_from_mask(self, mask, max_blobs=MAX_BLOBS, debug_cap=0):
+        n = mask.shape[0]
+        xy = torch.empty((n, max_blobs, 2), dtype=torch.int32, device=self.device)
+        cnt = torch.empty((n,), dtype=torch.int32, device=self.device)
+        dbg = dbg_n = None
+        if debug_cap:
+            dbg = torch.zeros((n, debug_cap, C.sizeof(_abi.Contour)), dtype=torch.uint8, device=self.device)
+            dbg_n = torch.zeros((n,), dtype=torch.int32, device=self.device)
+        _abi.check(self.lib.mocap_contours_from_mask(self._h, _ptr(mask), n, _ptr(xy), _ptr(cnt), max_blobs, _ptr(dbg),
+                                                     _ptr(dbg_n), debug_cap, _stream()))
+        if not debug_cap:
+            return xy, cnt
+        raw = dbg.cpu().numpy()
+        counts = dbg_n.cpu().numpy()
+        recs = []
+        for i in range(n):
+            arr = (_abi.Contour * debug_cap).from_buffer_copy(raw[i].tobytes())
+            recs.append([{k: getattr(arr[j], k) for k, _ in _abi.Contour._fields_} for j in range(min(counts[i], debug_cap))])
+        return xy, cnt, recs
+
+    def image_filter(self, img, order=0, slot=-1):
+        """image_filter_gpu (order 0) / image_filter_cpu (order 1) on one device image -> {0,255} device image."""
+        assert img.is_cuda and img.dtype == torch.uint8 and img.shape == (self.height, self.width)
+        out = torch.empty_like(img, memory_format=torch.contiguous_format)
+        _abi.check(self.lib.mocap_image_filter_u8(self._h, _ptr(img), _ptr(out), img.stride(0), out.stride(0), order, slot,
+                                                  _stream()))
+        return out
+
+    def undistort(self, img, slot=0):
+        assert img.is_cuda and img.dtype == torch.uint8 and img.shape == (self.height, self.width)
+        out = torch.empty_like(img, memory_format=torch.contiguous_format)
+        _abi.check(self.lib.mocap_undistort_u8(self._h, slot, _ptr(img), _ptr(out), img.stride(0), out.stride(0), _stream()))
+        return out
+
+    def box_blur(self, img, ksize=5):
+        assert img.is_cuda and img.dtype == torch.uint8 and img.dim() == 2
+        out = torch.empty_like(img, memory_format=torch.contiguous_format)
+        _abi.check(self.lib.mocap_box_blur_u8(self._h, _ptr(img), _ptr(out), img.shape[0], img.shape[1], img.stride(0),
+                                              out.stride(0), ksize, _stream()))
+        return out
+
+    def demosaic(self, bayer):
+        assert bayer.is_cuda and bayer.dtype == torch.uint8 and bayer.dim() == 2
+        out = torch.empty(bayer.shape + (3,), dtype=torch.uint8, device=self.device)
+        _abi.check(self.lib.mocap_demosaic_u8(self._h, _ptr(bayer), _ptr(out), bayer.shape[0], bayer.shape[1],
+                                              bayer.stride(0), _stream()))
+        return out
+
+    # ---- geometry stage ----------------------------------------------------------------------------------------
+    def correspond(self, pts, counts, cutoff=10.0, max_groups=4096, out=None):
+        """pts [T, C, P, 2] (int32 or float64), counts [T, C] int32, both on the GPU -> dict of device tensors."""
+        assert pts.is_cuda and pts.is_contiguous() and counts.is_contiguous() and counts.dtype == torch.int32
+        T, Cn, P, _ = pts.shape
+        f64 = pts.dtype == torch.float64
+        assert f64 or pts.dtype == torch.int32
+        dev = self.device
+        if out is None:
+            out = {"xyz": torch.empty((T, P, 3), dtype=torch.float64, device=dev),
+                   "err": torch.empty((T, P), dtype=torch.float64, device=dev),
+                   "grp": torch.empty((T, P, Cn, 2), dtype=torch.float64, device=dev),
+                   "root": torch.empty((T, P), dtype=torch.int32, device=dev),
+                   "order": torch.empty((T, P), dtype=torch.int32, device=dev),
+                   "n": torch.empty((T,), dtype=torch.int32, device=dev)}
+        _abi.check(self.lib.mocap_correspond(self._h, _ptr(pts), _ptr(counts), int(f64), T, Cn, P, cutoff, max_groups,
+                                             _ptr(out["xyz"]), _ptr(out["err"]), _ptr(out["grp"]), _ptr(out["root"]),
+                                             _ptr(out["order"]), _ptr(out["n"]), _stream()))
+        return out
+
+    def triangulate_batch(self, pts, valid, compact_k=True):
+        """pts [N, C, 2] float64 host array, valid [N, C] -> (xyz [N,3], ok [N]) host arrays."""
+        pts = np.ascontiguousarray(pts, np.float64)
+        N, Cn = pts.shape[:2]
+        d_pts = torch.from_numpy(pts).to(self.device)
+        d_val = torch.from_numpy(np.ascontiguousarray(valid, np.uint8).reshape(N, Cn)).to(self.device)
+        xyz = torch.zeros((N, 3), dtype=torch.float64, device=self.device)
+        ok = torch.zeros((N,), dtype=torch.int32, device=self.device)
+        _abi.check(self.lib.mocap_triangulate_batch(self._h, _ptr(d_pts), _ptr(d_val), N, Cn, int(compact_k), _ptr(xyz),
+                                                    _ptr(ok), _stream()))
+        return xyz.cpu().numpy(), ok.cpu().numpy()
+
+    def reproject_batch(self, pts, valid, xyz, compact_k=True):
+        pts = np.ascontiguousarray(pts, np.float64)
+        N, Cn = pts.shape[:2]
+        d_pts = torch.from_numpy(pts).to(self.device)
+        d_val = torch.from_numpy(np.ascontiguousarray(valid, np.uint8).reshape(N, Cn)).to(self.device)
+        d_xyz = torch.from_numpy(np.ascontiguousarray(xyz, np.float64).reshape(N, 3)).to(self.device)
+        mse = torch.zeros((N,), dtype=torch.float64, device=self.device)
+        ok = torch.zeros((N,), dtype=torch.int32, device=self.device)
+        _abi.check(self.lib.mocap_reproject_batch(self._h, _ptr(d_pts), _ptr(d_val), _ptr(d_xyz), N, Cn, int(compact_k),
+                                                  _ptr(mse), _ptr(ok), _stream()))
+        return mse.cpu().numpy(), ok.cpu().numpy()
+
+    # ---- profiling -----------------------------------------------------------------------------------------------
+    def profile(self, on=True):
+        _abi.check(self.lib.mocap_profile_enable(self._h, int(on)))
+
+    def profile_read(self):
+        ms = [C.c_double(0) for _ in range(3)]
+        n = [C.c_int(0) for _ in range(3)]
+        _abi.check(self.lib.mocap_profile_read(self._h, C.byref(ms[0]), C.byref(n[0]), C.byref(ms[1]), C.byref(n[1]),
+                                               C.byref(ms[2]), C.byref(n[2])))
+        return {"filter_ms": ms[0].value, "filter_launches": n[0].value, "contour_ms": ms[1].value,
+                "contour_launches": n[1].value, "corr_ms": ms[2].value, "corr_launches": n[2].value}
+
+
+_contexts = {}
+
+
+def default_context(width=1, height=1, n_slots=1, device=None):
+    """Process-wide context cache keyed by geometry (the drop-in modules under mocapv2_amd.lib use it)."""
+    if device is None:
+        device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    key = (int(width), int(height), int(n_slots), int(device))
+    ctx = _contexts.get(key)
+    if ctx is None:
+        ctx = _contexts[key] = MocapContext(width, height, n_slots, device)
+    return ctx

@@ -1,0 +1,180 @@
+"""Parity of the HIP blob path (through the C-ABI) with the CPU oracle: bit-exact masks, contours, centroids."""
+import numpy as np
+import pytest
+
+import oracle
+from mocapv2_amd.synth import MILD_DIST, ZERO_DIST, Scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+def make_ctx(W, H, K=None, dist=None, n_slots=1):
+    from mocapv2_amd.engine import MocapContext
+    ctx = MocapContext(W, H, n_slots)
+    K = np.array([[0.7 * W, 0, W / 2.0], [0, 0.7 * W, H / 2.0], [0, 0, 1]]) if K is None else K
+    ident = ctx.set_undistort(0, K, np.zeros(5) if dist is None else dist)
+    return ctx, K, ident
+
+
+def rand_frames(rng, n, H, W, bright=0.35, blobs=3):
+    img = rng.integers(0, 200, (n, H, W), dtype=np.uint8)
+    img[rng.random((n, H, W)) < bright] = 255
+    yy, xx = np.mgrid[0:H, 0:W]
+    for i in range(n):
+        for _ in range(blobs):
+            cx, cy, r = rng.uniform(-5, W + 5), rng.uniform(-5, H + 5), rng.uniform(3, max(4, min(H, W) / 4))
+            img[i][(xx - cx) ** 2 + (yy - cy) ** 2 <= r * r] = 255
+    return img
+
+
+SIZES = [(1, 1), (5, 3), (7, 9), (31, 17), (33, 40), (64, 64), (239, 20), (240, 33), (241, 50), (250, 130), (257, 140),
+         (481, 31), (500, 300), (960, 540)]
+
+
+@pytest.mark.parametrize("W,H", SIZES)
+def test_filter_mask_identity(torch_cuda, W, H):
+    from gpu_util import unpack_mask
+    torch = torch_cuda
+    rng = np.random.default_rng(W * 1000 + H)
+    frames = rand_frames(rng, 3, H, W)
+    ctx, K, ident = make_ctx(W, H)
+    assert ident
+    mask = ctx.filter_mask(torch.from_numpy(frames).cuda())
+    got, pad = unpack_mask(mask, W)
+    assert not pad.any()
+    for i in range(3):
+        exp = oracle.image_filter(frames[i], 0) != 0
+        assert np.array_equal(got[i], exp), f"image {i}: {np.argwhere(got[i] != exp)[:5]}"
+
+
+@pytest.mark.parametrize("W,H", [(64, 48), (250, 130), (500, 300), (960, 540)])
+@pytest.mark.parametrize("scale", [1.0, 4.0])
+def test_filter_mask_remap(torch_cuda, W, H, scale):
+    from gpu_util import unpack_mask
+    torch = torch_cuda
+    rng = np.random.default_rng(W + H)
+    frames = rand_frames(rng, 2, H, W, bright=0.2, blobs=6)
+    dist = np.array(MILD_DIST) * scale
+    ctx, K, ident = make_ctx(W, H, dist=dist)
+    assert not ident
+    # the device-built map equals the oracle's: undistorted images identical, pixel for pixel
+    und = ctx.undistort(torch.from_numpy(frames[0]).cuda()).cpu().numpy()
+    assert np.array_equal(und, oracle.undistort(frames[0], K, dist))
+    got, _ = unpack_mask(ctx.filter_mask(torch.from_numpy(frames).cuda()), W)
+    for i in range(2):
+        exp = oracle.image_filter(oracle.undistort(frames[i], K, dist), 0) != 0
+        assert np.array_equal(got[i], exp)
+
+
+def test_filter_mask_unaligned_pitch_and_threshold_variants(torch_cuda):
+    from gpu_util import unpack_mask
+    torch = torch_cuda
+    rng = np.random.default_rng(5)
+    H, W = 70, 123
+    big = torch.from_numpy(rand_frames(rng, 2, H, W + 5)).cuda()
+    view = big[:, :, 1:W + 1]  # pitch W+5, base offset 1: the byte-load path
+    ctx, K, _ = make_ctx(W, H)
+    for thresh in [255 * 0.85, 100.0, 0.0, 254.5, 255.0, 300.0, -5.0]:
+        ctx.set_blob_params(thresh=thresh)
+        got, _ = unpack_mask(ctx.filter_mask(view), W)
+        for i in range(2):
+            exp = oracle.image_filter(view[i].cpu().numpy(), 0, thresh=thresh) != 0
+            assert np.array_equal(got[i], exp), thresh
+
+
+def structured_mask(rng, H, W, n=10):
+    yy, xx = np.mgrid[0:H, 0:W]
+    m = np.zeros((H, W), bool)
+    for _ in range(n):
+        cx, cy, r = rng.uniform(0, W), rng.uniform(0, H), rng.uniform(4, min(H, W) / 3)
+        d2 = (xx - cx) ** 2 + (yy - cy) ** 2
+        m |= d2 <= r * r
+        if rng.random() < 0.6:
+            m &= ~(d2 <= (0.7 * r) ** 2)
+            if rng.random() < 0.6:
+                m |= d2 <= (0.4 * r) ** 2
+                if rng.random() < 0.5:
+                    m &= ~(d2 <= (0.2 * r) ** 2)
+    return (m * 255).astype(np.uint8)
+
+
+def check_against_oracle(mask, recs, xy, count, min_area, min_circ, max_blobs):
+    """Every border the kernel found == every border cv.findContours would list (per the oracle), with the same
+    measurements, the same parent, and the kept ones in the same order."""
+    H, W = mask.shape
+    table = oracle.find_contours(mask, min_area=min_area, min_circ=min_circ)
+    for c in table:  # discovery position: the start pixel, or the background pixel right of it for a hole
+        c["key"] = c["oy"] * (W + 1) + c["ox"] + (1 if c["is_hole"] else 0)
+    by_key = {(r["key"], r["is_hole"]): r for r in recs}
+    assert len(recs) == len(table) == len(by_key)
+    for c in table:
+        r = by_key[(c["key"], c["is_hole"])]
+        for f in ("a00", "a10", "a01", "npts", "steps", "kept", "cx", "cy"):
+            assert r[f] == c[f], (f, r, c)
+        assert r["area"] == c["area"] and r["perimeter"] == c["perimeter"]
+        assert (r["sx"], r["sy"]) == (c["ox"], c["oy"])
+        assert (c["a00"] > 0) == bool(c["is_hole"]) or c["a00"] == 0  # orientation tells the border kind
+        exp_parent = None if c["parent_order"] < 0 else (table[c["parent_order"]]["key"], table[c["parent_order"]]["is_hole"])
+        got_parent = None if r["parent"] < 0 else (recs[r["parent"]]["key"], recs[r["parent"]]["is_hole"])
+        assert exp_parent == got_parent, (c, r)
+    kept = [c for c in table if c["kept"]]
+    assert count == len(kept)
+    for j, c in enumerate(kept):
+        assert by_key[(c["key"], c["is_hole"])]["order"] == j
+        if j < max_blobs:
+            assert list(xy[j]) == [c["cx"], c["cy"]]
+    return len(table), len(kept)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_contours_match_oracle(torch_cuda, seed):
+    from gpu_util import pack_mask
+    from mocapv2_amd.engine import MocapContext
+    rng = np.random.default_rng(seed)
+    H, W = [(40, 70), (64, 64), (90, 130), (33, 31)][seed % 4]
+    if seed % 3 == 0:
+        masks = [((rng.random((H, W)) < p) * 255).astype(np.uint8) for p in (0.03, 0.9, 0.97)]
+    else:
+        masks = [structured_mask(rng, H, W, n=rng.integers(2, 9)) for _ in range(3)]
+    masks.append(np.zeros((H, W), np.uint8))
+    masks.append(np.full((H, W), 255, np.uint8))
+    ctx = MocapContext(W, H)
+    ctx.set_blob_params(min_area=20.0, min_circ=0.3)  # small gates so that many contours are kept
+    xy, cnt, recs = ctx.contours_from_mask(pack_mask(np.stack(masks)), max_blobs=128, debug_cap=384)
+    xy, cnt = xy.cpu().numpy(), cnt.cpu().numpy()
+    seen = 0
+    for i, m in enumerate(masks):
+        if cnt[i] < 0:  # capacity overflow is reported, never silent
+            assert len(oracle.find_contours(m)) > 100, cnt[i]
+            continue
+        n_all, n_kept = check_against_oracle(m, recs[i], xy[i], cnt[i], 20.0, 0.3, 128)
+        seen += n_all
+    assert seen > 0
+
+
+@pytest.mark.parametrize("dist", [ZERO_DIST, MILD_DIST], ids=["nodist", "mild"])
+def test_find_dot_synthetic_frames(torch_cuda, dist):
+    torch = torch_cuda
+    from mocapv2_amd.engine import MocapContext
+    sc = Scene(3, width=960, height=540, dist=dist)
+    frames = sc.render_batch(seed=42, n_steps=3, n_markers=6, radius_range=(16, 22), salt=0.001)  # [3,3,H,W]
+    ctx = MocapContext(960, 540, n_slots=3)
+    for s in range(3):
+        ctx.set_undistort(s, sc.K, sc.dist)
+    xy, cnt = ctx.blob_centroids(torch.from_numpy(frames).cuda(), cam_mod=3)
+    xy, cnt = xy.cpu().numpy(), cnt.cpu().numpy()
+    flat = frames.reshape(-1, 540, 960)
+    total = 0
+    for i in range(len(flat)):
+        exp = oracle.find_dot(flat[i], sc.K, sc.dist)
+        assert cnt[i] == len(exp)
+        assert xy[i, :cnt[i]].tolist() == exp
+        total += len(exp)
+    assert total >= 40  # the scene really contains detectable markers

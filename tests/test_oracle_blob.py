@@ -167,9 +167,10 @@ def test_find_dot_on_synthetic_frame():
 
 def test_demosaic_interior():
     rng = np.random.default_rng(6)
-    b = rng.integers(0, 256, (8, 10), dtype=np.uint8)
-    out = oracle.demosaic(b)
+    b8 = rng.integers(0, 256, (8, 10), dtype=np.uint8)
+    out = oracle.demosaic(b8)
+    b = b8.astype(int)
     y, x = 2, 2  # blue site
     assert out[y, x, 0] == b[y, x]
-    assert out[y, x, 1] == (int(b[y, x - 1]) + b[y, x + 1] + b[y - 1, x] + b[y + 1, x]) // 4
-    assert out[0, 0, 2] == int(b[1, 1]) // 4  # border taps read 0, divisor stays 4
+    assert out[y, x, 1] == (b[y, x - 1] + b[y, x + 1] + b[y - 1, x] + b[y + 1, x]) // 4
+    assert out[0, 0, 2] == b[1, 1] // 4  # border taps read 0, divisor stays 4
