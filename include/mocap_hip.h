@@ -20,6 +20,7 @@ extern "C" {
 #endif
 
 #define MOCAP_ABI_VERSION 1
+#define MOCAP_API __attribute__((visibility("default")))
 
 enum {
     MOCAP_OK = 0,
@@ -57,27 +58,27 @@ typedef struct mocap_contour {
     int32_t kept, cx, cy, link, parent, order;
 } mocap_contour;
 
-int mocap_abi_version(void);
-const char* mocap_last_error(void);
+MOCAP_API int mocap_abi_version(void);
+MOCAP_API const char* mocap_last_error(void);
 
 /* Context for one GPU and one image geometry.  n_slots = number of undistortion maps kept resident
  * (one per camera; the reference itself always uses camera 0's, lib/ImageOperations.py:37). */
-int mocap_ctx_create(int device_id, int width, int height, int n_slots, mocap_ctx_t* out);
-int mocap_ctx_destroy(mocap_ctx_t ctx);
-int mocap_sync(mocap_ctx_t ctx, void* stream); /* hipStreamSynchronize */
+MOCAP_API int mocap_ctx_create(int device_id, int width, int height, int n_slots, mocap_ctx_t* out);
+MOCAP_API int mocap_ctx_destroy(mocap_ctx_t ctx);
+MOCAP_API int mocap_sync(mocap_ctx_t ctx, void* stream); /* hipStreamSynchronize */
 
-int mocap_set_blob_params(mocap_ctx_t ctx, const mocap_blob_params* p);
+MOCAP_API int mocap_set_blob_params(mocap_ctx_t ctx, const mocap_blob_params* p);
 
 /* cv.undistort(img, K, dist) set-up (lib/ImageOperations.py:38): builds the quantised remap table of `slot`
  * on the device (synchronous).  identity_out (optional) receives 1 when the table is the identity. */
-int mocap_set_undistort(mocap_ctx_t ctx, int slot, const double K[9], const double dist[5], int* identity_out);
+MOCAP_API int mocap_set_undistort(mocap_ctx_t ctx, int slot, const double K[9], const double dist[5], int* identity_out);
 
 /* camera_params + camera_poses of lib/Helpers.py (K_i, dist_i from jsons/camera-params-in.json :30-40,
  * R_i, t_i from get_extrinsics :282-291); n <= 32.  Synchronous host->device copy. */
-int mocap_set_cameras(mocap_ctx_t ctx, int n, const double* K /*[n][9]*/, const double* dist /*[n][5]*/,
+MOCAP_API int mocap_set_cameras(mocap_ctx_t ctx, int n, const double* K /*[n][9]*/, const double* dist /*[n][5]*/,
                       const double* R /*[n][9]*/, const double* t /*[n][3]*/);
 /* Fs of lib/Helpers.py:22-28: F[i-1] maps a camera-0 pixel to its epipolar line in camera i; n <= 31. */
-int mocap_set_fundamentals(mocap_ctx_t ctx, int n, const double* F /*[n][9]*/);
+MOCAP_API int mocap_set_fundamentals(mocap_ctx_t ctx, int n, const double* F /*[n][9]*/);
 
 /* _find_dot over a batch (lib/ImageOperations.py:33-78 without the drawing calls).
  * frames_dev: n_images uint8 images of height x width, rows `pitch` bytes apart, images `image_stride` bytes
@@ -85,31 +86,31 @@ int mocap_set_fundamentals(mocap_ctx_t ctx, int n, const double* F /*[n][9]*/);
  * out_xy_dev [n_images][max_blobs][2] int32 receives (cx, cy) in the reference's contour order,
  * out_count_dev [n_images] the number of image points (0 where the reference returns [[None, None]];
  * values above max_blobs mean truncation; negative = MOCAP_BLOB_E_*). */
-int mocap_blob_centroids(mocap_ctx_t ctx, const void* frames_dev, int n_images, int cam_mod, size_t image_stride,
+MOCAP_API int mocap_blob_centroids(mocap_ctx_t ctx, const void* frames_dev, int n_images, int cam_mod, size_t image_stride,
                          int pitch, int32_t* out_xy_dev, int32_t* out_count_dev, int max_blobs, void* stream);
 
 /* The two halves of mocap_blob_centroids, exposed for tests and profiling.
  * mask_dev: [n_images][height][ceil(width/32)] uint32, bit b of word k = pixel 32k+b.  Must be zero-initialised
  * once by the caller (padding bits are never written). */
-int mocap_filter_mask(mocap_ctx_t ctx, const void* frames_dev, int n_images, int cam_mod, size_t image_stride,
+MOCAP_API int mocap_filter_mask(mocap_ctx_t ctx, const void* frames_dev, int n_images, int cam_mod, size_t image_stride,
                       int pitch, uint32_t* mask_dev, void* stream);
-int mocap_contours_from_mask(mocap_ctx_t ctx, const uint32_t* mask_dev, int n_images, int32_t* out_xy_dev,
+MOCAP_API int mocap_contours_from_mask(mocap_ctx_t ctx, const uint32_t* mask_dev, int n_images, int32_t* out_xy_dev,
                              int32_t* out_count_dev, int max_blobs, mocap_contour* dbg_dev /*[n_images][dbg_cap] or NULL*/,
                              int32_t* dbg_count_dev, int dbg_cap, void* stream);
 
 /* image_filter_gpu (order 0: blur -> threshold -> median, lib/ImageOperations.py:23-31) and image_filter_cpu
  * (order 1: median -> threshold, :15-21) on one image; slot >= 0 applies that undistortion first (as _find_dot
  * does), slot < 0 filters the image as given.  dst receives the {0,255} image. */
-int mocap_image_filter_u8(mocap_ctx_t ctx, const void* src_dev, void* dst_dev, int spitch, int dpitch, int order,
+MOCAP_API int mocap_image_filter_u8(mocap_ctx_t ctx, const void* src_dev, void* dst_dev, int spitch, int dpitch, int order,
                           int slot, void* stream);
 /* cv.undistort through the table of `slot` (lib/ImageOperations.py:38) */
-int mocap_undistort_u8(mocap_ctx_t ctx, int slot, const void* src_dev, void* dst_dev, int spitch, int dpitch,
+MOCAP_API int mocap_undistort_u8(mocap_ctx_t ctx, int slot, const void* src_dev, void* dst_dev, int spitch, int dpitch,
                        void* stream);
 /* fast_cuda_blur(image, kernel_size) (lib/CudaOperations.py:24-41): uint8 in, uint8 out, any size */
-int mocap_box_blur_u8(mocap_ctx_t ctx, const void* src_dev, void* dst_dev, int height, int width, int spitch,
+MOCAP_API int mocap_box_blur_u8(mocap_ctx_t ctx, const void* src_dev, void* dst_dev, int height, int width, int spitch,
                       int dpitch, int ksize, void* stream);
 /* fast_cuda_demosaic(bayer) (lib/CudaOperations.py:84-100): uint8[H][W] -> uint8[H][W][3] (B,G,R) */
-int mocap_demosaic_u8(mocap_ctx_t ctx, const void* bayer_dev, void* bgr_dev, int height, int width, int spitch,
+MOCAP_API int mocap_demosaic_u8(mocap_ctx_t ctx, const void* bayer_dev, void* bgr_dev, int height, int width, int spitch,
                       void* stream);
 
 /* find_point_correspondance_and_object_points for T time steps (lib/Helpers.py:178-280).
@@ -122,7 +123,7 @@ int mocap_demosaic_u8(mocap_ctx_t ctx, const void* bayer_dev, void* bgr_dev, int
  *   order    [T][P]     argsort of root_err                          (Helpers.py:274)
  *   n_roots  [T]        number of surviving roots, or MOCAP_CORR_E_GROUPS
  * The caller applies obj_count (Helpers.py:275-279).  Requires mocap_set_cameras + mocap_set_fundamentals. */
-int mocap_correspond(mocap_ctx_t ctx, const void* pts_dev, const int32_t* counts_dev, int pts_f64, int T, int C,
+MOCAP_API int mocap_correspond(mocap_ctx_t ctx, const void* pts_dev, const int32_t* counts_dev, int pts_f64, int T, int C,
                      int P, double cutoff, int max_groups, double* root_xyz_dev, double* root_err_dev,
                      double* root_grp_dev, int32_t* root_idx_dev, int32_t* order_dev, int32_t* n_roots_dev,
                      void* stream);
@@ -130,17 +131,17 @@ int mocap_correspond(mocap_ctx_t ctx, const void* pts_dev, const int32_t* counts
 /* triangulate_point(s) over N groups (lib/Helpers.py:43-99).  pts_dev [N][C][2] float64, valid_dev [N][C]
  * (0 = [None, None]).  compact_k != 0 reproduces the reference's indexing of the intrinsics by position after
  * the None entries are dropped (:59-61).  ok_dev[n] = 0 where the reference returns [None, None, None]. */
-int mocap_triangulate_batch(mocap_ctx_t ctx, const double* pts_dev, const uint8_t* valid_dev, int N, int C,
+MOCAP_API int mocap_triangulate_batch(mocap_ctx_t ctx, const double* pts_dev, const uint8_t* valid_dev, int N, int C,
                             int compact_k, double* xyz_dev, int32_t* ok_dev, void* stream);
 /* calculate_reprojection_error over N (group, object point) pairs (lib/Helpers.py:113-143);
  * ok_dev[n] = 0 where the reference returns None. */
-int mocap_reproject_batch(mocap_ctx_t ctx, const double* pts_dev, const uint8_t* valid_dev, const double* xyz_dev,
+MOCAP_API int mocap_reproject_batch(mocap_ctx_t ctx, const double* pts_dev, const uint8_t* valid_dev, const double* xyz_dev,
                           int N, int C, int compact_k, double* mse_dev, int32_t* ok_dev, void* stream);
 
 /* HIP-event timing of the kernels launched by mocap_blob_centroids / mocap_filter_mask on their stream.
  * mocap_profile_read synchronises, returns accumulated milliseconds and launch counts, and resets. */
-int mocap_profile_enable(mocap_ctx_t ctx, int on);
-int mocap_profile_read(mocap_ctx_t ctx, double* filter_ms, int* filter_launches, double* contour_ms,
+MOCAP_API int mocap_profile_enable(mocap_ctx_t ctx, int on);
+MOCAP_API int mocap_profile_read(mocap_ctx_t ctx, double* filter_ms, int* filter_launches, double* contour_ms,
                        int* contour_launches, double* corr_ms, int* corr_launches);
 
 #ifdef __cplusplus
