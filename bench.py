@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Throughput of the MocapV2 per-frame hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dist mild|zero]
+
+Workload (BASELINE.json configs[1]): 6 cameras x 1920x1080 synthetic IR frames, 8 markers.  One "step" = one pass
+of the whole hot path (undistort -> box blur -> threshold -> median -> contours -> centroids -> epipolar
+correspondence -> DLT triangulation) over one batch of T = 64 time steps (384 camera images, 796 MB) that is
+resident in HBM before the timed region starts.  A "frame" = one time step of all 6 cameras.  With N ranks every
+rank processes its own 384 images (weak scaling; camera-major sharding + one all-gather, mocapv2_amd/pipeline.py).
+
+Prints ONE JSON line (rank 0) with the driver's fields plus `roofline` (the fused filter kernel against the HBM
+read roofline, from HIP events recorded on the launch stream) and `cpu_baseline` (the C oracle on host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_CAM, WIDTH, HEIGHT, N_MARKERS, T_STEPS = 6, 1920, 1080, 8, 64
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def render_local(scene, image_list, seed_base=1000):
+    """uint8 [n, H, W] frames for (camera, global time step) pairs; time step t uses seed seed_base + t."""
+    out = np.empty((len(image_list), scene.height, scene.width), np.uint8)
+    cache = {}
+    for i, (c, t) in enumerate(image_list):
+        if t not in cache:
+            rng = np.random.default_rng(seed_base + t)
+            cache = {t: scene.markers(rng, N_MARKERS)}
+        rng = np.random.default_rng((seed_base + t) * 64 + c)
+        out[i] = scene.render(rng, cache[t], c, radius_range=(16.0, 22.0), salt=0.001)
+    return out
+
+
+def cpu_baseline(scene, arrays, n_steps, seed_base=1000):
+    """The oracle (scalar C port of the reference's CPU path) on `n_steps` time steps: thread-per-camera blob
+    extraction as the reference does (RealtimeTracking_FLIR.py:307-312), then correspondence + DLT."""
+    import ctypes
+    from concurrent.futures import ThreadPoolExecutor
+
+    import oracle
+    K, dist, R, t, F = arrays
+    prm = oracle.default_params(undistort=True, filter_order=2)
+    frames = render_local(scene, [(c, s) for s in range(n_steps) for c in range(N_CAM)], seed_base)
+    frames = frames.reshape(n_steps, N_CAM, scene.height, scene.width)
+    oracle.lib()
+    pool = ThreadPoolExecutor(N_CAM)
+    t0 = time.perf_counter()
+    n_pts = 0
+    for s in range(n_steps):
+        lists = list(pool.map(lambda c: oracle.find_dot(frames[s, c], K[c], dist[c], params=prm), range(N_CAM)))
+        P = max(1, max(len(l) for l in lists))
+        pts = np.zeros((N_CAM, P, 2))
+        cnt = np.zeros(N_CAM, np.int32)
+        for c, l in enumerate(lists):
+            cnt[c] = len(l)
+            if l:
+                pts[c, :len(l)] = l
+        res = oracle.correspond(pts, cnt, K, dist, R, t, F)
+        n_pts += len(res["root"])
+    dt = time.perf_counter() - t0
+    pool.shutdown()
+    return n_steps / dt, dt, n_pts, (lists, res)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dist", choices=["mild", "zero"], default="mild")
+    ap.add_argument("--cpu-steps", type=int, default=16, help="time steps in the CPU baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from mocapv2_amd.pipeline import BatchTracker, scene_arrays
+    from mocapv2_amd.synth import MILD_DIST, ZERO_DIST, Scene
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with python -m torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    scene = Scene(N_CAM, WIDTH, HEIGHT, dist=MILD_DIST if args.dist == "mild" else ZERO_DIST)
+    arrays = scene_arrays(scene)
+    tracker = BatchTracker(*arrays, WIDTH, HEIGHT, T_STEPS, world=world, rank=rank, device=local_rank)
+    images = tracker.local_image_list()
+    frames = torch.from_numpy(render_local(scene, images)).cuda()
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tracker.step(frames)
+    barrier()
+    tracker.ctx.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = tracker.step(frames)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tracker.ctx.profile(False)
+    prof = tracker.ctx.profile_read()
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    n_roots = out["n"].cpu().numpy()
+    status_ok = bool((n_roots >= 0).all()) and bool((tracker.records[:, 0] >= 0).all().item())
+
+    if rank == 0:
+        frames_per_step = T_STEPS * world
+        value = frames_per_step * args.steps / elapsed
+        launches = max(1, prof["filter_launches"])
+        images_per_launch = len(images) / (1 if world == 1 else len(tracker.segs))
+        filt_ms = prof["filter_ms"] / launches
+        achieved = WIDTH * HEIGHT * images_per_launch / (filt_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "filter_traffic.json")
+        if os.path.exists(tpath):  # HBM bytes per launch from the PMC pass (profiles/README.md), same workload
+            with open(tpath) as f:
+                tj = json.load(f)
+            if tj.get("dist") == args.dist and tj.get("images_per_launch") == images_per_launch:
+                traffic = tj.get("hbm_bytes_per_launch")
+        line = {
+            "metric": "frames/sec (6-cam 1080p)", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8+int64+f64",
+            "data": "synthetic",
+            "config": {"workload": "6-camera 1920x1080 synthetic IR frames, 8 markers (BASELINE.json configs[1])",
+                       "cameras": N_CAM, "width": WIDTH, "height": HEIGHT, "markers": N_MARKERS,
+                       "time_steps_per_step_per_gpu": T_STEPS, "distortion": args.dist,
+                       "frames_resident_in_hbm": True,
+                       "parallelism": "single launch, time-major" if world == 1 else f"camera-major blocks x{world} + 1 all-gather"},
+            "roofline": {"bound": "hbm", "kernel": "filter_mask_kernel", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": traffic, "avg_launch_ms": round(filt_ms, 4), "images_per_launch": images_per_launch,
+                         "algorithmic_bytes_per_image": WIDTH * HEIGHT},
+            "kernel_ms_per_step": {"filter": round(prof["filter_ms"] / args.steps, 4),
+                                   "contours": round(prof["contour_ms"] / args.steps, 4),
+                                   "correspond": round(prof["corr_ms"] / args.steps, 4)},
+            "status_ok": status_ok,
+            "points_per_frame": float(n_roots.mean()),
+        }
+        if world == 1 and args.cpu_steps > 0:
+            fps, dt, n_pts, last = cpu_baseline(scene, arrays, args.cpu_steps)
+            line["cpu_baseline"] = {"value": round(fps, 3), "unit": "frames/s", "cores": N_CAM, "kind": "port",
+                                    "sample": f"{args.cpu_steps} time steps x {N_CAM} cameras of the same workload, "
+                                              f"{dt:.1f} s, thread-per-camera C oracle ({os.cpu_count()} host cpus)"}
+            # parity spot check of the timed batch against the oracle (not timed): last CPU time step
+            s = args.cpu_steps - 1
+            k = int(n_roots[s])
+            gpu_xyz = out["xyz"][s, :k].cpu().numpy()
+            ref = last[1]
+            line["parity_spot_check"] = bool(k == len(ref["root"]) and (k == 0 or np.abs(gpu_xyz - ref["xyz"]).max() < 1e-7))
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -82,21 +82,24 @@ MOCAP_API int mocap_set_fundamentals(mocap_ctx_t ctx, int n, const double* F /*[
 
 /* _find_dot over a batch (lib/ImageOperations.py:33-78 without the drawing calls).
  * frames_dev: n_images uint8 images of height x width, rows `pitch` bytes apart, images `image_stride` bytes
- * apart; image n uses undistort slot n % cam_mod (frames laid out [time][camera]).
- * out_xy_dev [n_images][max_blobs][2] int32 receives (cx, cy) in the reference's contour order,
- * out_count_dev [n_images] the number of image points (0 where the reference returns [[None, None]];
- * values above max_blobs mean truncation; negative = MOCAP_BLOB_E_*). */
-MOCAP_API int mocap_blob_centroids(mocap_ctx_t ctx, const void* frames_dev, int n_images, int cam_mod, size_t image_stride,
-                         int pitch, int32_t* out_xy_dev, int32_t* out_count_dev, int max_blobs, void* stream);
+ * apart; image n uses undistort slot slot_base + n % cam_mod (frames laid out [time][camera]).
+ * Image n writes its (cx, cy) pairs, in the reference's contour order, to out_xy_dev + n*xy_stride (int32
+ * [max_blobs][2]) and its number of image points to out_count_dev[n*count_stride] (0 where the reference returns
+ * [[None, None]]; values above max_blobs mean truncation; negative = MOCAP_BLOB_E_*).  The strides (in int32
+ * elements) let both land in one fixed-size centroid record per image, ready for the all-gather. */
+MOCAP_API int mocap_blob_centroids(mocap_ctx_t ctx, const void* frames_dev, int n_images, int cam_mod, int slot_base,
+                         size_t image_stride, int pitch, int32_t* out_xy_dev, long xy_stride, int32_t* out_count_dev,
+                         long count_stride, int max_blobs, void* stream);
 
 /* The two halves of mocap_blob_centroids, exposed for tests and profiling.
  * mask_dev: [n_images][height][ceil(width/32)] uint32, bit b of word k = pixel 32k+b.  Must be zero-initialised
  * once by the caller (padding bits are never written). */
-MOCAP_API int mocap_filter_mask(mocap_ctx_t ctx, const void* frames_dev, int n_images, int cam_mod, size_t image_stride,
-                      int pitch, uint32_t* mask_dev, void* stream);
+MOCAP_API int mocap_filter_mask(mocap_ctx_t ctx, const void* frames_dev, int n_images, int cam_mod, int slot_base,
+                      size_t image_stride, int pitch, uint32_t* mask_dev, void* stream);
 MOCAP_API int mocap_contours_from_mask(mocap_ctx_t ctx, const uint32_t* mask_dev, int n_images, int32_t* out_xy_dev,
-                             int32_t* out_count_dev, int max_blobs, mocap_contour* dbg_dev /*[n_images][dbg_cap] or NULL*/,
-                             int32_t* dbg_count_dev, int dbg_cap, void* stream);
+                             long xy_stride, int32_t* out_count_dev, long count_stride, int max_blobs,
+                             mocap_contour* dbg_dev /*[n_images][dbg_cap] or NULL*/, int32_t* dbg_count_dev,
+                             int dbg_cap, void* stream);
 
 /* image_filter_gpu (order 0: blur -> threshold -> median, lib/ImageOperations.py:23-31) and image_filter_cpu
  * (order 1: median -> threshold, :15-21) on one image; slot >= 0 applies that undistortion first (as _find_dot
@@ -114,8 +117,11 @@ MOCAP_API int mocap_demosaic_u8(mocap_ctx_t ctx, const void* bayer_dev, void* bg
                       void* stream);
 
 /* find_point_correspondance_and_object_points for T time steps (lib/Helpers.py:178-280).
- * pts_dev [T][C][P][2] (int32, or float64 when pts_f64), counts_dev [T][C] valid points per camera (sentinel
- * already removed).  Per time step and surviving camera-0 root o (in root order):
+ * The up-to-P points of camera c at time step t start at pts_dev + t*pt_stride_t + c*pt_stride_c (strides in
+ * scalars of the point type: int32, or float64 when pts_f64; a point is 2 scalars), their number (sentinel
+ * already removed) is counts_dev[t*cnt_stride_t + c*cnt_stride_c].  A dense [T][C][P][2] array has strides
+ * (C*P*2, P*2) and (C, 1); centroid records gathered from other GPUs are read in place through other strides.
+ * Per time step and surviving camera-0 root o (in root order):
  *   root_xyz [T][P][3]  3-D point of the root's first group          (Helpers.py:272)
  *   root_err [T][P]     mean reprojection error over its groups      (Helpers.py:273)
  *   root_grp [T][P][C][2] the first group's image points             (Helpers.py:268)
@@ -123,7 +129,8 @@ MOCAP_API int mocap_demosaic_u8(mocap_ctx_t ctx, const void* bayer_dev, void* bg
  *   order    [T][P]     argsort of root_err                          (Helpers.py:274)
  *   n_roots  [T]        number of surviving roots, or MOCAP_CORR_E_GROUPS
  * The caller applies obj_count (Helpers.py:275-279).  Requires mocap_set_cameras + mocap_set_fundamentals. */
-MOCAP_API int mocap_correspond(mocap_ctx_t ctx, const void* pts_dev, const int32_t* counts_dev, int pts_f64, int T, int C,
+MOCAP_API int mocap_correspond(mocap_ctx_t ctx, const void* pts_dev, long pt_stride_t, long pt_stride_c,
+                     const int32_t* counts_dev, long cnt_stride_t, long cnt_stride_c, int pts_f64, int T, int C,
                      int P, double cutoff, int max_groups, double* root_xyz_dev, double* root_err_dev,
                      double* root_grp_dev, int32_t* root_idx_dev, int32_t* order_dev, int32_t* n_roots_dev,
                      void* stream);

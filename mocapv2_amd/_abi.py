@@ -25,7 +25,7 @@ class Contour(C.Structure):
                 ("parent", C.c_int32), ("order", C.c_int32)]
 
 
-_vp, _i, _d, _sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
+_vp, _i, _d, _sz, _l = C.c_void_p, C.c_int, C.c_double, C.c_size_t, C.c_long
 _dp, _ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
 
 # name -> argtypes; every symbol include/mocap_hip.h declares (restype int unless noted)
@@ -39,14 +39,14 @@ SIGNATURES = {
     "mocap_set_undistort": [_vp, _i, _dp, _dp, _ip],
     "mocap_set_cameras": [_vp, _i, _dp, _dp, _dp, _dp],
     "mocap_set_fundamentals": [_vp, _i, _dp],
-    "mocap_blob_centroids": [_vp, _vp, _i, _i, _sz, _i, _vp, _vp, _i, _vp],
-    "mocap_filter_mask": [_vp, _vp, _i, _i, _sz, _i, _vp, _vp],
-    "mocap_contours_from_mask": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp],
+    "mocap_blob_centroids": [_vp, _vp, _i, _i, _i, _sz, _i, _vp, _l, _vp, _l, _i, _vp],
+    "mocap_filter_mask": [_vp, _vp, _i, _i, _i, _sz, _i, _vp, _vp],
+    "mocap_contours_from_mask": [_vp, _vp, _i, _vp, _l, _vp, _l, _i, _vp, _vp, _i, _vp],
     "mocap_image_filter_u8": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mocap_undistort_u8": [_vp, _i, _vp, _vp, _i, _i, _vp],
     "mocap_box_blur_u8": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "mocap_demosaic_u8": [_vp, _vp, _vp, _i, _i, _i, _vp],
-    "mocap_correspond": [_vp, _vp, _vp, _i, _i, _i, _i, _d, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mocap_correspond": [_vp, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, _i, _d, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mocap_triangulate_batch": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "mocap_reproject_batch": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "mocap_profile_enable": [_vp, _i],

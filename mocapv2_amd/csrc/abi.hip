@@ -215,25 +215,27 @@ int mocap_profile_read(mocap_ctx_t c, double* fms, int* fn, double* cms, int* cn
 }
 
 // ---- blob stage ------------------------------------------------------------------------------------------------
-static int check_frames(mocap_ctx* c, const void* frames, int n_images, int cam_mod, size_t image_stride, int pitch)
+static int check_frames(mocap_ctx* c, const void* frames, int n_images, int cam_mod, int slot_base, size_t image_stride, int pitch)
 {
     if (!c || !frames) return fail(MOCAP_E_INVALID, "null argument");
     if (n_images < 1) return fail(MOCAP_E_INVALID, "n_images = %d", n_images);
-    if (cam_mod < 1 || cam_mod > c->n_slots) return fail(MOCAP_E_INVALID, "cam_mod %d not in 1..%d", cam_mod, c->n_slots);
+    if (cam_mod < 1 || slot_base < 0 || slot_base + cam_mod > c->n_slots)
+        return fail(MOCAP_E_INVALID, "slots %d..%d not in 0..%d", slot_base, slot_base + cam_mod - 1, c->n_slots - 1);
     if (pitch < c->W) return fail(MOCAP_E_INVALID, "pitch %d < width %d", pitch, c->W);
     if (n_images > 1 && image_stride < (size_t)pitch * (c->H - 1) + c->W) return fail(MOCAP_E_INVALID, "image_stride too small");
-    for (int s = 0; s < cam_mod; s++)
+    for (int s = slot_base; s < slot_base + cam_mod; s++)
         if (c->slot_state[s] == 0) return fail(MOCAP_E_STATE, "mocap_set_undistort was not called for slot %d", s);
     return 0;
 }
 
-static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mod, size_t image_stride, int pitch,
-                      uint32_t* mask, hipStream_t s)
+static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mod, int slot_base, size_t image_stride,
+                      int pitch, uint32_t* mask, hipStream_t s)
 {
     FilterArgs a;
     a.src = (const uint8_t*)frames; a.image_stride = image_stride; a.pitch = pitch; a.H = c->H; a.W = c->W;
     a.aligned4 = (((uintptr_t)frames | (uintptr_t)pitch | (uintptr_t)image_stride) & 3) == 0;
-    a.mask = mask; a.words_per_row = c->wpr; a.map = c->maps; a.cam_mod = cam_mod;
+    a.mask = mask; a.words_per_row = c->wpr; a.cam_mod = cam_mod;
+    a.map = c->maps ? c->maps + (size_t)slot_base * c->H * c->W : nullptr;
     a.n_images = n_images; a.n_steps = (n_images + cam_mod - 1) / cam_mod;
     double ft = floor(c->prm.thresh);
     a.thr_mul = ft < -1.0 ? 0 : (ft > 255.0 ? 256 : (int)ft + 1);
@@ -244,7 +246,7 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
     a.rows_per_chunk = rows;
     a.n_cgroups = (c->H + 4 * rows - 1) / (4 * rows);
     bool remap = false;
-    for (int sl = 0; sl < cam_mod; sl++) remap |= c->slot_state[sl] == 2;
+    for (int sl = slot_base; sl < slot_base + cam_mod; sl++) remap |= c->slot_state[sl] == 2;
     EvPair p; bool on;
     prof_begin(c, 0, s, p, on);
     launch_filter_mask(a, remap, s);
@@ -253,12 +255,13 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
     return 0;
 }
 
-static int run_contours(mocap_ctx* c, const uint32_t* mask, int n_images, int32_t* out_xy, int32_t* out_count,
-                        int max_blobs, mocap_contour* dbg, int32_t* dbg_count, int dbg_cap, hipStream_t s)
+static int run_contours(mocap_ctx* c, const uint32_t* mask, int n_images, int32_t* out_xy, long xy_stride,
+                        int32_t* out_count, long count_stride, int max_blobs, mocap_contour* dbg, int32_t* dbg_count, int dbg_cap, hipStream_t s)
 {
     ContourArgs a;
     a.mask = mask; a.words_per_row = c->wpr; a.H = c->H; a.W = c->W; a.n_images = n_images;
     a.out_xy = out_xy; a.out_count = out_count; a.max_blobs = max_blobs;
+    a.xy_stride = xy_stride; a.count_stride = count_stride;
     a.min_area = c->prm.min_area; a.min_circ = c->prm.min_circ;
     a.dbg = (ContourRec*)dbg; a.dbg_count = dbg_count; a.dbg_cap = dbg_cap;
     long long ms = 4LL * c->H * c->W + 16;
@@ -284,36 +287,42 @@ static int ensure_mask(mocap_ctx* c, int n_images)
     return 0;
 }
 
-int mocap_filter_mask(mocap_ctx_t c, const void* frames, int n_images, int cam_mod, size_t image_stride, int pitch,
-                      uint32_t* mask_dev, void* stream)
+int mocap_filter_mask(mocap_ctx_t c, const void* frames, int n_images, int cam_mod, int slot_base, size_t image_stride,
+                      int pitch, uint32_t* mask_dev, void* stream)
 {
-    int rc = check_frames(c, frames, n_images, cam_mod, image_stride, pitch);
+    int rc = check_frames(c, frames, n_images, cam_mod, slot_base, image_stride, pitch);
     if (rc) return rc;
     if (!mask_dev) return fail(MOCAP_E_INVALID, "null mask");
     if (set_device(c)) return MOCAP_E_HIP;
-    return run_filter(c, frames, n_images, cam_mod, image_stride, pitch, mask_dev, (hipStream_t)stream);
+    return run_filter(c, frames, n_images, cam_mod, slot_base, image_stride, pitch, mask_dev, (hipStream_t)stream);
 }
 
-int mocap_contours_from_mask(mocap_ctx_t c, const uint32_t* mask_dev, int n_images, int32_t* out_xy, int32_t* out_count,
-                             int max_blobs, mocap_contour* dbg, int32_t* dbg_count, int dbg_cap, void* stream)
+int mocap_contours_from_mask(mocap_ctx_t c, const uint32_t* mask_dev, int n_images, int32_t* out_xy, long xy_stride,
+                             int32_t* out_count, long count_stride, int max_blobs, mocap_contour* dbg, int32_t* dbg_count,
+                             int dbg_cap, void* stream)
 {
     if (!c || !mask_dev || !out_xy || !out_count) return fail(MOCAP_E_INVALID, "null argument");
-    if (n_images < 1 || max_blobs < 1) return fail(MOCAP_E_INVALID, "n_images=%d max_blobs=%d", n_images, max_blobs);
+    if (n_images < 1 || max_blobs < 1 || xy_stride < 2L * max_blobs || count_stride < 1)
+        return fail(MOCAP_E_INVALID, "n_images=%d max_blobs=%d strides %ld %ld", n_images, max_blobs, xy_stride, count_stride);
     if ((dbg != nullptr) != (dbg_count != nullptr) || (dbg && dbg_cap < 1)) return fail(MOCAP_E_INVALID, "inconsistent debug buffers");
     if (set_device(c)) return MOCAP_E_HIP;
-    return run_contours(c, mask_dev, n_images, out_xy, out_count, max_blobs, dbg, dbg_count, dbg_cap, (hipStream_t)stream);
+    return run_contours(c, mask_dev, n_images, out_xy, xy_stride, out_count, count_stride, max_blobs, dbg, dbg_count, dbg_cap,
+                        (hipStream_t)stream);
 }
 
-int mocap_blob_centroids(mocap_ctx_t c, const void* frames, int n_images, int cam_mod, size_t image_stride, int pitch,
-                         int32_t* out_xy, int32_t* out_count, int max_blobs, void* stream)
+int mocap_blob_centroids(mocap_ctx_t c, const void* frames, int n_images, int cam_mod, int slot_base, size_t image_stride,
+                         int pitch, int32_t* out_xy, long xy_stride, int32_t* out_count, long count_stride, int max_blobs,
+                         void* stream)
 {
-    int rc = check_frames(c, frames, n_images, cam_mod, image_stride, pitch);
+    int rc = check_frames(c, frames, n_images, cam_mod, slot_base, image_stride, pitch);
     if (rc) return rc;
-    if (!out_xy || !out_count || max_blobs < 1) return fail(MOCAP_E_INVALID, "bad output arguments");
+    if (!out_xy || !out_count || max_blobs < 1 || xy_stride < 2L * max_blobs || count_stride < 1)
+        return fail(MOCAP_E_INVALID, "bad output arguments");
     if (set_device(c)) return MOCAP_E_HIP;
     if ((rc = ensure_mask(c, n_images))) return rc;
-    if ((rc = run_filter(c, frames, n_images, cam_mod, image_stride, pitch, c->mask, (hipStream_t)stream))) return rc;
-    return run_contours(c, c->mask, n_images, out_xy, out_count, max_blobs, nullptr, nullptr, 0, (hipStream_t)stream);
+    if ((rc = run_filter(c, frames, n_images, cam_mod, slot_base, image_stride, pitch, c->mask, (hipStream_t)stream))) return rc;
+    return run_contours(c, c->mask, n_images, out_xy, xy_stride, out_count, count_stride, max_blobs, nullptr, nullptr, 0,
+                        (hipStream_t)stream);
 }
 
 int mocap_undistort_u8(mocap_ctx_t c, int slot, const void* src, void* dst, int spitch, int dpitch, void* stream)
@@ -389,12 +398,14 @@ int mocap_demosaic_u8(mocap_ctx_t c, const void* bayer, void* bgr, int H, int W,
 }
 
 // ---- geometry stage --------------------------------------------------------------------------------------------
-int mocap_correspond(mocap_ctx_t c, const void* pts, const int32_t* counts, int pts_f64, int T, int C, int P, double cutoff,
+int mocap_correspond(mocap_ctx_t c, const void* pts, long pt_st, long pt_sc, const int32_t* counts, long cnt_st, long cnt_sc,
+                     int pts_f64, int T, int C, int P, double cutoff,
                      int max_groups, double* root_xyz, double* root_err, double* root_grp, int32_t* root_idx,
                      int32_t* order, int32_t* n_roots, void* stream)
 {
     if (!c || !pts || !counts || !root_xyz || !root_err || !root_grp || !root_idx || !order || !n_roots)
         return fail(MOCAP_E_INVALID, "null argument");
+    if ((pt_st | pt_sc) & 1) return fail(MOCAP_E_INVALID, "point strides must be even (whole points)");
     if (T < 1 || C < 1 || C > 32 || P < 1 || P > 255 || max_groups < 1) return fail(MOCAP_E_INVALID, "T=%d C=%d P=%d max_groups=%d", T, C, P, max_groups);
     if (c->n_cam < C) return fail(MOCAP_E_STATE, "mocap_set_cameras: %d cameras set, %d needed", c->n_cam, C);
     if (c->n_F < C - 1) return fail(MOCAP_E_STATE, "mocap_set_fundamentals: %d matrices set, %d needed", c->n_F, C - 1);
@@ -408,6 +419,7 @@ int mocap_correspond(mocap_ctx_t c, const void* pts, const int32_t* counts, int 
     }
     CorrArgs a;
     a.cams = c->cams; a.pts = pts; a.counts = counts; a.pts_f64 = pts_f64; a.T = T; a.C = C; a.P = P;
+    a.pt_st = pt_st; a.pt_sc = pt_sc; a.cnt_st = cnt_st; a.cnt_sc = cnt_sc;
     a.cutoff = cutoff; a.max_groups = max_groups; a.root_xyz = root_xyz; a.root_err = root_err; a.root_grp = root_grp;
     a.root_idx = root_idx; a.order = order; a.n_roots = n_roots; a.scratch = c->scratch;
     EvPair p; bool on;

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void contours_kernel(ContourArgs a)
     }
     __syncthreads();
     if (ncand > MAXC) {
-        if (tid == 0) { a.out_count[image] = BLOB_ERR_CANDIDATES; if (a.dbg_count) a.dbg_count[image] = 0; }
+        if (tid == 0) { a.out_count[(size_t)image * a.count_stride] = BLOB_ERR_CANDIDATES; if (a.dbg_count) a.dbg_count[image] = 0; }
         return;
     }
 
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void contours_kernel(ContourArgs a)
     }
     __syncthreads();
     if (nrec > MAXR || err) {
-        if (tid == 0) { a.out_count[image] = err ? BLOB_ERR_STEPS : BLOB_ERR_CONTOURS; if (a.dbg_count) a.dbg_count[image] = 0; }
+        if (tid == 0) { a.out_count[(size_t)image * a.count_stride] = err ? BLOB_ERR_STEPS : BLOB_ERR_CONTOURS; if (a.dbg_count) a.dbg_count[image] = 0; }
         return;
     }
 
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void contours_kernel(ContourArgs a)
     }
     __syncthreads();
     if (err) {
-        if (tid == 0) { a.out_count[image] = err == 1 ? BLOB_ERR_STEPS : BLOB_ERR_CONTOURS; if (a.dbg_count) a.dbg_count[image] = 0; }
+        if (tid == 0) { a.out_count[(size_t)image * a.count_stride] = err == 1 ? BLOB_ERR_STEPS : BLOB_ERR_CONTOURS; if (a.dbg_count) a.dbg_count[image] = 0; }
         return;
     }
 
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void contours_kernel(ContourArgs a)
     }
     __syncthreads();
     if (err || nkept > MAXK) {
-        if (tid == 0) { a.out_count[image] = err ? BLOB_ERR_DEPTH : BLOB_ERR_CONTOURS; if (a.dbg_count) a.dbg_count[image] = 0; }
+        if (tid == 0) { a.out_count[(size_t)image * a.count_stride] = err ? BLOB_ERR_DEPTH : BLOB_ERR_CONTOURS; if (a.dbg_count) a.dbg_count[image] = 0; }
         return;
     }
 
@@ -323,11 +323,11 @@ __global__ __launch_bounds__(256) void contours_kernel(ContourArgs a)
         ContourRec& r = recs[kept_idx[c]];
         r.order = rank;
         if (rank < a.max_blobs) {
-            int32_t* o = a.out_xy + ((size_t)image * a.max_blobs + rank) * 2;
+            int32_t* o = a.out_xy + (size_t)image * a.xy_stride + (size_t)rank * 2;
             o[0] = r.cx; o[1] = r.cy;
         }
     }
-    if (tid == 0) a.out_count[image] = nkept;
+    if (tid == 0) a.out_count[(size_t)image * a.count_stride] = nkept;
     if (a.dbg) {
         for (int c = tid; c < nrec && c < a.dbg_cap; c += 256) a.dbg[(size_t)image * a.dbg_cap + c] = recs[c];
         if (tid == 0) a.dbg_count[image] = nrec;

@@ -219,9 +219,10 @@ __global__ __launch_bounds__(256) void correspond_kernel(CorrArgs a)
     __shared__ int s_err, s_nout;
 
     const CameraTable* cams = a.cams;
-    const int32_t* cnt = a.counts + (size_t)t * C;
-    const size_t pbase = (size_t)t * C * P;
-    const int n0 = cnt[0] < P ? cnt[0] : P;
+    auto cnt = [&](int c) { return a.counts[(size_t)t * a.cnt_st + (size_t)c * a.cnt_sc]; };
+    // element offset (in points) of camera c's list; strides are given in scalars, a point is 2 scalars
+    auto pbase = [&](int c) { return ((size_t)t * a.pt_st + (size_t)c * a.pt_sc) / 2; };
+    const int n0 = cnt(0) < P ? cnt(0) : P;
     if (tid == 0) { s_err = 0; s_nout = 0; }
     __syncthreads();
 
@@ -229,15 +230,15 @@ __global__ __launch_bounds__(256) void correspond_kernel(CorrArgs a)
     for (int w = tid; w < n0 * (C - 1); w += blockDim.x) {
         int j = w / (C - 1), i = 1 + w % (C - 1);
         double rx, ry;
-        load_pt<PT>(a.pts, pbase + j, rx, ry);
+        load_pt<PT>(a.pts, pbase(0) + j, rx, ry);
         float line[3];
         epiline(cams->F[i - 1], (float)rx, (float)ry, line);
         double md[MAXM];
-        int mi[MAXM], k = 0, ni = cnt[i] < P ? cnt[i] : P;
+        int mi[MAXM], k = 0, ni = cnt(i) < P ? cnt(i) : P;
         bool over = false;
         for (int p = 0; p < ni; p++) {
             double x, y;
-            load_pt<PT>(a.pts, pbase + (size_t)i * P + p, x, y);
+            load_pt<PT>(a.pts, pbase(i) + p, x, y);
             double d = epi_distance(line, x, y);
             if (d < a.cutoff) {
                 if (k == MAXM) { over = true; break; }
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(256) void correspond_kernel(CorrArgs a)
         while (G[lo] == 0) lo++; // skip dead roots sharing the offset
         int j = lo, g = w - goff[j], rem = g;
         double gx[32], gy[32];
-        load_pt<PT>(a.pts, pbase + j, gx[0], gy[0]);
+        load_pt<PT>(a.pts, pbase(0) + j, gx[0], gy[0]);
         DltAcc acc;
         acc.clear();
         acc.add(cams->K[0], cams->R[0], cams->t[0], gx[0], gy[0]);
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(256) void correspond_kernel(CorrArgs a)
             int n_i = nm[j * C + i], dgt = rem % n_i;
             rem /= n_i;
             int p = midx[((size_t)j * C + i) * MAXM + dgt];
-            load_pt<PT>(a.pts, pbase + (size_t)i * P + p, gx[i], gy[i]);
+            load_pt<PT>(a.pts, pbase(i) + p, gx[i], gy[i]);
             acc.add(cams->K[i], cams->R[i], cams->t[i], gx[i], gy[i]);
         }
         double X[3];

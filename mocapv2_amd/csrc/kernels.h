@@ -13,7 +13,7 @@ struct FilterArgs {
     uint32_t* mask;       // [n_images][H][words_per_row], bit b of word k = pixel 32k+b
     int words_per_row;
     const uint32_t* map;  // [cam_mod][H][W] packed (dx | dy<<16) in 1/32 px (remap variant only)
-    int cam_mod;          // undistort slot of image n = n % cam_mod
+    int cam_mod;          // undistort slot of image n = n % cam_mod (map already points at the first slot)
     int n_images, n_steps; // n_steps = ceil(n_images / cam_mod)
     int thr_mul;          // floor(thresh)+1: blurred > thresh  <=>  S >= thr_mul * taps
     int rows_per_chunk, n_strips, n_cgroups;
@@ -44,8 +44,9 @@ struct ContourRec {
 struct ContourArgs {
     const uint32_t* mask;
     int words_per_row, H, W, n_images;
-    int32_t* out_xy;     // [n_images][max_blobs][2]
-    int32_t* out_count;  // [n_images]  number of image points (may exceed max_blobs: truncated), <0 = error
+    int32_t* out_xy;     // image n: out_xy + n*xy_stride, [max_blobs][2]
+    int32_t* out_count;  // image n: out_count[n*count_stride]; may exceed max_blobs (truncated), <0 = error
+    long xy_stride, count_stride;
     int max_blobs;
     double min_area, min_circ;
     ContourRec* dbg;     // optional [n_images][dbg_cap]
@@ -74,8 +75,9 @@ struct CameraTable {           // device-resident, written by mocap_set_cameras 
 
 struct CorrArgs {
     const CameraTable* cams;
-    const void* pts;           // [T][C][P][2] int32 or float64
-    const int32_t* counts;     // [T][C]
+    const void* pts;           // points of (t,c): pts + (t*pt_st + c*pt_sc) elements, [P][2] int32 or float64
+    const int32_t* counts;     // count of (t,c): counts[t*cnt_st + c*cnt_sc]
+    long pt_st, pt_sc, cnt_st, cnt_sc;
     int pts_f64;
     int T, C, P;               // P = capacity per camera
     double cutoff;

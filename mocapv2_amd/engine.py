@@ -109,24 +109,33 @@ class MocapContext:
         stride = flat.stride(0) if n > 1 else pitch * self.height
         return flat, n, stride, pitch
 
-    def blob_centroids(self, frames, cam_mod=1, max_blobs=MAX_BLOBS, out_xy=None, out_count=None):
-        """_find_dot over uint8 frames [..., H, W] resident on the GPU (image n uses undistort slot n % cam_mod).
-        Returns (xy int32 [n, max_blobs, 2], count int32 [n]) device tensors."""
+    def blob_centroids(self, frames, cam_mod=1, slot_base=0, max_blobs=MAX_BLOBS, records=None):
+        """_find_dot over uint8 frames [..., H, W] resident on the GPU (image n uses undistort slot
+        slot_base + n % cam_mod).  Results land in centroid records, int32 [n, 2 + 2*max_blobs]:
+        record[0] = number of image points, record[2:] = (cx, cy) pairs in the reference's contour order.
+        Returns the records tensor (use record_views for xy / count views)."""
         flat, n, stride, pitch = self._frames(frames)
-        if out_xy is None:
-            out_xy = torch.empty((n, max_blobs, 2), dtype=torch.int32, device=self.device)
-        if out_count is None:
-            out_count = torch.empty((n,), dtype=torch.int32, device=self.device)
-        _abi.check(self.lib.mocap_blob_centroids(self._h, _ptr(flat), n, cam_mod, stride, pitch, _ptr(out_xy),
-                                                 _ptr(out_count), max_blobs, _stream()))
-        return out_xy, out_count
+        rec_ints = 2 + 2 * max_blobs
+        if records is None:
+            records = torch.empty((n, rec_ints), dtype=torch.int32, device=self.device)
+        assert records.is_contiguous() and records.shape == (n, rec_ints) and records.dtype == torch.int32
+        xy_ptr = C.c_void_p(records.data_ptr() + 8)
+        _abi.check(self.lib.mocap_blob_centroids(self._h, _ptr(flat), n, cam_mod, slot_base, stride, pitch, xy_ptr, rec_ints,
+                                                 _ptr(records), rec_ints, max_blobs, _stream()))
+        return records
 
-    def filter_mask(self, frames, cam_mod=1, mask=None):
+    @staticmethod
+    def record_views(records):
+        """(xy [n, max_blobs, 2], count [n]) views of a records tensor"""
+        n, rec_ints = records.shape
+        return records[:, 2:].reshape(n, (rec_ints - 2) // 2, 2), records[:, 0]
+
+    def filter_mask(self, frames, cam_mod=1, slot_base=0, mask=None):
         flat, n, stride, pitch = self._frames(frames)
         wpr = (self.width + 31) // 32
         if mask is None:
             mask = torch.zeros((n, self.height, wpr), dtype=torch.int32, device=self.device)
-        _abi.check(self.lib.mocap_filter_mask(self._h, _ptr(flat), n, cam_mod, stride, pitch, _ptr(mask), _stream()))
+        _abi.check(self.lib.mocap_filter_mask(self._h, _ptr(flat), n, cam_mod, slot_base, stride, pitch, _ptr(mask), _stream()))
         return mask
 
     def contours_from_mask(self, mask, max_blobs=MAX_BLOBS, debug_cap=0):
@@ -137,8 +146,8 @@ class MocapContext:
         if debug_cap:
             dbg = torch.zeros((n, debug_cap, C.sizeof(_abi.Contour)), dtype=torch.uint8, device=self.device)
             dbg_n = torch.zeros((n,), dtype=torch.int32, device=self.device)
-        _abi.check(self.lib.mocap_contours_from_mask(self._h, _ptr(mask), n, _ptr(xy), _ptr(cnt), max_blobs, _ptr(dbg),
-                                                     _ptr(dbg_n), debug_cap, _stream()))
+        _abi.check(self.lib.mocap_contours_from_mask(self._h, _ptr(mask), n, _ptr(xy), 2 * max_blobs, _ptr(cnt), 1, max_blobs,
+                                                     _ptr(dbg), _ptr(dbg_n), debug_cap, _stream()))
         if not debug_cap:
             return xy, cnt
         raw = dbg.cpu().numpy()
@@ -178,23 +187,43 @@ class MocapContext:
         return out
 
     # ---- geometry stage ----------------------------------------------------------------------------------------
+    def _corr_out(self, T, P, Cn):
+        dev = self.device
+        return {"xyz": torch.empty((T, P, 3), dtype=torch.float64, device=dev),
+                "err": torch.empty((T, P), dtype=torch.float64, device=dev),
+                "grp": torch.empty((T, P, Cn, 2), dtype=torch.float64, device=dev),
+                "root": torch.empty((T, P), dtype=torch.int32, device=dev),
+                "order": torch.empty((T, P), dtype=torch.int32, device=dev),
+                "n": torch.empty((T,), dtype=torch.int32, device=dev)}
+
     def correspond(self, pts, counts, cutoff=10.0, max_groups=4096, out=None):
         """pts [T, C, P, 2] (int32 or float64), counts [T, C] int32, both on the GPU -> dict of device tensors."""
         assert pts.is_cuda and pts.is_contiguous() and counts.is_contiguous() and counts.dtype == torch.int32
         T, Cn, P, _ = pts.shape
         f64 = pts.dtype == torch.float64
         assert f64 or pts.dtype == torch.int32
-        dev = self.device
-        if out is None:
-            out = {"xyz": torch.empty((T, P, 3), dtype=torch.float64, device=dev),
-                   "err": torch.empty((T, P), dtype=torch.float64, device=dev),
-                   "grp": torch.empty((T, P, Cn, 2), dtype=torch.float64, device=dev),
-                   "root": torch.empty((T, P), dtype=torch.int32, device=dev),
-                   "order": torch.empty((T, P), dtype=torch.int32, device=dev),
-                   "n": torch.empty((T,), dtype=torch.int32, device=dev)}
-        _abi.check(self.lib.mocap_correspond(self._h, _ptr(pts), _ptr(counts), int(f64), T, Cn, P, cutoff, max_groups,
-                                             _ptr(out["xyz"]), _ptr(out["err"]), _ptr(out["grp"]), _ptr(out["root"]),
-                                             _ptr(out["order"]), _ptr(out["n"]), _stream()))
+        out = out or self._corr_out(T, P, Cn)
+        _abi.check(self.lib.mocap_correspond(self._h, _ptr(pts), Cn * P * 2, P * 2, _ptr(counts), Cn, 1, int(f64), T, Cn, P,
+                                             cutoff, max_groups, _ptr(out["xyz"]), _ptr(out["err"]), _ptr(out["grp"]),
+                                             _ptr(out["root"]), _ptr(out["order"]), _ptr(out["n"]), _stream()))
+        return out
+
+    def correspond_records(self, records, T, Cn, t0=0, stride_t=None, stride_c=None, P=None, cutoff=10.0, max_groups=4096,
+                           out=None):
+        """Correspondence + triangulation straight from centroid records (int32 [..., 2 + 2*max_blobs]) laid out so
+        that the record of (time step t0 + t, camera c) sits stride_t*t + stride_c*c records after records[t0 * ...].
+        Default layout: records [T_total, C, rec] (time-major).  P limits the points read per camera."""
+        rec_ints = records.shape[-1]
+        flat = records.reshape(-1, rec_ints)
+        stride_t = Cn if stride_t is None else stride_t
+        stride_c = 1 if stride_c is None else stride_c
+        P = P or min(255, (rec_ints - 2) // 2)
+        out = out or self._corr_out(T, P, Cn)
+        base = flat.data_ptr() + 4 * rec_ints * stride_t * t0
+        _abi.check(self.lib.mocap_correspond(self._h, C.c_void_p(base + 8), rec_ints * stride_t, rec_ints * stride_c,
+                                             C.c_void_p(base), rec_ints * stride_t, rec_ints * stride_c, 0, T, Cn, P,
+                                             cutoff, max_groups, _ptr(out["xyz"]), _ptr(out["err"]), _ptr(out["grp"]),
+                                             _ptr(out["root"]), _ptr(out["order"]), _ptr(out["n"]), _stream()))
         return out
 
     def triangulate_batch(self, pts, valid, compact_k=True):

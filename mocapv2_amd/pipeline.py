@@ -1,0 +1,109 @@
+"""Batched tracker: the build's counterpart of the reference's track_points / track loops
+(reference RealtimeTracking_FLIR.py:95-143,157-209), fed from frames resident in HBM instead of PySpin.
+
+One process per GPU.  The grid of (camera, time step) images is cut camera-major into equal contiguous blocks,
+one per rank (a rank holds whole cameras, or a run of time steps of one, never a mix it does not need); each rank
+extracts the 2-D centroids of its block, ONE all-gather of fixed-size centroid records (RCCL over xGMI) gives every
+rank all centroids, and each rank then runs correspondence + triangulation for its own slice of the time steps.
+With one rank the block is the whole grid and no collective runs.
+"""
+import numpy as np
+import torch
+
+from .engine import MAX_BLOBS, REC_INTS, MocapContext
+
+
+def shard_plan(n_cams, steps_per_rank, world, rank):
+    """Segments (camera, t_begin, t_end) of the camera-major block of `rank`.
+
+    The run covers T_total = steps_per_rank * world time steps (weak scaling: n_cams * steps_per_rank images per
+    rank whatever the world size).  Image (c, t) has flat index c * T_total + t; rank r owns
+    [r * per, (r + 1) * per) with per = n_cams * steps_per_rank."""
+    t_total = steps_per_rank * world
+    per = n_cams * steps_per_rank
+    lo, hi = rank * per, (rank + 1) * per
+    segs = []
+    idx = lo
+    while idx < hi:
+        c, t = divmod(idx, t_total)
+        t_end = min(t_total, t + (hi - idx))
+        segs.append((c, t, t_end))
+        idx += t_end - t
+    return segs
+
+
+def allgather_records(local, world, group=None):
+    """The path's only collective: every rank contributes its [per, REC] centroid records, every rank receives
+    [world * per, REC] in rank order = camera-major order.  `local` may live on the GPU (nccl = RCCL) or on the
+    CPU (gloo, used by the multi-process tests)."""
+    if world == 1:
+        return local
+    import torch.distributed as dist
+    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    if local.is_cuda:
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    else:
+        dist.all_gather(list(out.chunk(world, dim=0)), local.contiguous(), group=group)
+    return out
+
+
+class BatchTracker:
+    """Frames -> 3-D marker positions for `steps_per_rank` time steps per call on this rank."""
+
+    def __init__(self, K, dist, R, t, F, width, height, steps_per_rank, world=1, rank=0, device=0, group=None,
+                 max_points=32, max_groups=4096):
+        self.n_cam = len(K)
+        self.T = int(steps_per_rank)
+        self.world, self.rank, self.group = world, rank, group
+        self.t_total = self.T * world
+        self.max_points, self.max_groups = max_points, max_groups
+        self.segs = shard_plan(self.n_cam, self.T, world, rank)
+        local_cams = sorted({c for c, _, _ in self.segs})
+        self.slot_of = {c: i for i, c in enumerate(local_cams)}
+        n_slots = self.n_cam if world == 1 else len(local_cams)
+        self.ctx = MocapContext(width, height, n_slots, device)
+        if world == 1:
+            for c in range(self.n_cam):
+                self.ctx.set_undistort(c, K[c], dist[c])
+        else:
+            for c in local_cams:
+                self.ctx.set_undistort(self.slot_of[c], K[c], dist[c])
+        self.ctx.set_cameras(K, dist, R, t)
+        self.ctx.set_fundamentals(F)
+        self.per = self.n_cam * self.T
+        self.records = torch.zeros((self.per, REC_INTS), dtype=torch.int32, device=self.ctx.device)
+        self.out = None
+
+    def local_image_list(self):
+        """(camera, global time step) of every local image, in the order `step` expects the frames."""
+        if self.world == 1:
+            return [(c, t) for t in range(self.T) for c in range(self.n_cam)]  # time-major [T][C]
+        return [(c, t) for c, t0, t1 in self.segs for t in range(t0, t1)]
+
+    def step(self, frames):
+        """frames: uint8 [per, H, W] on the GPU, ordered as local_image_list().  Returns the correspondence
+        outputs (dict of device tensors, see MocapContext.correspond) for this rank's time steps
+        [rank * T, (rank + 1) * T)."""
+        ctx = self.ctx
+        if self.world == 1:
+            ctx.blob_centroids(frames, cam_mod=self.n_cam, records=self.records)
+            self.out = ctx.correspond_records(self.records, self.T, self.n_cam, t0=0, stride_t=self.n_cam, stride_c=1,
+                                              P=self.max_points, max_groups=self.max_groups, out=self.out)
+            return self.out
+        o = 0
+        for c, t0, t1 in self.segs:
+            n = t1 - t0
+            ctx.blob_centroids(frames[o:o + n], cam_mod=1, slot_base=self.slot_of[c], records=self.records[o:o + n])
+            o += n
+        gathered = allgather_records(self.records, self.world, self.group)  # [C * T_total, REC], camera-major
+        self.out = ctx.correspond_records(gathered, self.T, self.n_cam, t0=self.rank * self.T, stride_t=1,
+                                          stride_c=self.t_total, P=self.max_points, max_groups=self.max_groups,
+                                          out=self.out)
+        return self.out
+
+
+def scene_arrays(scene):
+    """(K, dist, R, t, F) arrays of a synth.Scene"""
+    C = scene.n_cam
+    return (np.stack([scene.K] * C), np.stack([scene.dist] * C), np.stack([p["R"] for p in scene.poses]),
+            np.stack([p["t"] for p in scene.poses]), np.stack(scene.Fs))

@@ -168,7 +168,7 @@ def test_find_dot_synthetic_frames(torch_cuda, dist):
     ctx = MocapContext(960, 540, n_slots=3)
     for s in range(3):
         ctx.set_undistort(s, sc.K, sc.dist)
-    xy, cnt = ctx.blob_centroids(torch.from_numpy(frames).cuda(), cam_mod=3)
+    xy, cnt = ctx.record_views(ctx.blob_centroids(torch.from_numpy(frames).cuda(), cam_mod=3))
     xy, cnt = xy.cpu().numpy(), cnt.cpu().numpy()
     flat = frames.reshape(-1, 540, 960)
     total = 0

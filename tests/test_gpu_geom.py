@@ -1,0 +1,182 @@
+"""Parity of the HIP geometry path and of the drop-in lib.* surface with the reference-generated fixtures
+(tests/golden, made by oracle/gen_golden.py from the reference's own lib/Helpers.py) and with the CPU oracle."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from mocapv2_amd.synth import MILD_DIST, Scene
+
+pytestmark = pytest.mark.gpu
+
+TOL_XYZ = 1e-7  # world units = 1e-4 mm (BASELINE.json)
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def params_from(K, dist):
+    return np.array([{"intrinsic_matrix": K[i].tolist(), "distortion_coef": dist[i].tolist()} for i in range(len(K))])
+
+
+def poses_from(R, t):
+    return [{"R": R[i], "t": t[i]} for i in range(len(R))]
+
+
+@pytest.fixture()
+def helpers():
+    import torch
+    assert torch.cuda.is_available()
+    import mocapv2_amd.lib.Helpers as H
+    H.camera_params = None
+    H.Fs = []
+    return H
+
+
+def test_k1_triangulate_points(helpers):
+    H = helpers
+    g = load("k1_bundled")
+    H.camera_params = params_from(g["K"], g["dist"])
+    out = H.triangulate_points(g["image_points"], poses_from(g["R"], g["t"]))
+    assert out.shape == (54, 3)
+    assert np.abs(out - g["objects_json"]).max() < TOL_XYZ   # the reference's own bundled known answer
+    assert np.abs(out - g["objects_ref"]).max() < 1e-9
+    e = H.calculate_reprojection_errors(g["image_points"], out, poses_from(g["R"], g["t"]))
+    assert np.allclose(e, g["reproj_mse"], rtol=1e-9, atol=1e-9)
+    one = H.calculate_reprojection_error(g["image_points"][3], out[3], poses_from(g["R"], g["t"]))
+    assert abs(one - g["reproj_mse"][3]) < 1e-9
+
+
+def test_triangulate_point_none_handling(helpers):
+    H = helpers
+    g = load("tri_none")
+    H.camera_params = params_from(g["K"], g["dist"])
+    poses = poses_from(g["R"], g["t"])
+    for grp, exp in zip(g["groups"], g["out"]):
+        pts = [[None, None] if np.isnan(p[0]) else [int(p[0]), int(p[1])] for p in grp]
+        got = H.triangulate_point(pts, poses)
+        if np.isnan(exp[0]):
+            assert list(got) == [None, None, None]
+        else:
+            assert np.abs(np.asarray(got, float) - exp).max() < TOL_XYZ
+    # groups with a None are skipped by triangulate_points
+    groups = [[[None, None] if np.isnan(p[0]) else [int(p[0]), int(p[1])] for p in grp] for grp in g["groups"]]
+    out = H.triangulate_points(groups, poses)
+    assert out.shape == (1, 3) and np.abs(out[0] - g["out"][0]).max() < TOL_XYZ
+    assert H.triangulate_points(groups[1:], poses).shape == (0,)
+
+
+def lists_from_fixture(g):
+    lists = []
+    for c in range(g["pts"].shape[0]):
+        n = int(g["counts"][c])
+        pts = g["pts"][c, :n]
+        l = pts.tolist() if not bool(g["out_img_is_int"]) and n else [[int(x), int(y)] for x, y in pts]
+        if bool(g["had_sentinel"][c]):
+            l = [[None, None]] + l
+        lists.append(l)
+    return lists
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "corr_*.npz"))), ids=lambda p: os.path.basename(p)[:-4])
+def test_correspondence_drop_in(helpers, path):
+    H = helpers
+    g = np.load(path)
+    H.camera_params = params_from(g["K"], g["dist"])
+    H.Fs = [F.tolist() for F in g["F"]]
+    lists = lists_from_fixture(g)
+    obj, img = H.find_point_correspondance_and_object_points(lists, poses_from(g["R"], g["t"]), int(g["obj_count"]))
+    assert [len(l) for l in lists] == g["mutated_counts"].tolist()  # the sentinel was removed from the caller's lists
+    assert obj.shape == tuple(g["out_obj_shape"]) and img.shape == tuple(g["out_img_shape"])
+    if obj.shape == (0,):
+        return
+    assert (img.dtype.kind in "iu") == bool(g["out_img_is_int"])
+    assert np.array_equal(img, g["out_img"])             # marker indices: bit-exact
+    assert np.abs(obj - g["out_obj"]).max() < TOL_XYZ     # 3-D points: within 1e-4 mm
+
+
+def test_ba_residual_vector(helpers):
+    H = helpers
+    g = load("ba_residuals")
+    H.camera_params = params_from(g["K"], g["dist"])
+    ip = g["image_points"]
+    for x, r in zip(g["params"], g["residuals"]):
+        poses = H.params_to_camera_poses(x, 2)
+        obj = H.triangulate_points(ip, poses)
+        e = H.calculate_reprojection_errors(ip, obj, poses).astype(np.float32)
+        assert e.shape == r.shape and np.allclose(e, r, rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("C,M,T", [(2, 5, 4), (6, 8, 16), (6, 32, 8), (8, 16, 4)])
+def test_batched_correspond_matches_oracle(C, M, T):
+    import torch
+    from mocapv2_amd.engine import MocapContext
+    sc = Scene(C, dist=MILD_DIST)
+    K = np.stack([sc.K] * C)
+    dist = np.stack([sc.dist] * C)
+    R = np.stack([p["R"] for p in sc.poses])
+    t = np.stack([p["t"] for p in sc.poses])
+    F = np.stack(sc.Fs)
+    P = M + 4
+    pts = np.zeros((T, C, P, 2), np.int32)
+    cnt = np.zeros((T, C), np.int32)
+    for s in range(T):
+        rng = np.random.default_rng(900 + s)
+        cents = sc.centroids(sc.markers(rng, M), rng, jitter=0.6)
+        for c in range(C):
+            l = cents[c][rng.permutation(M)]
+            if s % 3 == 1 and c == C - 1:
+                l = l[: M - 2]  # some markers unseen by the last camera
+            extra = rng.integers(0, 1000, (rng.integers(0, 4), 2))
+            l = np.concatenate([l, extra])
+            cnt[s, c] = len(l)
+            pts[s, c, : len(l)] = l
+    ctx = MocapContext(1, 1)
+    ctx.set_cameras(K, dist, R, t)
+    ctx.set_fundamentals(F)
+    out = ctx.correspond(torch.from_numpy(pts).cuda(), torch.from_numpy(cnt).cuda())
+    n = out["n"].cpu().numpy()
+    for s in range(T):
+        ref = oracle.correspond(pts[s].astype(float), cnt[s], K, dist, R, t, F)
+        assert n[s] == len(ref["root"])
+        k = n[s]
+        assert np.array_equal(out["root"][s, :k].cpu().numpy(), ref["root"])
+        assert np.array_equal(out["grp"][s, :k].cpu().numpy(), ref["groups"])
+        assert np.array_equal(out["order"][s, :k].cpu().numpy(), ref["order"])
+        assert np.abs(out["xyz"][s, :k].cpu().numpy() - ref["xyz"]).max() < TOL_XYZ
+        assert np.allclose(out["err"][s, :k].cpu().numpy(), ref["err"], rtol=1e-9, atol=1e-12)
+    assert n.sum() > 0
+
+
+def test_cuda_operations_drop_in():
+    from mocapv2_amd.lib.CudaOperations import fast_cuda_blur, fast_cuda_demosaic
+    rng = np.random.default_rng(0)
+    for H_, W_ in [(1, 1), (17, 23), (120, 200)]:
+        img = rng.integers(0, 256, (H_, W_), dtype=np.uint8)
+        out = fast_cuda_blur(img, 5)
+        assert out.dtype == np.uint8 and np.array_equal(out, oracle.box_blur(img, 5))
+        assert np.array_equal(fast_cuda_blur(img, 3), oracle.box_blur(img, 3))
+        assert np.array_equal(fast_cuda_demosaic(img), oracle.demosaic(img))
+    with pytest.raises(AssertionError):
+        fast_cuda_blur(np.zeros((4, 4, 3), np.uint8))
+
+
+def test_image_operations_drop_in():
+    import mocapv2_amd.lib.ImageOperations as IO
+    sc = Scene(2, width=640, height=360, dist=MILD_DIST)
+    rng = np.random.default_rng(4)
+    img = sc.render(rng, sc.markers(rng, 5, extent=1.0), 0, radius_range=(16, 20), salt=0.001)
+    IO.camera_params = [{"intrinsic_matrix": sc.K.tolist(), "distortion_coef": sc.dist.tolist()}]
+    assert np.array_equal(IO.image_filter_gpu(img), oracle.image_filter(img, 0))
+    assert np.array_equal(IO.image_filter_cpu(img), oracle.image_filter(img, 1))
+    out, pts = IO._find_dot(img)
+    assert pts == oracle.find_dot(img, sc.K, sc.dist) and len(pts) == 5
+    assert np.array_equal(out, oracle.undistort(img, sc.K, sc.dist))
+    filt, pts2 = IO._find_dot(img, return_filtered=True)
+    assert pts2 == pts and np.array_equal(filt, oracle.image_filter(oracle.undistort(img, sc.K, sc.dist), 0))
+    _, none = IO._find_dot(np.zeros((360, 640), np.uint8))
+    assert none == [[None, None]]
