@@ -40,22 +40,23 @@ def render_local(scene, image_list, seed_base=1000):
     return out
 
 
-def cpu_baseline(scene, arrays, n_steps, seed_base=1000):
-    """The oracle (scalar C port of the reference's CPU path) on `n_steps` time steps: thread-per-camera blob
-    extraction as the reference does (RealtimeTracking_FLIR.py:307-312), then correspondence + DLT."""
+def cpu_baseline(scene, arrays, frames, n_steps):
+    """The oracle (scalar C port of the reference's CPU path) on `n_steps` time steps of the benchmark batch
+    (frames uint8 [T, C, H, W], reused cyclically): thread-per-camera blob extraction as the reference does
+    (RealtimeTracking_FLIR.py:307-312), then correspondence + DLT."""
     import ctypes
     from concurrent.futures import ThreadPoolExecutor
 
     import oracle
     K, dist, R, t, F = arrays
     prm = oracle.default_params(undistort=True, filter_order=2)
-    frames = render_local(scene, [(c, s) for s in range(n_steps) for c in range(N_CAM)], seed_base)
-    frames = frames.reshape(n_steps, N_CAM, scene.height, scene.width)
     oracle.lib()
+    T = frames.shape[0]
     pool = ThreadPoolExecutor(N_CAM)
     t0 = time.perf_counter()
     n_pts = 0
-    for s in range(n_steps):
+    for i in range(n_steps):
+        s = i % T
         lists = list(pool.map(lambda c: oracle.find_dot(frames[s, c], K[c], dist[c], params=prm), range(N_CAM)))
         P = max(1, max(len(l) for l in lists))
         pts = np.zeros((N_CAM, P, 2))
@@ -77,7 +78,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dist", choices=["mild", "zero"], default="mild")
-    ap.add_argument("--cpu-steps", type=int, default=16, help="time steps in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=256, help="time steps in the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -100,7 +101,8 @@ def main():
     arrays = scene_arrays(scene)
     tracker = BatchTracker(*arrays, WIDTH, HEIGHT, T_STEPS, world=world, rank=rank, device=local_rank)
     images = tracker.local_image_list()
-    frames = torch.from_numpy(render_local(scene, images)).cuda()
+    frames_host = render_local(scene, images)
+    frames = torch.from_numpy(frames_host).cuda()
     torch.cuda.synchronize()
 
     def barrier():
@@ -162,12 +164,12 @@ def main():
             "points_per_frame": float(n_roots.mean()),
         }
         if world == 1 and args.cpu_steps > 0:
-            fps, dt, n_pts, last = cpu_baseline(scene, arrays, args.cpu_steps)
+            fps, dt, n_pts, last = cpu_baseline(scene, arrays, frames_host.reshape(T_STEPS, N_CAM, HEIGHT, WIDTH), args.cpu_steps)
             line["cpu_baseline"] = {"value": round(fps, 3), "unit": "frames/s", "cores": N_CAM, "kind": "port",
                                     "sample": f"{args.cpu_steps} time steps x {N_CAM} cameras of the same workload, "
                                               f"{dt:.1f} s, thread-per-camera C oracle ({os.cpu_count()} host cpus)"}
             # parity spot check of the timed batch against the oracle (not timed): last CPU time step
-            s = args.cpu_steps - 1
+            s = (args.cpu_steps - 1) % T_STEPS
             k = int(n_roots[s])
             gpu_xyz = out["xyz"][s, :k].cpu().numpy()
             ref = last[1]
