@@ -18,15 +18,38 @@ namespace mocap {
 
 __device__ __forceinline__ uint32_t lane_from_prev(uint32_t v)
 { // lane L receives lane L-1's value, lane 0 receives 0
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
 }
 __device__ __forceinline__ uint32_t lane_from_next(uint32_t v)
 { // lane L receives lane L+1's value, lane 63 receives 0
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /*wave_shl:1*/, 0xf, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /*wave_shl:1*/, 0xf, 0xf, true);
 }
 __device__ __forceinline__ uint32_t dot4(uint32_t a, uint32_t sel, uint32_t acc)
 {
     return __builtin_amdgcn_udot4(a, sel, acc, false);
+}
+
+// Re-materialise a wave-uniform pointer in SGPRs so that "pointer + 32-bit lane offset" becomes the
+// scalar-base + vector-offset addressing form instead of a 64-bit vector multiply-add per access.
+template <typename T>
+__device__ __forceinline__ T* uniform_ptr(T* p)
+{
+    uint64_t v = (uint64_t)p;
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (T*)(((uint64_t)hi << 32) | lo);
+}
+
+__device__ __forceinline__ uint32_t load_u32(const uint8_t* p)
+{ // possibly unaligned 4-byte load (the compiler emits one global_load_dword: unaligned access is enabled on amdhsa)
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+__device__ __forceinline__ uint32_t load_u16(const uint8_t* p)
+{
+    uint16_t v;
+    __builtin_memcpy(&v, p, 2);
+    return v;
 }
 
 // one undistorted pixel (cv::remap, INTER_LINEAR, BORDER_CONSTANT 0) through the packed (dx,dy) map
@@ -35,49 +58,98 @@ __device__ __forceinline__ uint32_t remap_px(const uint8_t* __restrict__ img, in
 {
     int dx = (int)(int16_t)(m & 0xffffu), dy = (int)m >> 16;
     int iu = 32 * x + dx, iv = 32 * y + dy;
-    int sx = iu >> 5, sy = iv >> 5, a = iu & 31, b = iv & 31;
-    uint32_t p00 = 0, p01 = 0, p10 = 0, p11 = 0;
-    bool x0ok = (unsigned)sx < (unsigned)W, x1ok = (unsigned)(sx + 1) < (unsigned)W;
-    if ((unsigned)sy < (unsigned)H) {
-        const uint8_t* r = img + (size_t)sy * pitch;
-        if (x0ok) p00 = r[sx];
-        if (x1ok) p01 = r[sx + 1];
+    int sx = iu >> 5, sy = iv >> 5;
+    uint32_t a = iu & 31, b = iv & 31;
+    uint32_t p00, p01, p10, p11;
+    if ((unsigned)sx < (unsigned)(W - 1) && (unsigned)sy < (unsigned)(H - 1)) { // all four taps inside (the common case)
+        const uint8_t* r = img + (size_t)sy * pitch + sx;
+        uint32_t t0 = load_u16(r), t1 = load_u16(r + pitch);
+        p00 = t0 & 0xffu; p01 = t0 >> 8; p10 = t1 & 0xffu; p11 = t1 >> 8;
+    } else {
+        p00 = p01 = p10 = p11 = 0;
+        bool x0ok = (unsigned)sx < (unsigned)W, x1ok = (unsigned)(sx + 1) < (unsigned)W;
+        if ((unsigned)sy < (unsigned)H) {
+            const uint8_t* r = img + (size_t)sy * pitch;
+            if (x0ok) p00 = r[sx];
+            if (x1ok) p01 = r[sx + 1];
+        }
+        if ((unsigned)(sy + 1) < (unsigned)H) {
+            const uint8_t* r = img + (size_t)(sy + 1) * pitch;
+            if (x0ok) p10 = r[sx];
+            if (x1ok) p11 = r[sx + 1];
+        }
     }
-    if ((unsigned)(sy + 1) < (unsigned)H) {
-        const uint8_t* r = img + (size_t)(sy + 1) * pitch;
-        if (x0ok) p10 = r[sx];
-        if (x1ok) p11 = r[sx + 1];
-    }
-    uint32_t top = p00 * (32 - a) + p01 * a, bot = p10 * (32 - a) + p11 * a;
-    return ((top * (32 - b) + bot * b) * 32 + (1u << 14)) >> 15;
+    uint32_t na = 32u - a;
+    uint32_t top = __umul24(p00, na) + __umul24(p01, a), bot = __umul24(p10, na) + __umul24(p11, a);
+    return ((__umul24(top, 32u - b) + __umul24(bot, b)) * 32u + (1u << 14)) >> 15;
 }
 
-template <bool REMAP>
-__device__ __forceinline__ uint32_t load_src4(const FilterArgs& a, const uint8_t* __restrict__ img,
-                                              const uint32_t* __restrict__ map, int y, int xl)
+// per-lane column constants of a 4-pixel group starting at column xl
+struct LaneCols {
+    int addr_x;        // column actually loaded from: clamp(xl, 0, W-4)
+    uint32_t shift;    // bits to shift the loaded dword right so that byte k is column xl+k
+    uint32_t bytemask; // 0xff for every byte k with 0 <= xl+k < W
+    bool interior;     // all four columns inside the image
+};
+
+__device__ __forceinline__ LaneCols lane_cols(int xl, int W)
 {
-    if (y < 0 || y >= a.H) return 0u; // wave-uniform
-    if (REMAP) {
-        uint32_t out = 0;
-        const uint32_t* mrow = map + (size_t)y * a.W;
+    LaneCols c;
+    int ax = xl < 0 ? 0 : (xl > W - 4 ? W - 4 : xl);
+    if (ax < 0) ax = 0;
+    c.addr_x = ax;
+    int sh = (xl - ax) * 8;
+    c.shift = sh < 0 ? 0u : (sh > 24 ? 24u : (uint32_t)sh);
+    c.bytemask = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            int x = xl + k;
-            if ((unsigned)x < (unsigned)a.W) out |= remap_px(img, a.pitch, a.H, a.W, mrow[x], x, y) << (8 * k);
+    for (int k = 0; k < 4; k++)
+        if ((unsigned)(xl + k) < (unsigned)W) c.bytemask |= 0xffu << (8 * k);
+    c.interior = xl >= 0 && xl + 3 < W;
+    return c;
+}
+
+// Raw fetch of the four source pixels of a lane (columns xl..xl+3 of row y).  For the plain path the dword is
+// returned as loaded (row clamped into the image) and finish_src4 applies the column shift/mask and the row
+// validity when the value is consumed, several iterations later, so the load stays in flight meanwhile.
+template <bool REMAP, bool TINY>
+__device__ __forceinline__ uint32_t fetch_src4(const FilterArgs& a, const uint8_t* __restrict__ img,
+                                               const uint32_t* __restrict__ map, int y, int xl, const LaneCols& lc)
+{
+    const int yc = y < 0 ? 0 : (y > a.H - 1 ? a.H - 1 : y); // y is wave-uniform
+    if (REMAP) {
+        if ((unsigned)y >= (unsigned)a.H) return 0u;
+        uint32_t out = 0;
+        const uint32_t* mrow = map + (size_t)yc * a.W;
+        if (lc.interior) {
+            uint4 m;
+            __builtin_memcpy(&m, mrow + xl, 16);
+            out = remap_px(img, a.pitch, a.H, a.W, m.x, xl, yc) | (remap_px(img, a.pitch, a.H, a.W, m.y, xl + 1, yc) << 8) |
+                  (remap_px(img, a.pitch, a.H, a.W, m.z, xl + 2, yc) << 16) | (remap_px(img, a.pitch, a.H, a.W, m.w, xl + 3, yc) << 24);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int x = xl + k;
+                if ((unsigned)x < (unsigned)a.W) out |= remap_px(img, a.pitch, a.H, a.W, mrow[x], x, yc) << (8 * k);
+            }
         }
         return out;
     } else {
-        const uint8_t* p = img + (size_t)y * a.pitch + xl;
-        if (xl >= 0 && xl + 3 < a.W) {
-            if (a.aligned4) return *(const uint32_t*)p;
-            return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
-        }
-        uint32_t out = 0;
+        const uint8_t* p = uniform_ptr(img + (size_t)yc * a.pitch);
+        if (!TINY) return load_u32(p + (uint32_t)lc.addr_x); // one branch-free (possibly unaligned) dword load; needs W >= 4
+        uint32_t v = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            if ((unsigned)(xl + k) < (unsigned)a.W) out |= (uint32_t)p[k] << (8 * k);
-        return out;
+            if ((unsigned)(xl + k) < (unsigned)a.W) v |= (uint32_t)p[xl + k] << (8 * k);
+        return v;
     }
+}
+
+template <bool REMAP, bool TINY>
+__device__ __forceinline__ uint32_t finish_src4(uint32_t raw, bool row_ok, const LaneCols& lc)
+{
+    if (REMAP) return raw;
+    uint32_t v = TINY ? raw : ((raw >> lc.shift) & lc.bytemask);
+    return row_ok ? v : 0u;
 }
 
 // number of in-image taps of a 5-wide window centred on v
@@ -87,7 +159,9 @@ __device__ __forceinline__ int taps5(int v, int n)
     return hi - lo + 1;
 }
 
-template <bool REMAP>
+template <int J> struct IC { static constexpr int value = J; };
+
+template <bool REMAP, bool TINY>
 __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
 {
     __shared__ uint32_t lut[256];
@@ -101,7 +175,8 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
         for (int k = 0; k < 4; k++) v |= (uint32_t)__popc((i >> k) & 0x1fu) << (8 * k);
         lut[i] = v;
     }
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform: keeps the row loop scalar
 #pragma unroll
     for (int s = 0; s < 8; s++) {
         hring[wv][s][lane] = make_uint2(0u, 0u);
@@ -113,8 +188,8 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
     // one (camera, strip, chunk group) tile are dealt to the same XCD back to back, so the tile's undistort
     // map is fetched into that XCD's L2 once per batch instead of once per frame.
     const int tiles = a.cam_mod * a.n_strips * a.n_cgroups;
-    const int b = blockIdx.x, xcd = b & 7, q = b >> 3;
-    const int tile = (q / a.n_steps) * 8 + xcd, tstep = q % a.n_steps;
+    const int b = blockIdx.x, xcd = b & 7, q_ = b >> 3;
+    const int tile = (q_ / a.n_steps) * 8 + xcd, tstep = q_ % a.n_steps;
     if (tile >= tiles) return;
     const int slot = tile % a.cam_mod;
     const int strip = (tile / a.cam_mod) % a.n_strips;
@@ -144,6 +219,7 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
         for (int k = 0; k < 4; k++)
             if ((unsigned)(xl + k) < (unsigned)a.W) colmask |= 1u << k;
     }
+    const LaneCols lc = lane_cols(xl, a.W);
     const bool left_edge = xbase < 0;
     const bool right_edge = xbase + 255 >= a.W;
     const int lane_r = (a.W - 1 - xbase) >> 2, bit_r = (a.W - 1 - xbase) & 3; // lane / bit of column W-1
@@ -151,27 +227,27 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
     const int out_byte = strip * 30 + ((lane - 2) >> 1);
     const bool stores = ((lane & 1) == 0) && lane >= 2 && lane <= 60 && out_byte < ((a.W + 7) >> 3) &&
                         out_byte < row_bytes;
-
-    uint32_t V01 = 0, V23 = 0, Cv = 0;
-    int hi = 0, cj = 0; // ring counters
+    const uint32_t out_off = stores ? (uint32_t)out_byte : 0u;
 
     const int Hm1 = a.H - 1;
     int kfirst = r0 - 2;
     kfirst = kfirst < 0 ? 0 : (kfirst > Hm1 ? Hm1 : kfirst);
+    const int ks = r0 - 1 > 1 ? r0 - 1 : 1;                 // steady range: every iteration slides one source row
+    const int ke = r1 + 1 < Hm1 ? r1 + 1 : Hm1;
 
-    // source-row prefetch queue (4 rows ahead)
-    int ynext = kfirst - 2;
-    uint32_t q0 = load_src4<REMAP>(a, img, map, ynext, xl);
-    uint32_t q1 = load_src4<REMAP>(a, img, map, ynext + 1, xl);
-    uint32_t q2 = load_src4<REMAP>(a, img, map, ynext + 2, xl);
-    uint32_t q3 = load_src4<REMAP>(a, img, map, ynext + 3, xl);
-    ynext += 4;
+    uint32_t V01 = 0, V23 = 0, Cv = 0;
+    // source-row queue, 8 deep.  q[3] holds the first row so that the five set-up slides consume q[3..7] and the
+    // steady loop starts at q[0] / ring slot 0 with all indices static.
+    uint32_t q[8];
+    const int y0 = kfirst - 2;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        int row = y0 + ((j + 5) & 7);
+        q[j] = fetch_src4<REMAP, TINY>(a, img, map, row, xl, lc);
+    }
 
-    auto slide = [&]() {
-        uint32_t B = q0;
-        q0 = q1; q1 = q2; q2 = q3;
-        q3 = load_src4<REMAP>(a, img, map, ynext, xl);
-        ynext++;
+    // horizontal 5-sums of one source row -> vertical running sums (history in the LDS ring)
+    auto hsum_update = [&](uint32_t B, int s_new, int s_old) {
         uint32_t A = lane_from_prev(B), C = lane_from_next(B);
         uint32_t sB = dot4(B, 0x01010101u, 0u);
         uint32_t h0 = dot4(A, 0x01010000u, dot4(B, 0x00010101u, 0u));
@@ -179,56 +255,112 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
         uint32_t h2 = dot4(C, 0x00000001u, sB);
         uint32_t h3 = dot4(C, 0x00000101u, dot4(B, 0x01010100u, 0u));
         uint32_t H01 = h0 | (h1 << 16), H23 = h2 | (h3 << 16);
-        uint2 old = hring[wv][(hi + 3) & 7][lane];
-        hring[wv][hi & 7][lane] = make_uint2(H01, H23);
-        hi++;
+        uint2 old = hring[wv][s_old][lane];
+        hring[wv][s_new][lane] = make_uint2(H01, H23);
         V01 += H01 - old.x; // 16-bit fields never borrow: the window sum always contains the row removed
         V23 += H23 - old.y;
     };
-
-    // rows kfirst-2 .. kfirst+1
-    slide(); slide(); slide(); slide();
-
-    int kc_cur = kfirst - 1;
-    uint32_t c_cur = 0;
-    for (int k = r0 - 2; k <= r1 + 1; ++k) {
-        int kc = k < 0 ? 0 : (k > Hm1 ? Hm1 : k);
-        if (kc != kc_cur) { // wave-uniform
-            kc_cur = kc;
-            slide(); // V = sum of source rows kc-2 .. kc+2
-            uint32_t m = (uint32_t)(a.thr_mul * taps5(kc, a.H));
-            uint32_t T01 = __umul24(cx01, m), T23 = __umul24(cx23, m);
-            uint32_t d01 = (V01 | 0x80008000u) - T01, d23 = (V23 | 0x80008000u) - T23;
-            uint32_t t = (d01 >> 15) & 0x10001u, u = (d23 >> 15) & 0x10001u;
-            uint32_t w = t | (u << 2);
-            uint32_t nib = (w | (w >> 15)) & 0xfu;
-            // medianBlur replicates the border: columns outside the image take the edge column's bit
-            if (left_edge) {
-                uint32_t e = __builtin_amdgcn_readlane(nib, 2) & 1u;
-                if (xl < 0) nib = e ? 0xfu : 0u;
-            }
-            if (right_edge) {
-                uint32_t e = (__builtin_amdgcn_readlane(nib, lane_r) >> bit_r) & 1u;
-                uint32_t keep = (2u << bit_r) - 1u;
-                if (lane > lane_r) nib = e ? 0xfu : 0u;
-                else if (lane == lane_r) nib = (nib & keep) | (e ? (0xfu & ~keep) : 0u);
-            }
-            uint32_t nl = lane_from_prev(nib), nr = lane_from_next(nib);
-            uint32_t win = (nl >> 2) | (nib << 2) | ((nr & 3u) << 6);
-            c_cur = lut[win];
+    // threshold row kc from the running sums -> packed horizontal 5-window counts of the thresholded row
+    auto thresh_counts = [&](int kc) -> uint32_t {
+        uint32_t m = (uint32_t)(a.thr_mul * taps5(kc, a.H));
+        uint32_t T01 = __umul24(cx01, m), T23 = __umul24(cx23, m);
+        uint32_t d01 = (V01 | 0x80008000u) - T01, d23 = (V23 | 0x80008000u) - T23;
+        uint32_t t = (d01 >> 15) & 0x10001u, u = (d23 >> 15) & 0x10001u;
+        uint32_t w = t | (u << 2);
+        uint32_t nib = (w | (w >> 15)) & 0xfu;
+        // medianBlur replicates the border: columns outside the image take the edge column's bit
+        if (left_edge) {
+            uint32_t e = __builtin_amdgcn_readlane(nib, 2) & 1u;
+            if (xl < 0) nib = e ? 0xfu : 0u;
         }
-        uint32_t cold = cring[wv][(cj + 3) & 7][lane];
-        cring[wv][cj & 7][lane] = c_cur;
+        if (right_edge) {
+            uint32_t e = (__builtin_amdgcn_readlane(nib, lane_r) >> bit_r) & 1u;
+            uint32_t keep = (2u << bit_r) - 1u;
+            if (lane > lane_r) nib = e ? 0xfu : 0u;
+            else if (lane == lane_r) nib = (nib & keep) | (e ? (0xfu & ~keep) : 0u);
+        }
+        uint32_t nl = lane_from_prev(nib), nr = lane_from_next(nib);
+        uint32_t win = (nl >> 2) | (nib << 2) | ((nr & 3u) << 6);
+        return lut[win];
+    };
+    auto push_counts = [&](uint32_t c, int s_new, int s_old) {
+        uint32_t cold = cring[wv][s_old][lane];
+        cring[wv][s_new][lane] = c;
+        Cv += c - cold;
+    };
+    // majority (>= 13 of 25) of output row `row`, two lanes -> one byte of the bit mask
+    auto emit = [&](int row, bool on) {
+        uint32_t mm = ((Cv + 0x73737373u) >> 7) & 0x01010101u;
+        uint32_t t1 = mm | (mm >> 7);
+        uint32_t mn = (t1 | (t1 >> 14)) & colmask;
+        uint32_t odd = lane_from_next(mn);
+        uint32_t byte = (mn & 0xfu) | ((odd & 0xfu) << 4);
+        uint8_t* rowp = uniform_ptr(mrow_base + (ptrdiff_t)row * row_bytes); // scalar base + 32-bit lane offset
+        if (stores && on) rowp[out_off] = (uint8_t)byte;
+    };
+
+    // ---- set-up: source rows kfirst-2 .. kfirst+2 (ring slots 3..7), first threshold row, replicated top rows ----
+    hsum_update(finish_src4<REMAP, TINY>(q[3], (unsigned)(y0 + 0) < (unsigned)a.H, lc), 3, 6);
+    q[3] = fetch_src4<REMAP, TINY>(a, img, map, y0 + 8, xl, lc);
+    hsum_update(finish_src4<REMAP, TINY>(q[4], (unsigned)(y0 + 1) < (unsigned)a.H, lc), 4, 7);
+    q[4] = fetch_src4<REMAP, TINY>(a, img, map, y0 + 9, xl, lc);
+    hsum_update(finish_src4<REMAP, TINY>(q[5], (unsigned)(y0 + 2) < (unsigned)a.H, lc), 5, 0);
+    q[5] = fetch_src4<REMAP, TINY>(a, img, map, y0 + 10, xl, lc);
+    hsum_update(finish_src4<REMAP, TINY>(q[6], (unsigned)(y0 + 3) < (unsigned)a.H, lc), 6, 1);
+    q[6] = fetch_src4<REMAP, TINY>(a, img, map, y0 + 11, xl, lc);
+    hsum_update(finish_src4<REMAP, TINY>(q[7], (unsigned)(y0 + 4) < (unsigned)a.H, lc), 7, 2);
+    q[7] = fetch_src4<REMAP, TINY>(a, img, map, y0 + 12, xl, lc);
+    uint32_t c_cur = thresh_counts(kfirst);
+    // count-ring phase chosen so that the steady loop starts at slot 0: pushes so far = 1 (+2 at the image top)
+    int cj = (r0 == 0) ? 5 : 7;
+    push_counts(c_cur, cj & 7, (cj + 3) & 7);
+    cj++;
+    for (int kk = r0 - 1; kk < ks; ++kk) { // rows above the image replicate row 0 (only the top chunk gets here)
+        push_counts(c_cur, cj & 7, (cj + 3) & 7);
         cj++;
-        Cv += c_cur - cold;
-        if (k >= r0 + 2) {
-            // majority: count >= 13 in each byte
-            uint32_t mm = ((Cv + 0x73737373u) >> 7) & 0x01010101u;
-            uint32_t t1 = mm | (mm >> 7);
-            uint32_t mn = (t1 | (t1 >> 14)) & colmask;
-            uint32_t odd = lane_from_next(mn);
-            uint32_t byte = (mn & 0xfu) | ((odd & 0xfu) << 4);
-            if (stores) mrow_base[(size_t)(k - 2) * row_bytes + out_byte] = (uint8_t)byte;
+        if (kk >= r0 + 2) emit(kk - 2, true);
+    }
+
+    // ---- steady state: one source row in, one threshold row, one output row per step; unrolled by 8 so that the
+    // queue registers and both ring slots are compile-time constants ----
+    auto step = [&](auto Jc, int k) {
+        constexpr int J = decltype(Jc)::value;
+        uint32_t B = finish_src4<REMAP, TINY>(q[J], k + 2 <= Hm1, lc);
+        // refill 8 rows ahead, unconditionally (rows past the chunk are clamped into the image and simply unused:
+        // a branch here would make the compiler drain the whole queue at the join)
+        q[J] = fetch_src4<REMAP, TINY>(a, img, map, k + 10, xl, lc);
+        hsum_update(B, J, (J + 3) & 7);
+        c_cur = thresh_counts(k);
+        push_counts(c_cur, J, (J + 3) & 7);
+        emit(k - 2, k >= r0 + 2);
+    };
+    int k = ks;
+    for (; k + 7 <= ke; k += 8) { // hot loop: no guards, every index static
+        step(IC<0>{}, k);
+        step(IC<1>{}, k + 1);
+        step(IC<2>{}, k + 2);
+        step(IC<3>{}, k + 3);
+        step(IC<4>{}, k + 4);
+        step(IC<5>{}, k + 5);
+        step(IC<6>{}, k + 6);
+        step(IC<7>{}, k + 7);
+    }
+    if (k <= ke) step(IC<0>{}, k);
+    if (k + 1 <= ke) step(IC<1>{}, k + 1);
+    if (k + 2 <= ke) step(IC<2>{}, k + 2);
+    if (k + 3 <= ke) step(IC<3>{}, k + 3);
+    if (k + 4 <= ke) step(IC<4>{}, k + 4);
+    if (k + 5 <= ke) step(IC<5>{}, k + 5);
+    if (k + 6 <= ke) step(IC<6>{}, k + 6);
+    // ---- rows below the image replicate the last row (only the bottom chunk gets here) ----
+    {
+        int n_steady = ke >= ks ? ke - ks + 1 : 0;
+        cj = n_steady; // slot of the next push (the steady loop started at slot 0)
+        int kb = ke + 1 > ks ? ke + 1 : ks;
+        for (int kk = kb; kk <= r1 + 1; ++kk) {
+            push_counts(c_cur, cj & 7, (cj + 3) & 7);
+            cj++;
+            if (kk >= r0 + 2) emit(kk - 2, true);
         }
     }
 }
@@ -379,9 +511,11 @@ void launch_filter_mask(const FilterArgs& a, bool remap, hipStream_t s)
     int tiles = a.cam_mod * a.n_strips * a.n_cgroups;
     int blocks = ((tiles + 7) / 8) * 8 * a.n_steps;
     if (remap)
-        hipLaunchKernelGGL(filter_mask_kernel<true>, dim3(blocks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((filter_mask_kernel<true, false>), dim3(blocks), dim3(256), 0, s, a);
+    else if (a.W >= 4)
+        hipLaunchKernelGGL((filter_mask_kernel<false, false>), dim3(blocks), dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL(filter_mask_kernel<false>, dim3(blocks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((filter_mask_kernel<false, true>), dim3(blocks), dim3(256), 0, s, a);
 }
 void launch_undistort_map(const MapArgs& m, hipStream_t s)
 {
