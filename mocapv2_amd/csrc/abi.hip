@@ -41,7 +41,7 @@ struct mocap_ctx {
     int device, W, H, n_slots, wpr;
     mocap_blob_params prm;
     uint32_t* maps;           // [n_slots][H][W]
-    uint32_t* map_flags;      // [n_slots] device
+    uint32_t* map_flags;      // [n_slots] device, followed by 256 trash bytes
     std::vector<int> slot_state; // 0 unset, 1 identity, 2 remap
     uint32_t* mask; size_t mask_images;
     CameraTable* cams; int n_cam, n_F;
@@ -72,7 +72,7 @@ int mocap_ctx_create(int device_id, int width, int height, int n_slots, mocap_ct
     c->maps = nullptr; c->map_flags = nullptr; c->mask = nullptr; c->mask_images = 0;
     c->cams = nullptr; c->n_cam = 0; c->n_F = 0; c->scratch = nullptr; c->scratch_elems = 0; c->profiling = false;
     c->slot_state.assign(n_slots, 0);
-    hipError_t e = hipMalloc(&c->map_flags, sizeof(uint32_t) * n_slots);
+    hipError_t e = hipMalloc(&c->map_flags, sizeof(uint32_t) * n_slots + 256);
     if (e == hipSuccess) e = hipMemset(c->map_flags, 0, sizeof(uint32_t) * n_slots);
     if (e == hipSuccess) e = hipMalloc(&c->cams, sizeof(CameraTable));
     if (e == hipSuccess) e = hipMemset(c->cams, 0, sizeof(CameraTable));
@@ -235,13 +235,14 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
     a.src = (const uint8_t*)frames; a.image_stride = image_stride; a.pitch = pitch; a.H = c->H; a.W = c->W;
     a.aligned4 = (((uintptr_t)frames | (uintptr_t)pitch | (uintptr_t)image_stride) & 3) == 0;
     a.mask = mask; a.words_per_row = c->wpr; a.cam_mod = cam_mod;
+    a.trash = (uint8_t*)(c->map_flags + c->n_slots);
     a.map = c->maps ? c->maps + (size_t)slot_base * c->H * c->W : nullptr;
     a.n_images = n_images; a.n_steps = (n_images + cam_mod - 1) / cam_mod;
     double ft = floor(c->prm.thresh);
     a.thr_mul = ft < -1.0 ? 0 : (ft > 255.0 ? 256 : (int)ft + 1);
     a.n_strips = (c->W + 239) / 240;
     // four waves per workgroup, each sliding over rows_per_chunk rows (+8 halo rows)
-    int rows = 135;
+    int rows = 135; // must stay <= STAGE_ROWS (blob_filter.hip)
     if (c->H < 4 * 32) rows = (c->H + 3) / 4 > 8 ? (c->H + 3) / 4 : 8;
     a.rows_per_chunk = rows;
     a.n_cgroups = (c->H + 4 * rows - 1) / (4 * rows);
@@ -363,10 +364,11 @@ int mocap_image_filter_u8(mocap_ctx_t c, const void* src, void* dst, int spitch,
     a.src = (const uint8_t*)src; a.image_stride = 0; a.pitch = spitch; a.H = c->H; a.W = c->W;
     a.aligned4 = (((uintptr_t)src | (uintptr_t)spitch) & 3) == 0;
     a.mask = c->mask; a.words_per_row = c->wpr; a.cam_mod = 1; a.n_images = 1; a.n_steps = 1;
+    a.trash = (uint8_t*)(c->map_flags + c->n_slots);
     a.map = slot >= 0 ? c->maps + (size_t)slot * c->H * c->W : nullptr;
     a.thr_mul = ithresh + 1;
     a.n_strips = (c->W + 239) / 240;
-    int rows = 135;
+    int rows = 135; // must stay <= STAGE_ROWS (blob_filter.hip)
     if (c->H < 4 * 32) rows = (c->H + 3) / 4 > 8 ? (c->H + 3) / 4 : 8;
     a.rows_per_chunk = rows;
     a.n_cgroups = (c->H + 4 * rows - 1) / (4 * rows);

@@ -29,16 +29,6 @@ __device__ __forceinline__ uint32_t dot4(uint32_t a, uint32_t sel, uint32_t acc)
     return __builtin_amdgcn_udot4(a, sel, acc, false);
 }
 
-// Re-materialise a wave-uniform pointer in SGPRs so that "pointer + 32-bit lane offset" becomes the
-// scalar-base + vector-offset addressing form instead of a 64-bit vector multiply-add per access.
-template <typename T>
-__device__ __forceinline__ T* uniform_ptr(T* p)
-{
-    uint64_t v = (uint64_t)p;
-    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-    return (T*)(((uint64_t)hi << 32) | lo);
-}
-
 __device__ __forceinline__ uint32_t load_u32(const uint8_t* p)
 { // possibly unaligned 4-byte load (the compiler emits one global_load_dword: unaligned access is enabled on amdhsa)
     uint32_t v;
@@ -134,8 +124,10 @@ __device__ __forceinline__ uint32_t fetch_src4(const FilterArgs& a, const uint8_
         }
         return out;
     } else {
-        const uint8_t* p = uniform_ptr(img + (size_t)yc * a.pitch);
-        if (!TINY) return load_u32(p + (uint32_t)lc.addr_x); // one branch-free (possibly unaligned) dword load; needs W >= 4
+        // uniform base + 32-bit offset keeps the scalar-base addressing form (and the global address space:
+        // a pointer rebuilt from integers would turn these into flat loads, which vmcnt cannot count in order)
+        if (!TINY) return load_u32(img + ((uint32_t)yc * (uint32_t)a.pitch + (uint32_t)lc.addr_x)); // needs W >= 4
+        const uint8_t* p = img + (size_t)yc * a.pitch;
         uint32_t v = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++)
@@ -152,6 +144,85 @@ __device__ __forceinline__ uint32_t finish_src4(uint32_t raw, bool row_ok, const
     return row_ok ? v : 0u;
 }
 
+// ---- software-pipelined remap (three stages, each one source row apart in time) -----------------------------
+//   A: issue the load of the row's four packed map words          (8 rows ahead of use)
+//   B: decode them, issue the 2x2 tap loads, build blend weights  (4 rows ahead of use)
+//   C: blend the taps                                             (at use)
+// so that neither memory latency is exposed.  Pixels whose taps are not all inside the image (image border only)
+// are resolved synchronously in stage B and carried as (value, identity weights).
+struct MapSlot { uint4 m; };
+struct TapSlot { uint32_t t0[4], t1[4], w[4]; };
+
+__device__ __forceinline__ void remap_issue_map(MapSlot& ms, const uint32_t* __restrict__ map, int row, int H, int W,
+                                                const LaneCols& lc)
+{
+    int rc = row < 0 ? 0 : (row > H - 1 ? H - 1 : row);
+    __builtin_memcpy(&ms.m, map + ((uint32_t)rc * (uint32_t)W + (uint32_t)lc.addr_x), 16);
+}
+
+// blend weights of one axis when the 2-tap window [s, s+1] was loaded at the clamped position sc:
+// a tap that fell outside the image reads 0 (BORDER_CONSTANT), i.e. its weight moves to nothing
+__device__ __forceinline__ void edge_weights(int s, int sc, uint32_t f, uint32_t& w0, uint32_t& w1)
+{
+    int d = s - sc;
+    uint32_t nf = 32u - f;
+    w0 = d == 0 ? nf : (d == -1 ? f : 0u);
+    w1 = d == 0 ? f : (d == 1 ? nf : 0u);
+}
+
+__device__ __forceinline__ void remap_issue_taps(TapSlot& ts, const MapSlot& ms, const uint8_t* __restrict__ img, int pitch,
+                                                 int H, int W, int row, const int xq[4])
+{
+    // rows outside the image contribute zeros: same loads (row clamped), weights forced to 0 -- no branch around
+    // the loads, so the compiler's in-flight counts stay exact
+    const bool row_ok = (unsigned)row < (unsigned)H;
+    const uint32_t wmask = row_ok ? 0xffffffffu : 0u;
+    row = row < 0 ? 0 : (row > H - 1 ? H - 1 : row);
+    const uint8_t* base = img;
+    const uint32_t mm[4] = {ms.m.x, ms.m.y, ms.m.z, ms.m.w};
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { // no branch around the loads: the compiler keeps exact in-flight counts
+        uint32_t m = mm[k];
+        int iu = 32 * xq[k] + (int)(int16_t)(m & 0xffffu), iv = 32 * row + ((int)m >> 16);
+        int sx = iu >> 5, sy = iv >> 5;
+        uint32_t a = iu & 31, b = iv & 31;
+        int sxc = max(0, min(sx, W - 2)), syc = max(0, min(sy, H - 2));
+        bad |= (sx != sxc) | (sy != syc);
+        uint32_t off0 = __umul24((uint32_t)syc, (uint32_t)pitch) + (uint32_t)sxc, off1 = off0 + (uint32_t)pitch;
+        ts.t0[k] = load_u16(base + off0);
+        ts.t1[k] = load_u16(base + off1);
+        ts.w[k] = ((0x20000020u + __umul24(a, 0xffu)) - __umul24(b, 0xff0000u)) & wmask; // bytes: 32-a | a | b | 32-b
+    }
+    if (__any(bad)) { // wave-uniform, image border only: some tap fell outside the image
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t m = mm[k];
+            int iu = 32 * xq[k] + (int)(int16_t)(m & 0xffffu), iv = 32 * row + ((int)m >> 16);
+            int sx = iu >> 5, sy = iv >> 5;
+            int sxc = sx < 0 ? 0 : (sx > W - 2 ? W - 2 : sx), syc = sy < 0 ? 0 : (sy > H - 2 ? H - 2 : sy);
+            uint32_t wx0, wx1, wy0, wy1;
+            edge_weights(sx, sxc, iu & 31, wx0, wx1);
+            edge_weights(sy, syc, iv & 31, wy0, wy1);
+            ts.w[k] = (wx0 | (wx1 << 8) | (wy1 << 16) | (wy0 << 24)) & wmask;
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t remap_combine(const TapSlot& ts, const LaneCols& lc)
+{
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t w = ts.w[k];
+        uint32_t top = dot4(ts.t0[k], w, 0u), bot = dot4(ts.t1[k], w, 0u); // tap bytes 2,3 are zero
+        uint32_t r = __umul24(top, w >> 24) + 512u;
+        r += __umul24(bot, (w >> 16) & 0xffu);
+        out |= (r >> 10) << (8 * k);
+    }
+    return out & lc.bytemask; // columns outside the image do not exist
+}
+
 // number of in-image taps of a 5-wide window centred on v
 __device__ __forceinline__ int taps5(int v, int n)
 {
@@ -160,13 +231,17 @@ __device__ __forceinline__ int taps5(int v, int n)
 }
 
 template <int J> struct IC { static constexpr int value = J; };
+constexpr int STAGE_ROWS = 136; // >= rows_per_chunk
 
-template <bool REMAP, bool TINY>
+template <bool REMAP, bool TINY, bool PIPE>
 __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
 {
     __shared__ uint32_t lut[256];
     __shared__ uint2 hring[4][8][64];
     __shared__ uint32_t cring[4][8][64];
+    // output staging: the chunk's mask bytes wait here and are written out after the last load, so that no store
+    // is in flight while loads are (the compiler drains the whole load queue at every use otherwise)
+    __shared__ __attribute__((aligned(4))) uint8_t ostage[4][PIPE ? STAGE_ROWS : 1][32];
 
     // lut[w]: byte k = number of set bits among bits k..k+4 of the 8-bit window w
     {
@@ -227,7 +302,6 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
     const int out_byte = strip * 30 + ((lane - 2) >> 1);
     const bool stores = ((lane & 1) == 0) && lane >= 2 && lane <= 60 && out_byte < ((a.W + 7) >> 3) &&
                         out_byte < row_bytes;
-    const uint32_t out_off = stores ? (uint32_t)out_byte : 0u;
 
     const int Hm1 = a.H - 1;
     int kfirst = r0 - 2;
@@ -239,12 +313,50 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
     // source-row queue, 8 deep.  q[3] holds the first row so that the five set-up slides consume q[3..7] and the
     // steady loop starts at q[0] / ring slot 0 with all indices static.
     uint32_t q[8];
-    const int y0 = kfirst - 2;
+    MapSlot mq[4];
+    TapSlot tq[4];
+    int xq[4];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        int row = y0 + ((j + 5) & 7);
-        q[j] = fetch_src4<REMAP, TINY>(a, img, map, row, xl, lc);
+    for (int k = 0; k < 4; k++) { int x = xl + k; xq[k] = x < 0 ? 0 : (x > a.W - 1 ? a.W - 1 : x); }
+    const int y0 = kfirst - 2;
+    if (PIPE) {
+        // slot of source row rho = (rho - (y0 + 5)) & 3, so that the steady loop starts at slot 0
+        remap_issue_map(mq[3], map, y0, a.H, a.W, lc);
+        remap_issue_map(mq[0], map, y0 + 1, a.H, a.W, lc);
+        remap_issue_map(mq[1], map, y0 + 2, a.H, a.W, lc);
+        remap_issue_map(mq[2], map, y0 + 3, a.H, a.W, lc);
+        remap_issue_taps(tq[3], mq[3], img, a.pitch, a.H, a.W, y0, xq);
+        remap_issue_map(mq[3], map, y0 + 4, a.H, a.W, lc);
+        remap_issue_taps(tq[0], mq[0], img, a.pitch, a.H, a.W, y0 + 1, xq);
+        remap_issue_map(mq[0], map, y0 + 5, a.H, a.W, lc);
+        remap_issue_taps(tq[1], mq[1], img, a.pitch, a.H, a.W, y0 + 2, xq);
+        remap_issue_map(mq[1], map, y0 + 6, a.H, a.W, lc);
+        remap_issue_taps(tq[2], mq[2], img, a.pitch, a.H, a.W, y0 + 3, xq);
+        remap_issue_map(mq[2], map, y0 + 7, a.H, a.W, lc);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            int row = y0 + ((j + 5) & 7);
+            q[j] = fetch_src4<REMAP, TINY>(a, img, map, row, xl, lc);
+        }
     }
+    // next source row (row index `row`, queue slot J): its four pixels, and the refill of the pipeline behind it
+    auto next_row = [&](auto Jc, int row) -> uint32_t {
+        constexpr int J = decltype(Jc)::value;
+        if (PIPE) {
+            constexpr int S = J & 3;
+            uint32_t B = remap_combine(tq[S], lc);
+            remap_issue_taps(tq[S], mq[S], img, a.pitch, a.H, a.W, row + 4, xq);
+            remap_issue_map(mq[S], map, row + 8, a.H, a.W, lc);
+            return B;
+        } else {
+            uint32_t B = finish_src4<REMAP, TINY>(q[J], (unsigned)row < (unsigned)a.H, lc);
+            // refill 8 rows ahead, unconditionally (rows past the chunk are clamped into the image and simply
+            // unused: a branch here would make the compiler drain the whole queue at the join)
+            q[J] = fetch_src4<REMAP, TINY>(a, img, map, row + 8, xl, lc);
+            return B;
+        }
+    };
 
     // horizontal 5-sums of one source row -> vertical running sums (history in the LDS ring)
     auto hsum_update = [&](uint32_t B, int s_new, int s_old) {
@@ -295,21 +407,20 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
         uint32_t mn = (t1 | (t1 >> 14)) & colmask;
         uint32_t odd = lane_from_next(mn);
         uint32_t byte = (mn & 0xfu) | ((odd & 0xfu) << 4);
-        uint8_t* rowp = uniform_ptr(mrow_base + (ptrdiff_t)row * row_bytes); // scalar base + 32-bit lane offset
-        if (stores && on) rowp[out_off] = (uint8_t)byte;
+        if (PIPE) {
+            if (stores && on) ostage[wv][row - r0][(lane - 2) >> 1] = (uint8_t)byte;
+        } else {
+            // plain path: direct byte store (the compiler keeps counted vmcnt waits around this exec-masked store)
+            if (stores && on) mrow_base[(size_t)row * row_bytes + out_byte] = (uint8_t)byte;
+        }
     };
 
     // ---- set-up: source rows kfirst-2 .. kfirst+2 (ring slots 3..7), first threshold row, replicated top rows ----
-    hsum_update(finish_src4<REMAP, TINY>(q[3], (unsigned)(y0 + 0) < (unsigned)a.H, lc), 3, 6);
-    q[3] = fetch_src4<REMAP, TINY>(a, img, map, y0 + 8, xl, lc);
-    hsum_update(finish_src4<REMAP, TINY>(q[4], (unsigned)(y0 + 1) < (unsigned)a.H, lc), 4, 7);
-    q[4] = fetch_src4<REMAP, TINY>(a, img, map, y0 + 9, xl, lc);
-    hsum_update(finish_src4<REMAP, TINY>(q[5], (unsigned)(y0 + 2) < (unsigned)a.H, lc), 5, 0);
-    q[5] = fetch_src4<REMAP, TINY>(a, img, map, y0 + 10, xl, lc);
-    hsum_update(finish_src4<REMAP, TINY>(q[6], (unsigned)(y0 + 3) < (unsigned)a.H, lc), 6, 1);
-    q[6] = fetch_src4<REMAP, TINY>(a, img, map, y0 + 11, xl, lc);
-    hsum_update(finish_src4<REMAP, TINY>(q[7], (unsigned)(y0 + 4) < (unsigned)a.H, lc), 7, 2);
-    q[7] = fetch_src4<REMAP, TINY>(a, img, map, y0 + 12, xl, lc);
+    hsum_update(next_row(IC<3>{}, y0), 3, 6);
+    hsum_update(next_row(IC<4>{}, y0 + 1), 4, 7);
+    hsum_update(next_row(IC<5>{}, y0 + 2), 5, 0);
+    hsum_update(next_row(IC<6>{}, y0 + 3), 6, 1);
+    hsum_update(next_row(IC<7>{}, y0 + 4), 7, 2);
     uint32_t c_cur = thresh_counts(kfirst);
     // count-ring phase chosen so that the steady loop starts at slot 0: pushes so far = 1 (+2 at the image top)
     int cj = (r0 == 0) ? 5 : 7;
@@ -325,10 +436,7 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
     // queue registers and both ring slots are compile-time constants ----
     auto step = [&](auto Jc, int k) {
         constexpr int J = decltype(Jc)::value;
-        uint32_t B = finish_src4<REMAP, TINY>(q[J], k + 2 <= Hm1, lc);
-        // refill 8 rows ahead, unconditionally (rows past the chunk are clamped into the image and simply unused:
-        // a branch here would make the compiler drain the whole queue at the join)
-        q[J] = fetch_src4<REMAP, TINY>(a, img, map, k + 10, xl, lc);
+        uint32_t B = next_row(Jc, k + 2);
         hsum_update(B, J, (J + 3) & 7);
         c_cur = thresh_counts(k);
         push_counts(c_cur, J, (J + 3) & 7);
@@ -361,6 +469,21 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
             push_counts(c_cur, cj & 7, (cj + 3) & 7);
             cj++;
             if (kk >= r0 + 2) emit(kk - 2, true);
+        }
+    }
+    // ---- write the staged rows out: 15 two-byte stores per row, two rows per wave instruction ----
+    if (PIPE) {
+        const int n_rows = r1 - r0;
+        const int half = lane >> 5, pair = lane & 31;
+        const int byte0 = strip * 30 + 2 * pair;
+        const bool lane_ok = pair < 15 && byte0 < ((a.W + 7) >> 3);
+        for (int i = half; i < n_rows; i += 2) {
+            uint16_t v = *(const uint16_t*)&ostage[wv][i][2 * pair];
+            if (lane_ok) {
+                uint8_t* dst = mrow_base + (size_t)(r0 + i) * row_bytes + byte0;
+                if (byte0 + 1 < ((a.W + 7) >> 3)) *(uint16_t*)dst = v; // byte0 is even: aligned; padding bytes are never written
+                else *dst = (uint8_t)v;
+            }
         }
     }
 }
@@ -510,12 +633,14 @@ void launch_filter_mask(const FilterArgs& a, bool remap, hipStream_t s)
 {
     int tiles = a.cam_mod * a.n_strips * a.n_cgroups;
     int blocks = ((tiles + 7) / 8) * 8 * a.n_steps;
-    if (remap)
-        hipLaunchKernelGGL((filter_mask_kernel<true, false>), dim3(blocks), dim3(256), 0, s, a);
+    if (remap && a.W >= 4 && (a.W & 3) == 0 && a.H >= 2)
+        hipLaunchKernelGGL((filter_mask_kernel<true, false, true>), dim3(blocks), dim3(256), 0, s, a);
+    else if (remap)
+        hipLaunchKernelGGL((filter_mask_kernel<true, false, false>), dim3(blocks), dim3(256), 0, s, a);
     else if (a.W >= 4)
-        hipLaunchKernelGGL((filter_mask_kernel<false, false>), dim3(blocks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((filter_mask_kernel<false, false, false>), dim3(blocks), dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL((filter_mask_kernel<false, true>), dim3(blocks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((filter_mask_kernel<false, true, false>), dim3(blocks), dim3(256), 0, s, a);
 }
 void launch_undistort_map(const MapArgs& m, hipStream_t s)
 {

@@ -12,6 +12,7 @@ struct FilterArgs {
     int aligned4;         // src base, pitch and image_stride are multiples of 4
     uint32_t* mask;       // [n_images][H][words_per_row], bit b of word k = pixel 32k+b
     int words_per_row;
+    uint8_t* trash;       // >= 256 bytes: where lanes with nothing to write put their byte
     const uint32_t* map;  // [cam_mod][H][W] packed (dx | dy<<16) in 1/32 px (remap variant only)
     int cam_mod;          // undistort slot of image n = n % cam_mod (map already points at the first slot)
     int n_images, n_steps; // n_steps = ceil(n_images / cam_mod)
