@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 #include <math.h>
 #include <string>
@@ -44,6 +45,7 @@ struct mocap_ctx {
     uint32_t* map_flags;      // [n_slots] device, followed by 256 trash bytes
     std::vector<int> slot_state; // 0 unset, 1 identity, 2 remap
     uint32_t* mask; size_t mask_images;
+    uint32_t* cells; size_t cells_images; // occupancy cells written by the filter kernel for c->mask
     CameraTable* cams; int n_cam, n_F;
     double* scratch; size_t scratch_elems;
     bool profiling;
@@ -69,7 +71,7 @@ int mocap_ctx_create(int device_id, int width, int height, int n_slots, mocap_ct
     mocap_ctx* c = new mocap_ctx();
     c->device = device_id; c->W = width; c->H = height; c->n_slots = n_slots; c->wpr = (width + 31) / 32;
     c->prm = mocap_blob_params{5, 5, 255 * 0.85, 500.0, 0.5};
-    c->maps = nullptr; c->map_flags = nullptr; c->mask = nullptr; c->mask_images = 0;
+    c->maps = nullptr; c->map_flags = nullptr; c->mask = nullptr; c->mask_images = 0; c->cells = nullptr; c->cells_images = 0;
     c->cams = nullptr; c->n_cam = 0; c->n_F = 0; c->scratch = nullptr; c->scratch_elems = 0; c->profiling = false;
     c->slot_state.assign(n_slots, 0);
     hipError_t e = hipMalloc(&c->map_flags, sizeof(uint32_t) * n_slots + 256);
@@ -92,6 +94,7 @@ int mocap_ctx_destroy(mocap_ctx_t c)
     if (c->maps) (void)hipFree(c->maps);
     if (c->map_flags) (void)hipFree(c->map_flags);
     if (c->mask) (void)hipFree(c->mask);
+    if (c->cells) (void)hipFree(c->cells);
     if (c->cams) (void)hipFree(c->cams);
     if (c->scratch) (void)hipFree(c->scratch);
     delete c;
@@ -228,24 +231,33 @@ static int check_frames(mocap_ctx* c, const void* frames, int n_images, int cam_
     return 0;
 }
 
+struct Tiling { int rows, n_cgroups, n_strips; };
+static Tiling tiling(const mocap_ctx* c)
+{
+    Tiling t;
+    t.rows = 135; // must stay <= STAGE_ROWS (blob_filter.hip)
+    if (c->H < 4 * 32) t.rows = (c->H + 3) / 4 > 8 ? (c->H + 3) / 4 : 8;
+    t.n_cgroups = (c->H + 4 * t.rows - 1) / (4 * t.rows);
+    t.n_strips = (c->W + 239) / 240;
+    return t;
+}
+static size_t cells_per_image(const mocap_ctx* c) { Tiling t = tiling(c); return (size_t)t.n_cgroups * 4 * t.n_strips; }
+
 static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mod, int slot_base, size_t image_stride,
-                      int pitch, uint32_t* mask, hipStream_t s)
+                      int pitch, uint32_t* mask, uint32_t* cells, hipStream_t s)
 {
     FilterArgs a;
     a.src = (const uint8_t*)frames; a.image_stride = image_stride; a.pitch = pitch; a.H = c->H; a.W = c->W;
     a.aligned4 = (((uintptr_t)frames | (uintptr_t)pitch | (uintptr_t)image_stride) & 3) == 0;
     a.mask = mask; a.words_per_row = c->wpr; a.cam_mod = cam_mod;
-    a.trash = (uint8_t*)(c->map_flags + c->n_slots);
+    a.cells = cells;
     a.map = c->maps ? c->maps + (size_t)slot_base * c->H * c->W : nullptr;
     a.n_images = n_images; a.n_steps = (n_images + cam_mod - 1) / cam_mod;
     double ft = floor(c->prm.thresh);
     a.thr_mul = ft < -1.0 ? 0 : (ft > 255.0 ? 256 : (int)ft + 1);
-    a.n_strips = (c->W + 239) / 240;
     // four waves per workgroup, each sliding over rows_per_chunk rows (+8 halo rows)
-    int rows = 135; // must stay <= STAGE_ROWS (blob_filter.hip)
-    if (c->H < 4 * 32) rows = (c->H + 3) / 4 > 8 ? (c->H + 3) / 4 : 8;
-    a.rows_per_chunk = rows;
-    a.n_cgroups = (c->H + 4 * rows - 1) / (4 * rows);
+    Tiling tl = tiling(c);
+    a.n_strips = tl.n_strips; a.rows_per_chunk = tl.rows; a.n_cgroups = tl.n_cgroups;
     bool remap = false;
     for (int sl = slot_base; sl < slot_base + cam_mod; sl++) remap |= c->slot_state[sl] == 2;
     EvPair p; bool on;
@@ -256,7 +268,7 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
     return 0;
 }
 
-static int run_contours(mocap_ctx* c, const uint32_t* mask, int n_images, int32_t* out_xy, long xy_stride,
+static int run_contours(mocap_ctx* c, const uint32_t* mask, const uint32_t* cells, int n_images, int32_t* out_xy, long xy_stride,
                         int32_t* out_count, long count_stride, int max_blobs, mocap_contour* dbg, int32_t* dbg_count, int dbg_cap, hipStream_t s)
 {
     ContourArgs a;
@@ -267,6 +279,8 @@ static int run_contours(mocap_ctx* c, const uint32_t* mask, int n_images, int32_
     a.dbg = (ContourRec*)dbg; a.dbg_count = dbg_count; a.dbg_cap = dbg_cap;
     long long ms = 4LL * c->H * c->W + 16;
     a.max_steps = ms > (1 << 22) ? (1 << 22) : (int)ms;
+    Tiling tl = tiling(c);
+    a.cells = cells; a.rows_per_chunk = tl.rows; a.n_chunks = tl.n_cgroups * 4; a.n_strips = tl.n_strips;
     EvPair p; bool on;
     prof_begin(c, 1, s, p, on);
     launch_contours(a, s);
@@ -280,11 +294,16 @@ static int ensure_mask(mocap_ctx* c, int n_images)
     if ((size_t)n_images <= c->mask_images) return 0;
     std::lock_guard<std::mutex> lk(c->mu);
     if ((size_t)n_images <= c->mask_images) return 0;
-    if (c->mask) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c->mask)); c->mask = nullptr; c->mask_images = 0; }
+    if (c->mask) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c->mask)); c->mask = nullptr; c->mask_images = 0; c->cells = nullptr; c->cells_images = 0; }
     size_t bytes = sizeof(uint32_t) * (size_t)n_images * c->H * c->wpr;
     HIP_TRY(hipMalloc(&c->mask, bytes));
     HIP_TRY(hipMemset(c->mask, 0, bytes));
     c->mask_images = n_images;
+    if (c->cells) { HIP_TRY(hipFree(c->cells)); c->cells = nullptr; }
+    size_t cbytes = sizeof(uint32_t) * (size_t)n_images * cells_per_image(c);
+    HIP_TRY(hipMalloc(&c->cells, cbytes));
+    HIP_TRY(hipMemset(c->cells, 0, cbytes));
+    c->cells_images = n_images;
     return 0;
 }
 
@@ -295,7 +314,8 @@ int mocap_filter_mask(mocap_ctx_t c, const void* frames, int n_images, int cam_m
     if (rc) return rc;
     if (!mask_dev) return fail(MOCAP_E_INVALID, "null mask");
     if (set_device(c)) return MOCAP_E_HIP;
-    return run_filter(c, frames, n_images, cam_mod, slot_base, image_stride, pitch, mask_dev, (hipStream_t)stream);
+    if ((rc = ensure_mask(c, n_images))) return rc; // for the occupancy cells, which always live in the context
+    return run_filter(c, frames, n_images, cam_mod, slot_base, image_stride, pitch, mask_dev, c->cells, (hipStream_t)stream);
 }
 
 int mocap_contours_from_mask(mocap_ctx_t c, const uint32_t* mask_dev, int n_images, int32_t* out_xy, long xy_stride,
@@ -307,7 +327,7 @@ int mocap_contours_from_mask(mocap_ctx_t c, const uint32_t* mask_dev, int n_imag
         return fail(MOCAP_E_INVALID, "n_images=%d max_blobs=%d strides %ld %ld", n_images, max_blobs, xy_stride, count_stride);
     if ((dbg != nullptr) != (dbg_count != nullptr) || (dbg && dbg_cap < 1)) return fail(MOCAP_E_INVALID, "inconsistent debug buffers");
     if (set_device(c)) return MOCAP_E_HIP;
-    return run_contours(c, mask_dev, n_images, out_xy, xy_stride, out_count, count_stride, max_blobs, dbg, dbg_count, dbg_cap,
+    return run_contours(c, mask_dev, nullptr, n_images, out_xy, xy_stride, out_count, count_stride, max_blobs, dbg, dbg_count, dbg_cap,
                         (hipStream_t)stream);
 }
 
@@ -321,8 +341,8 @@ int mocap_blob_centroids(mocap_ctx_t c, const void* frames, int n_images, int ca
         return fail(MOCAP_E_INVALID, "bad output arguments");
     if (set_device(c)) return MOCAP_E_HIP;
     if ((rc = ensure_mask(c, n_images))) return rc;
-    if ((rc = run_filter(c, frames, n_images, cam_mod, slot_base, image_stride, pitch, c->mask, (hipStream_t)stream))) return rc;
-    return run_contours(c, c->mask, n_images, out_xy, xy_stride, out_count, count_stride, max_blobs, nullptr, nullptr, 0,
+    if ((rc = run_filter(c, frames, n_images, cam_mod, slot_base, image_stride, pitch, c->mask, c->cells, (hipStream_t)stream))) return rc;
+    return run_contours(c, c->mask, c->cells, n_images, out_xy, xy_stride, out_count, count_stride, max_blobs, nullptr, nullptr, 0,
                         (hipStream_t)stream);
 }
 
@@ -364,14 +384,11 @@ int mocap_image_filter_u8(mocap_ctx_t c, const void* src, void* dst, int spitch,
     a.src = (const uint8_t*)src; a.image_stride = 0; a.pitch = spitch; a.H = c->H; a.W = c->W;
     a.aligned4 = (((uintptr_t)src | (uintptr_t)spitch) & 3) == 0;
     a.mask = c->mask; a.words_per_row = c->wpr; a.cam_mod = 1; a.n_images = 1; a.n_steps = 1;
-    a.trash = (uint8_t*)(c->map_flags + c->n_slots);
+    a.cells = c->cells;
     a.map = slot >= 0 ? c->maps + (size_t)slot * c->H * c->W : nullptr;
     a.thr_mul = ithresh + 1;
-    a.n_strips = (c->W + 239) / 240;
-    int rows = 135; // must stay <= STAGE_ROWS (blob_filter.hip)
-    if (c->H < 4 * 32) rows = (c->H + 3) / 4 > 8 ? (c->H + 3) / 4 : 8;
-    a.rows_per_chunk = rows;
-    a.n_cgroups = (c->H + 4 * rows - 1) / (4 * rows);
+    Tiling tl = tiling(c);
+    a.n_strips = tl.n_strips; a.rows_per_chunk = tl.rows; a.n_cgroups = tl.n_cgroups;
     launch_filter_mask(a, slot >= 0 && c->slot_state[slot] == 2, s);
     HIP_TRY(hipGetLastError());
     launch_mask_expand(c->mask, c->wpr, (uint8_t*)dst, c->H, c->W, dpitch, s);

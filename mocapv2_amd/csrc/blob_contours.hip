@@ -9,13 +9,17 @@
 //     the raster-minimum of the border it lies on;
 //   * a hole border starts at the foreground pixel left of a background pixel whose W and N neighbours are
 //     foreground and that is the raster-minimum of the left-side cracks of the border.
-// Candidates are found with word-parallel bit tests on the mask; each candidate is followed by ONE LANE with
-// literally the reference border-following step (same neighbour order, same CHAIN_APPROX_SIMPLE vertex rule),
-// and is dropped as soon as it meets an earlier pixel of its own border.  The Green's-theorem sums are exact
+// Candidates are found with word-parallel bit tests on the mask.  Each candidate is then followed by ONE WAVE:
+// the wave keeps a 64 x 64 pixel window of the mask in registers (one 64-bit row per lane), the walker state
+// (position, direction, the three rows around the current pixel, the integer Green's-theorem sums) is
+// wave-uniform and lives in scalar registers, rows enter the scalar cache through v_readlane -- so a border step
+// costs a few dozen scalar instructions instead of a round trip to memory per neighbour probe.  The step itself is
+// literally the reference border-following step (same neighbour order, same CHAIN_APPROX_SIMPLE vertex rule);
+// a candidate is dropped as soon as it meets an earlier pixel of its own border.  The polygon sums are exact
 // integers (int64), the perimeter is a sum of float32 square roots held exactly in a double.
-// Tree order (parent = enclosing border, siblings in reverse discovery order, pre-order walk) is rebuilt
-// from "which border owns the crack left of my start pixel", found by following that border once.
-// One workgroup per image; the mask is 1/8 B per pixel and is read through L2.
+// Tree order (parent = enclosing border, siblings in reverse discovery order, pre-order walk) is rebuilt from
+// "which border owns the crack left of my start pixel", found by following that border once.
+// One workgroup (4 waves) per image; the mask is 1/8 B per pixel and is read through L2.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "kernels.h"
@@ -28,6 +32,9 @@ constexpr int MAXC = 2048;  // candidates per image
 constexpr int MAXR = 384;   // borders per image
 constexpr int MAXK = 256;   // kept contours per image
 constexpr int MAXD = 8;     // nesting depth of a kept contour
+constexpr int MAXCELL = 4096; // occupancy cells (strip x 8 rows) scanned per image
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 struct Mask {
     const uint32_t* w;
@@ -37,23 +44,26 @@ struct Mask {
     {
         return ((unsigned)y < (unsigned)H && (unsigned)k < (unsigned)wpr) ? w[(size_t)y * wpr + k] : 0u;
     }
-    // bits x-1, x, x+1 of row y in bits 0..2
-    __device__ __forceinline__ uint32_t three(int y, int x) const
+};
+
+// 64 x 64 window of the mask held by one wave: lane r has row y0 + r, bit c of its 64-bit word is column x0 + c.
+struct Window {
+    uint32_t lo, hi; // per lane
+    int x0, y0;      // wave-uniform
+    __device__ void load(const Mask& M, int nx0, int ny0, int lane)
     {
-        if ((unsigned)y >= (unsigned)H) return 0u;
-        int k = x >> 5, b = x & 31;
-        uint64_t cur = word(y, k);
-        uint64_t v = cur << 1;
-        if (b == 0) v |= (word(y, k - 1) >> 31);
-        if (b == 31) v |= ((uint64_t)(word(y, k + 1) & 1u) << 33);
-        return (uint32_t)(v >> b) & 7u;
+        x0 = nx0; y0 = ny0;
+        int y = y0 + lane;
+        int k0 = x0 >> 5, sh = x0 & 31; // arithmetic shift = floor for negative x0
+        uint32_t w0 = M.word(y, k0), w1 = M.word(y, k0 + 1), w2 = M.word(y, k0 + 2);
+        lo = sh ? (w0 >> sh) | (w1 << (32 - sh)) : w0;
+        hi = sh ? (w1 >> sh) | (w2 << (32 - sh)) : w1;
     }
-    // occupancy of the 8 neighbours of (x,y), bit s = direction code s (0=E 1=NE 2=N 3=NW 4=W 5=SW 6=S 7=SE)
-    __device__ __forceinline__ uint32_t nbr8(int x, int y) const
+    // the 64-bit row `r` (must be inside the window) as a wave-uniform value
+    __device__ __forceinline__ uint64_t row(int r) const
     {
-        uint32_t up = three(y - 1, x), mid = three(y, x), dn = three(y + 1, x);
-        return ((mid >> 2) & 1u) | (((up >> 2) & 1u) << 1) | (((up >> 1) & 1u) << 2) | ((up & 1u) << 3) |
-               ((mid & 1u) << 4) | ((dn & 1u) << 5) | (((dn >> 1) & 1u) << 6) | (((dn >> 2) & 1u) << 7);
+        uint32_t a = __builtin_amdgcn_readlane(lo, r - y0), b = __builtin_amdgcn_readlane(hi, r - y0);
+        return ((uint64_t)b << 32) | a;
     }
 };
 
@@ -67,7 +77,6 @@ struct Trace {
     int min_fg;   // raster-minimum border pixel
     int min_ebg;  // raster-minimum background pixel right of a border pixel whose East side was examined
     int status;   // 0 ok, 1 aborted (not the raster-first start), 2 step limit
-    // polygon state
     int fx, fy, px, py;
     __device__ __forceinline__ void edge(int xp, int yp, int xi, int yi)
     {
@@ -87,10 +96,12 @@ struct Trace {
     }
 };
 
-// Follow the border through pixel (sx,sy) whose neighbour in direction `first` (4 = W for an outer start,
-// 0 = E for a hole start) is background.  Aborts when a border pixel with raster index < abort_fg or an
-// East-side background pixel with raster index < abort_ebg is met.
-__device__ void follow(const Mask& M, int sx, int sy, int first, int abort_fg, int abort_ebg, int max_steps, Trace& T)
+// Border following by one wave.  Follows the border through pixel (sx,sy) whose neighbour in direction `first`
+// (4 = W for an outer start, 0 = E for a hole start) is background.  Aborts when a border pixel with raster index
+// < abort_fg or an East-side background pixel with raster index < abort_ebg is met.  Every argument and every
+// field of T is wave-uniform.
+__device__ void follow(const Mask& M, int sx, int sy, int first, int top_start, int abort_fg, int abort_ebg,
+                       int max_steps, Trace& T, int lane)
 {
     T.a00 = T.a10 = T.a01 = 0;
     T.per = 0.0;
@@ -98,7 +109,22 @@ __device__ void follow(const Mask& M, int sx, int sy, int first, int abort_fg, i
     T.status = 0;
     T.min_fg = sy * M.RS + sx;
     T.min_ebg = 0x7fffffff;
-    uint32_t n = M.nbr8(sx, sy);
+
+    Window win;
+    // a raster-first start sits on the top row of its border: put it near the top of the window
+    win.load(M, sx - 31, top_start ? sy - 2 : sy - 31, lane);
+    int x = sx, y = sy;
+    uint64_t rU = win.row(y - 1), rM = win.row(y), rD = win.row(y + 1);
+
+    // occupancy of the 8 neighbours of (x,y), bit s = direction code s (0=E 1=NE 2=N 3=NW 4=W 5=SW 6=S 7=SE)
+    auto nbr8 = [&]() -> uint32_t {
+        int c = x - win.x0 - 1; // column x-1 at bit 0
+        uint32_t up = (uint32_t)(rU >> c) & 7u, mid = (uint32_t)(rM >> c) & 7u, dn = (uint32_t)(rD >> c) & 7u;
+        return ((mid >> 2) & 1u) | (((up >> 2) & 1u) << 1) | (((up >> 1) & 1u) << 2) | ((up & 1u) << 3) |
+               ((mid & 1u) << 4) | ((dn & 1u) << 5) | (((dn >> 1) & 1u) << 6) | (((dn >> 2) & 1u) << 7);
+    };
+
+    uint32_t n = nbr8();
     int s = first, s_end = first;
     do {
         s = (s - 1) & 7;
@@ -110,7 +136,6 @@ __device__ void follow(const Mask& M, int sx, int sy, int first, int abort_fg, i
         return;
     }
     const int i1x = sx + DXc[s], i1y = sy + DYc[s];
-    int x = sx, y = sy;
     int prev_s = s ^ 4;
     for (;;) {
         s_end = s;
@@ -133,9 +158,19 @@ __device__ void follow(const Mask& M, int sx, int sy, int first, int abort_fg, i
         T.steps++;
         if (nx == sx && ny == sy && x == i1x && y == i1y) break;
         if (T.steps > max_steps) { T.status = 2; return; }
+        // move, keeping the three cached rows around the current pixel
+        int lx = nx - win.x0, ly = ny - win.y0;
+        if (lx < 1 || lx > 62 || ly < 1 || ly > 62) { // left the window: re-centre it on the new pixel
+            win.load(M, nx - 31, ny - 31, lane);
+            rU = win.row(ny - 1); rM = win.row(ny); rD = win.row(ny + 1);
+        } else if (ny > y) {
+            rU = rM; rM = rD; rD = win.row(ny + 1);
+        } else if (ny < y) {
+            rD = rM; rM = rU; rU = win.row(ny - 1);
+        }
         x = nx; y = ny;
         s = (s + 4) & 7;
-        n = M.nbr8(x, y);
+        n = nbr8();
     }
     T.edge(T.px, T.py, T.fx, T.fy); // close the polygon
 }
@@ -173,113 +208,179 @@ __global__ __launch_bounds__(256) void contours_kernel(ContourArgs a)
     __shared__ int16_t kept_idx[MAXK];
     __shared__ int32_t kept_path[MAXK][MAXD];
     __shared__ int8_t kept_depth[MAXK];
-    __shared__ int ncand, nrec, nkept, err;
+    __shared__ uint16_t cell_list[MAXCELL];
+    __shared__ int ncand, nrec, nkept, err, ncell;
 
     const int image = blockIdx.x;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = uni(tid >> 6);
     Mask M{a.mask + (size_t)image * a.H * a.words_per_row, a.words_per_row, a.H, a.W, a.W + 1};
-    if (tid == 0) { ncand = 0; nrec = 0; nkept = 0; err = 0; }
+    int32_t* const out_count = a.out_count + (size_t)image * a.count_stride;
+    if (tid == 0) { ncand = 0; nrec = 0; nkept = 0; err = 0; ncell = 0; }
     __syncthreads();
 
-    // ---- phase A: candidate starts ------------------------------------------------------------------------
-    const int total_words = a.H * a.words_per_row;
-    for (int i = tid; i < total_words; i += 256) {
-        int y = i / a.words_per_row, k = i - y * a.words_per_row;
-        uint32_t w = M.w[i];
-        uint32_t lc = k > 0 ? (M.w[i - 1] >> 31) : 0u;
-        if ((w | lc) == 0u) continue;
-        uint32_t n = M.word(y - 1, k);
-        uint32_t nlc = M.word(y - 1, k - 1) >> 31, nrc = M.word(y - 1, k + 1) & 1u;
-        uint32_t Wn = (w << 1) | lc, NW = (n << 1) | nlc, NE = (n >> 1) | (nrc << 31);
-        uint32_t outer = w & ~Wn & ~n & ~NW & ~NE;
-        uint32_t hole = ~w & Wn & n;
-        // pixels beyond the image width are background and can never be hole pixels
-        int valid = a.W - 32 * k;
-        if (valid < 32) hole &= (1u << valid) - 1u;
-        while (outer) {
-            int b = __ffs((int)outer) - 1;
-            outer &= outer - 1;
-            int slot = atomicAdd(&ncand, 1);
-            if (slot < MAXC) cand[slot] = (uint32_t)(32 * k + b) | ((uint32_t)y << 16);
+    // ---- phase A: candidate starts -------------------------------------------------------------------------------
+    // A border can only start where the mask has set pixels.  The filter kernel leaves an occupancy word per
+    // (strip, chunk): bit g = rows 8g..8g+7 of the chunk contain set pixels in that 240-column strip.  Occupied
+    // cells, plus their right and lower neighbours (a hole can start in an empty cell whose W / N neighbour pixel
+    // lies in the occupied one), are scanned row by row with word-parallel bit tests; without the occupancy words
+    // (mask supplied by the caller) every cell is scanned.
+    {
+        const int R = a.rows_per_chunk, NS = a.n_strips, NCH = a.n_chunks;
+        const int gpc = (R + 7) >> 3;                       // 8-row groups per chunk
+        const uint32_t* cells = a.cells ? a.cells + (size_t)image * NCH * NS : nullptr;
+        auto occupied = [&](int ch, int st, int g) -> bool { // wave-divergent is fine: plain loads
+            if (!cells) return true;
+            if (ch < 0 || st < 0) return false;
+            return (cells[ch * NS + st] >> g) & 1u;
+        };
+        const int n_cells = NCH * NS * gpc;
+        if (cells) {
+            for (int cell = tid; cell < n_cells; cell += 256) {
+                int g = cell % gpc, st = (cell / gpc) % NS, ch = cell / (gpc * NS);
+                int ytop = ch * R + 8 * g;
+                if (ytop >= a.H || 8 * g >= R) continue;
+                bool scan = occupied(ch, st, g) || occupied(ch, st - 1, g) ||
+                            (g > 0 ? occupied(ch, st, g - 1) : occupied(ch - 1, st, gpc - 1));
+                if (!scan) continue;
+                int slot = atomicAdd(&ncell, 1);
+                if (slot < MAXCELL) cell_list[slot] = (uint16_t)cell;
+            }
+            __syncthreads();
+            if (ncell > MAXCELL && tid == 0) atomicMax(&err, 4);
         }
-        while (hole) {
-            int b = __ffs((int)hole) - 1;
-            hole &= hole - 1;
-            int slot = atomicAdd(&ncand, 1);
-            if (slot < MAXC) cand[slot] = (uint32_t)(32 * k + b) | ((uint32_t)y << 16) | 0x8000u;
+        const int ncl = cells ? (ncell < MAXCELL ? ncell : MAXCELL) : n_cells;
+        // one task = one row of one cell: the (up to 9) mask words covering the strip's 240 columns
+        for (int t = tid; t < ncl * 8; t += 256) {
+            int cell = cells ? (int)cell_list[t >> 3] : (t >> 3), j = t & 7;
+            int g = cell % gpc, st = (cell / gpc) % NS, ch = cell / (gpc * NS);
+            int y = ch * R + 8 * g + j;
+            int yend = (ch + 1) * R < a.H ? (ch + 1) * R : a.H;
+            if (y >= yend || 8 * g + j >= R) continue;
+            const int xa = 240 * st, xb = xa + 240 < a.W ? xa + 240 : a.W; // columns [xa, xb)
+            const int ka = xa >> 5, kb = (xb - 1) >> 5;
+            uint32_t prev_w = ka > 0 ? M.word(y, ka - 1) : 0u, prev_n = ka > 0 ? M.word(y - 1, ka - 1) : 0u;
+            uint32_t cur_w = M.word(y, ka), cur_n = M.word(y - 1, ka);
+            for (int k = ka; k <= kb; k++) {
+                uint32_t next_w = M.word(y, k + 1), next_n = M.word(y - 1, k + 1);
+                uint32_t w = cur_w, n = cur_n;
+                uint32_t Wn = (w << 1) | (prev_w >> 31), NW = (n << 1) | (prev_n >> 31), NE = (n >> 1) | (next_n << 31);
+                // foreground pixels touching nothing in the row above
+                uint32_t clear_above = ~(n | NW | NE);
+                uint32_t outer = w & ~Wn & clear_above;
+                // a raster-first pixel starts a run none of whose pixels touches the row above: spread "touches"
+                // leftwards along the run (within this word; a necessary condition only -- the follow step decides)
+                uint32_t touch = w & ~clear_above;
+#pragma unroll
+                for (int i = 0; i < 12; i++) touch |= (touch >> 1) & w;
+                outer &= ~touch;
+                uint32_t hole = ~w & Wn & n;
+                // keep only this cell's columns (and, for holes, columns inside the image)
+                int lo = xa - 32 * k, hi = xb - 32 * k; // bit range [lo, hi)
+                uint32_t m = 0xffffffffu;
+                if (lo > 0) m &= ~((1u << lo) - 1u);
+                if (hi < 32) m &= (1u << hi) - 1u;
+                outer &= m; hole &= m;
+                while (outer) {
+                    int b = __ffs((int)outer) - 1;
+                    outer &= outer - 1;
+                    int slot = atomicAdd(&ncand, 1);
+                    if (slot < MAXC) cand[slot] = (uint32_t)(32 * k + b) | ((uint32_t)y << 16);
+                }
+                while (hole) {
+                    int b = __ffs((int)hole) - 1;
+                    hole &= hole - 1;
+                    int slot = atomicAdd(&ncand, 1);
+                    if (slot < MAXC) cand[slot] = (uint32_t)(32 * k + b) | ((uint32_t)y << 16) | 0x8000u;
+                }
+                prev_w = cur_w; prev_n = cur_n; cur_w = next_w; cur_n = next_n;
+            }
         }
     }
     __syncthreads();
-    if (ncand > MAXC) {
-        if (tid == 0) { a.out_count[(size_t)image * a.count_stride] = BLOB_ERR_CANDIDATES; if (a.dbg_count) a.dbg_count[image] = 0; }
+    if (ncand > MAXC || err) {
+        if (tid == 0) { *out_count = BLOB_ERR_CANDIDATES; if (a.dbg_count) a.dbg_count[image] = 0; }
         return;
     }
 
-    // ---- phase B: follow every candidate, keep the raster-first ones ---------------------------------------
-    for (int c = tid; c < ncand; c += 256) {
-        uint32_t v = cand[c];
+    // ---- phase B: one wave follows one candidate; the raster-first ones become records ---------------------------
+    const int nc = ncand;
+    for (int c = wv; c < nc; c += 4) {
+        uint32_t v = (uint32_t)uni((int)cand[c]);
         int is_hole = (v >> 15) & 1, x = v & 0x7fff, y = v >> 16;
         int key = y * M.RS + x;
         Trace T;
-        if (!is_hole) follow(M, x, y, 4, key, -1, a.max_steps, T);
-        else follow(M, x - 1, y, 0, -1, key, a.max_steps, T);
-        if (T.status == 2) atomicMax(&err, 1);
+        if (!is_hole) follow(M, x, y, 4, 1, key, -1, a.max_steps, T, lane);
+        else follow(M, x - 1, y, 0, 0, -1, key, a.max_steps, T, lane);
+        if (T.status == 2 && lane == 0) atomicMax(&err, 1);
         if (T.status != 0) continue;
-        int slot = atomicAdd(&nrec, 1);
+        int slot = 0;
+        if (lane == 0) slot = atomicAdd(&nrec, 1);
+        slot = uni(slot);
         if (slot >= MAXR) continue;
-        ContourRec& r = recs[slot];
-        r.key = key; r.is_hole = is_hole;
-        r.sx = x - is_hole; r.sy = y;
-        r.npts = T.npts; r.steps = T.steps;
-        r.a00 = T.a00; r.a10 = T.a10; r.a01 = T.a01;
-        r.area = fabs((double)T.a00 * 0.5);
-        r.perimeter = T.npts > 1 ? T.per : 0.0;
-        r.link = -1; r.parent = -1; r.order = -1;
-        select_contour(r, a.min_area, a.min_circ);
+        if (lane == 0) {
+            ContourRec& r = recs[slot];
+            r.key = key; r.is_hole = is_hole;
+            r.sx = x - is_hole; r.sy = y;
+            r.npts = T.npts; r.steps = T.steps;
+            r.a00 = T.a00; r.a10 = T.a10; r.a01 = T.a01;
+            r.area = fabs((double)T.a00 * 0.5);
+            r.perimeter = T.npts > 1 ? T.per : 0.0;
+            r.link = -1; r.parent = -1; r.order = -1;
+            select_contour(r, a.min_area, a.min_circ);
+        }
     }
     __syncthreads();
     if (nrec > MAXR || err) {
-        if (tid == 0) { a.out_count[(size_t)image * a.count_stride] = err ? BLOB_ERR_STEPS : BLOB_ERR_CONTOURS; if (a.dbg_count) a.dbg_count[image] = 0; }
+        if (tid == 0) { *out_count = err ? BLOB_ERR_STEPS : BLOB_ERR_CONTOURS; if (a.dbg_count) a.dbg_count[image] = 0; }
         return;
     }
 
-    // ---- phase C1: link = the border that owns the crack met when scanning left from the start ---------------
+    // ---- phase C1: link = the border that owns the crack met when scanning left from the start ------------------
     //   outer border: nearest foreground pixel left of the start on the same row -> its East crack
     //   hole border : left end of the foreground run holding the start pixel     -> its West crack
-    for (int c = tid; c < nrec; c += 256) {
-        ContourRec& r = recs[c];
-        int y = r.sy, qx = -1;
-        if (!r.is_hole) {
-            int x = r.sx - 1; // background
-            for (int k = x >> 5; k >= 0 && x >= 0; k--) {
-                uint32_t w = M.word(y, k);
-                if (k == (x >> 5)) w &= (x & 31) == 31 ? 0xffffffffu : ((2u << (x & 31)) - 1u);
-                if (w) { qx = 32 * k + 31 - __clz((int)w); break; }
-            }
-        } else {
-            int x = r.sx; // foreground; find the nearest background pixel to the left
-            qx = 0;
-            for (int k = x >> 5; k >= 0; k--) {
-                uint32_t w = ~M.word(y, k);
-                if (k == (x >> 5)) w &= (x & 31) == 31 ? 0xffffffffu : ((2u << (x & 31)) - 1u);
-                if (w) { qx = 32 * k + 31 - __clz((int)w) + 1; break; }
+    const int nr = nrec;
+    for (int c = wv; c < nr; c += 4) {
+        const int r_is_hole = uni(recs[c].is_hole), r_sx = uni(recs[c].sx), y = uni(recs[c].sy);
+        // hole: nearest background pixel at/left of the start; outer: nearest foreground pixel left of it.
+        // The words of the row up to that column are examined 64 at a time, one per lane, right to left.
+        const int xs = r_is_hole ? r_sx : r_sx - 1;
+        int qx = r_is_hole ? 0 : -1;
+        for (int kbase = xs >> 5; kbase >= 0 && xs >= 0; kbase -= 64) {
+            int k = kbase - lane;
+            uint32_t w = k >= 0 ? M.word(y, k) : 0u;
+            if (r_is_hole) w = k >= 0 ? ~w : 0u;
+            if (k == (xs >> 5)) w &= (2u << (xs & 31)) - 1u; // only columns <= xs
+            uint64_t bal = __ballot(w != 0u);
+            if (bal) {
+                int src = __ffsll((long long)bal) - 1; // lowest lane = rightmost word
+                uint32_t ww = (uint32_t)__builtin_amdgcn_readlane((int)w, src);
+                int px = 32 * (kbase - src) + 31 - __clz((int)ww);
+                qx = r_is_hole ? px + 1 : px;
+                break;
             }
         }
-        if (qx < 0) { r.link = -1; continue; } // nothing to the left: the frame
+        if (qx < 0) { if (lane == 0) recs[c].link = -1; continue; } // nothing to the left: the frame
         Trace T;
-        follow(M, qx, y, r.is_hole ? 4 : 0, -1, -1, a.max_steps, T);
-        if (T.status) { atomicMax(&err, 1); continue; }
-        int ltype = T.a00 > 0 ? 1 : 0;            // hole borders run the other way round
+        follow(M, qx, y, r_is_hole ? 4 : 0, 0, -1, -1, a.max_steps, T, lane);
+        if (T.status) { if (lane == 0) atomicMax(&err, 1); continue; }
+        int ltype = T.a00 > 0 ? 1 : 0; // hole borders run the other way round
         int lkey = ltype ? T.min_ebg : T.min_fg;
         int found = -2;
-        for (int j = 0; j < nrec; j++)
-            if (recs[j].key == lkey && recs[j].is_hole == ltype) { found = j; break; }
-        if (found == -2) atomicMax(&err, 2);
-        r.link = found;
+        for (int jb = 0; jb < nr; jb += 64) {
+            int j = jb + lane;
+            bool hit = j < nr && recs[j].key == lkey && recs[j].is_hole == ltype;
+            uint64_t bal = __ballot(hit);
+            if (bal) { found = jb + __ffsll((long long)bal) - 1; break; }
+        }
+        if (lane == 0) {
+            if (found == -2) atomicMax(&err, 2);
+            recs[c].link = found;
+        }
     }
     __syncthreads();
     if (err) {
-        if (tid == 0) { a.out_count[(size_t)image * a.count_stride] = err == 1 ? BLOB_ERR_STEPS : BLOB_ERR_CONTOURS; if (a.dbg_count) a.dbg_count[image] = 0; }
+        if (tid == 0) { *out_count = err == 1 ? BLOB_ERR_STEPS : BLOB_ERR_CONTOURS; if (a.dbg_count) a.dbg_count[image] = 0; }
         return;
     }
 
@@ -303,7 +404,7 @@ __global__ __launch_bounds__(256) void contours_kernel(ContourArgs a)
     }
     __syncthreads();
     if (err || nkept > MAXK) {
-        if (tid == 0) { a.out_count[(size_t)image * a.count_stride] = err ? BLOB_ERR_DEPTH : BLOB_ERR_CONTOURS; if (a.dbg_count) a.dbg_count[image] = 0; }
+        if (tid == 0) { *out_count = err ? BLOB_ERR_DEPTH : BLOB_ERR_CONTOURS; if (a.dbg_count) a.dbg_count[image] = 0; }
         return;
     }
 
@@ -327,7 +428,7 @@ __global__ __launch_bounds__(256) void contours_kernel(ContourArgs a)
             o[0] = r.cx; o[1] = r.cy;
         }
     }
-    if (tid == 0) a.out_count[(size_t)image * a.count_stride] = nkept;
+    if (tid == 0) *out_count = nkept;
     if (a.dbg) {
         for (int c = tid; c < nrec && c < a.dbg_cap; c += 256) a.dbg[(size_t)image * a.dbg_cap + c] = recs[c];
         if (tid == 0) a.dbg_count[image] = nrec;

@@ -310,6 +310,8 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
     const int ke = r1 + 1 < Hm1 ? r1 + 1 : Hm1;
 
     uint32_t V01 = 0, V23 = 0, Cv = 0;
+    uint32_t lacc = 0; // per lane: bit g = this lane's columns have set pixels in output rows r0+8g .. r0+8g+7
+    const bool out_lane = lane >= 2 && lane <= 61;
     // source-row queue, 8 deep.  q[3] holds the first row so that the five set-up slides consume q[3..7] and the
     // steady loop starts at q[0] / ring slot 0 with all indices static.
     uint32_t q[8];
@@ -405,6 +407,7 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
         uint32_t mm = ((Cv + 0x73737373u) >> 7) & 0x01010101u;
         uint32_t t1 = mm | (mm >> 7);
         uint32_t mn = (t1 | (t1 >> 14)) & colmask;
+        lacc |= (mn != 0u ? 1u : 0u) << (((on ? row : r0) - r0) >> 3); // rows not yet valid have mn from a partial window: harmless superset
         uint32_t odd = lane_from_next(mn);
         uint32_t byte = (mn & 0xfu) | ((odd & 0xfu) << 4);
         if (PIPE) {
@@ -470,6 +473,13 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
             cj++;
             if (kk >= r0 + 2) emit(kk - 2, true);
         }
+    }
+    {   // occupancy word of this (strip, chunk): OR of the output lanes' bits
+        uint32_t cellmask = 0;
+        const int groups = (r1 - r0 + 7) >> 3;
+        for (int g = 0; g < groups; g++)
+            if (__ballot(out_lane && ((lacc >> g) & 1u)) != 0ull) cellmask |= 1u << g;
+        if (lane == 0) a.cells[((size_t)image * a.n_cgroups * 4 + (cgroup * 4 + wv)) * a.n_strips + strip] = cellmask;
     }
     // ---- write the staged rows out: 15 two-byte stores per row, two rows per wave instruction ----
     if (PIPE) {

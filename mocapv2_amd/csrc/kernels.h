@@ -12,7 +12,7 @@ struct FilterArgs {
     int aligned4;         // src base, pitch and image_stride are multiples of 4
     uint32_t* mask;       // [n_images][H][words_per_row], bit b of word k = pixel 32k+b
     int words_per_row;
-    uint8_t* trash;       // >= 256 bytes: where lanes with nothing to write put their byte
+    uint32_t* cells;      // [n_images][n_cgroups*4][n_strips]: bit g = rows 8g..8g+7 of the chunk have set pixels in the strip
     const uint32_t* map;  // [cam_mod][H][W] packed (dx | dy<<16) in 1/32 px (remap variant only)
     int cam_mod;          // undistort slot of image n = n % cam_mod (map already points at the first slot)
     int n_images, n_steps; // n_steps = ceil(n_images / cam_mod)
@@ -54,6 +54,8 @@ struct ContourArgs {
     int32_t* dbg_count;  // optional [n_images]
     int dbg_cap;
     int max_steps;
+    const uint32_t* cells; // occupancy written by the filter kernel (see FilterArgs), or null = scan every row
+    int rows_per_chunk, n_chunks, n_strips;
 };
 
 enum { BLOB_ERR_CANDIDATES = -2, BLOB_ERR_CONTOURS = -3, BLOB_ERR_STEPS = -4, BLOB_ERR_DEPTH = -5 };
