@@ -41,7 +41,7 @@ struct EvPair { hipEvent_t a, b; };
 struct mocap_ctx {
     int device, W, H, n_slots, wpr;
     mocap_blob_params prm;
-    uint32_t* maps;           // [n_slots][H][W]
+    uint32_t* maps;           // [2][n_slots][H][W]: tap positions, then blend weights
     uint32_t* map_flags;      // [n_slots] device, followed by 256 trash bytes
     std::vector<int> slot_state; // 0 unset, 1 identity, 2 remap
     uint32_t* mask; size_t mask_images;
@@ -126,22 +126,19 @@ int mocap_set_undistort(mocap_ctx_t c, int slot, const double K[9], const double
     if (set_device(c)) return MOCAP_E_HIP;
     std::lock_guard<std::mutex> lk(c->mu);
     size_t per = (size_t)c->H * c->W;
-    if (!c->maps) HIP_TRY(hipMalloc(&c->maps, sizeof(uint32_t) * per * c->n_slots));
+    if (!c->maps) HIP_TRY(hipMalloc(&c->maps, sizeof(uint32_t) * per * c->n_slots * 2));
     MapArgs m;
     memcpy(m.K, K, sizeof(m.K));
     memcpy(m.dist, dist, sizeof(m.dist));
     m.H = c->H; m.W = c->W;
     m.map = c->maps + per * slot;
+    m.mapw = c->maps + per * (c->n_slots + slot);
     m.flags = c->map_flags + slot;
     HIP_TRY(hipMemset(m.flags, 0, sizeof(uint32_t)));
     launch_undistort_map(m, 0);
     HIP_TRY(hipGetLastError());
     uint32_t flags = 0;
     HIP_TRY(hipMemcpy(&flags, m.flags, sizeof(flags), hipMemcpyDeviceToHost));
-    if (flags & 2u) {
-        c->slot_state[slot] = 0;
-        return fail(MOCAP_E_UNSUPPORTED, "undistort displacement exceeds +-1024 px for slot %d", slot);
-    }
     c->slot_state[slot] = (flags & 1u) ? 2 : 1;
     if (identity_out) *identity_out = c->slot_state[slot] == 1;
     return MOCAP_OK;
@@ -235,7 +232,7 @@ struct Tiling { int rows, n_cgroups, n_strips; };
 static Tiling tiling(const mocap_ctx* c)
 {
     Tiling t;
-    t.rows = 135; // must stay <= STAGE_ROWS (blob_filter.hip)
+    t.rows = 135; // <= 136 so that a chunk's 8-row groups fit one 32-bit occupancy word
     if (c->H < 4 * 32) t.rows = (c->H + 3) / 4 > 8 ? (c->H + 3) / 4 : 8;
     t.n_cgroups = (c->H + 4 * t.rows - 1) / (4 * t.rows);
     t.n_strips = (c->W + 239) / 240;
@@ -252,6 +249,7 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
     a.mask = mask; a.words_per_row = c->wpr; a.cam_mod = cam_mod;
     a.cells = cells;
     a.map = c->maps ? c->maps + (size_t)slot_base * c->H * c->W : nullptr;
+    a.mapw = c->maps ? c->maps + (size_t)(c->n_slots + slot_base) * c->H * c->W : nullptr;
     a.n_images = n_images; a.n_steps = (n_images + cam_mod - 1) / cam_mod;
     double ft = floor(c->prm.thresh);
     a.thr_mul = ft < -1.0 ? 0 : (ft > 255.0 ? 256 : (int)ft + 1);
@@ -281,6 +279,7 @@ static int run_contours(mocap_ctx* c, const uint32_t* mask, const uint32_t* cell
     a.max_steps = ms > (1 << 22) ? (1 << 22) : (int)ms;
     Tiling tl = tiling(c);
     a.cells = cells; a.rows_per_chunk = tl.rows; a.n_chunks = tl.n_cgroups * 4; a.n_strips = tl.n_strips;
+    { const char* e = getenv("MOCAP_DEBUG_STOP"); a.debug_stop = e ? atoi(e) : 0; }
     EvPair p; bool on;
     prof_begin(c, 1, s, p, on);
     launch_contours(a, s);
@@ -352,7 +351,8 @@ int mocap_undistort_u8(mocap_ctx_t c, int slot, const void* src, void* dst, int 
     if (slot < 0 || slot >= c->n_slots || c->slot_state[slot] == 0) return fail(MOCAP_E_STATE, "undistort slot %d not set", slot);
     if (spitch < c->W || dpitch < c->W) return fail(MOCAP_E_INVALID, "pitch < width");
     if (set_device(c)) return MOCAP_E_HIP;
-    launch_undistort((const uint8_t*)src, (uint8_t*)dst, c->H, c->W, spitch, dpitch, c->maps + (size_t)slot * c->H * c->W, (hipStream_t)stream);
+    launch_undistort((const uint8_t*)src, (uint8_t*)dst, c->H, c->W, spitch, dpitch, c->maps + (size_t)slot * c->H * c->W,
+                     c->maps + (size_t)(c->n_slots + slot) * c->H * c->W, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return MOCAP_OK;
 }
@@ -386,6 +386,7 @@ int mocap_image_filter_u8(mocap_ctx_t c, const void* src, void* dst, int spitch,
     a.mask = c->mask; a.words_per_row = c->wpr; a.cam_mod = 1; a.n_images = 1; a.n_steps = 1;
     a.cells = c->cells;
     a.map = slot >= 0 ? c->maps + (size_t)slot * c->H * c->W : nullptr;
+    a.mapw = slot >= 0 ? c->maps + (size_t)(c->n_slots + slot) * c->H * c->W : nullptr;
     a.thr_mul = ithresh + 1;
     Tiling tl = tiling(c);
     a.n_strips = tl.n_strips; a.rows_per_chunk = tl.rows; a.n_cgroups = tl.n_cgroups;

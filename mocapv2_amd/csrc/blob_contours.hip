@@ -19,7 +19,7 @@
 // integers (int64), the perimeter is a sum of float32 square roots held exactly in a double.
 // Tree order (parent = enclosing border, siblings in reverse discovery order, pre-order walk) is rebuilt from
 // "which border owns the crack left of my start pixel", found by following that border once.
-// One workgroup (4 waves) per image; the mask is 1/8 B per pixel and is read through L2.
+// One workgroup (16 waves) per image; the mask is 1/8 B per pixel and is read through L2.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "kernels.h"
@@ -67,8 +67,10 @@ struct Window {
     }
 };
 
-__device__ const int DXc[8] = {1, 1, 0, -1, -1, -1, 0, 1};
-__device__ const int DYc[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+// step of direction code s (0=E 1=NE 2=N 3=NW 4=W 5=SW 6=S 7=SE), from packed 2-bit tables (value + 1) so that the
+// scalar walker needs no memory access per step
+__device__ __forceinline__ int dir_dx(int s) { return (int)((0x901au >> (2 * s)) & 3u) - 1; }  // 1,1,0,-1,-1,-1,0,1
+__device__ __forceinline__ int dir_dy(int s) { return (int)((0xa901u >> (2 * s)) & 3u) - 1; }  // 0,-1,-1,-1,0,1,1,1
 
 struct Trace {
     int64_t a00, a10, a01;
@@ -135,7 +137,7 @@ __device__ void follow(const Mask& M, int sx, int sy, int first, int top_start, 
         T.edge(T.px, T.py, T.fx, T.fy);
         return;
     }
-    const int i1x = sx + DXc[s], i1y = sy + DYc[s];
+    const int i1x = sx + dir_dx(s), i1y = sy + dir_dy(s);
     int prev_s = s ^ 4;
     for (;;) {
         s_end = s;
@@ -154,7 +156,7 @@ __device__ void follow(const Mask& M, int sx, int sy, int first, int top_start, 
             T.vertex(x, y);
             prev_s = s;
         }
-        int nx = x + DXc[s], ny = y + DYc[s];
+        int nx = x + dir_dx(s), ny = y + dir_dy(s);
         T.steps++;
         if (nx == sx && ny == sy && x == i1x && y == i1y) break;
         if (T.steps > max_steps) { T.status = 2; return; }
@@ -201,7 +203,9 @@ __device__ void select_contour(ContourRec& r, double min_area, double min_circ)
 
 } // namespace
 
-__global__ __launch_bounds__(256) void contours_kernel(ContourArgs a)
+constexpr int NTHREADS = 1024, NWAVES = NTHREADS / 64;
+
+__global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
 {
     __shared__ uint32_t cand[MAXC];
     __shared__ ContourRec recs[MAXR];
@@ -218,6 +222,7 @@ __global__ __launch_bounds__(256) void contours_kernel(ContourArgs a)
     int32_t* const out_count = a.out_count + (size_t)image * a.count_stride;
     if (tid == 0) { ncand = 0; nrec = 0; nkept = 0; err = 0; ncell = 0; }
     __syncthreads();
+    if (a.debug_stop == 9) return;
 
     // ---- phase A: candidate starts -------------------------------------------------------------------------------
     // A border can only start where the mask has set pixels.  The filter kernel leaves an occupancy word per
@@ -236,7 +241,7 @@ __global__ __launch_bounds__(256) void contours_kernel(ContourArgs a)
         };
         const int n_cells = NCH * NS * gpc;
         if (cells) {
-            for (int cell = tid; cell < n_cells; cell += 256) {
+            for (int cell = tid; cell < n_cells; cell += NTHREADS) {
                 int g = cell % gpc, st = (cell / gpc) % NS, ch = cell / (gpc * NS);
                 int ytop = ch * R + 8 * g;
                 if (ytop >= a.H || 8 * g >= R) continue;
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(256) void contours_kernel(ContourArgs a)
         }
         const int ncl = cells ? (ncell < MAXCELL ? ncell : MAXCELL) : n_cells;
         // one task = one row of one cell: the (up to 9) mask words covering the strip's 240 columns
-        for (int t = tid; t < ncl * 8; t += 256) {
+        for (int t = tid; t < ncl * 8; t += NTHREADS) {
             int cell = cells ? (int)cell_list[t >> 3] : (t >> 3), j = t & 7;
             int g = cell % gpc, st = (cell / gpc) % NS, ch = cell / (gpc * NS);
             int y = ch * R + 8 * g + j;
@@ -264,17 +269,28 @@ __global__ __launch_bounds__(256) void contours_kernel(ContourArgs a)
             for (int k = ka; k <= kb; k++) {
                 uint32_t next_w = M.word(y, k + 1), next_n = M.word(y - 1, k + 1);
                 uint32_t w = cur_w, n = cur_n;
-                uint32_t Wn = (w << 1) | (prev_w >> 31), NW = (n << 1) | (prev_n >> 31), NE = (n >> 1) | (next_n << 31);
-                // foreground pixels touching nothing in the row above
-                uint32_t clear_above = ~(n | NW | NE);
-                uint32_t outer = w & ~Wn & clear_above;
-                // a raster-first pixel starts a run none of whose pixels touches the row above: spread "touches"
-                // leftwards along the run (within this word; a necessary condition only -- the follow step decides)
-                uint32_t touch = w & ~clear_above;
+                uint32_t Wn = (w << 1) | (prev_w >> 31);
+                // Necessary conditions, evaluated on the 64 columns starting at this word (this word + the next):
+                // a raster-first foreground pixel starts a run none of whose pixels touches (8-connectivity) the
+                // row above; a raster-first hole pixel starts a background run none of whose pixels has
+                // background directly above (4-connectivity).  "Touches" are spread leftwards along the run for 24
+                // columns; beyond that the candidate is merely kept -- the follow step decides.
+                uint64_t w64 = (uint64_t)w | ((uint64_t)next_w << 32), n64 = (uint64_t)n | ((uint64_t)next_n << 32);
+                uint64_t above64 = n64 | (n64 << 1) | (uint64_t)(prev_n >> 31) | (n64 >> 1); // NE of column 63 unknown: treated as clear
+                uint32_t outer = w & ~Wn & ~(uint32_t)above64;
+                if (outer) {
+                    uint64_t touch = w64 & above64;
 #pragma unroll
-                for (int i = 0; i < 12; i++) touch |= (touch >> 1) & w;
-                outer &= ~touch;
+                    for (int i = 0; i < 24; i++) touch |= (touch >> 1) & w64;
+                    outer &= ~(uint32_t)touch;
+                }
                 uint32_t hole = ~w & Wn & n;
+                if (hole) {
+                    uint64_t bg64 = ~w64, touch = bg64 & ~n64;
+#pragma unroll
+                    for (int i = 0; i < 24; i++) touch |= (touch >> 1) & bg64;
+                    hole &= ~(uint32_t)touch;
+                }
                 // keep only this cell's columns (and, for holes, columns inside the image)
                 int lo = xa - 32 * k, hi = xb - 32 * k; // bit range [lo, hi)
                 uint32_t m = 0xffffffffu;
@@ -303,9 +319,10 @@ __global__ __launch_bounds__(256) void contours_kernel(ContourArgs a)
         return;
     }
 
+    if (a.debug_stop == 1) return;
     // ---- phase B: one wave follows one candidate; the raster-first ones become records ---------------------------
     const int nc = ncand;
-    for (int c = wv; c < nc; c += 4) {
+    for (int c = wv; c < nc; c += NWAVES) {
         uint32_t v = (uint32_t)uni((int)cand[c]);
         int is_hole = (v >> 15) & 1, x = v & 0x7fff, y = v >> 16;
         int key = y * M.RS + x;
@@ -336,11 +353,12 @@ __global__ __launch_bounds__(256) void contours_kernel(ContourArgs a)
         return;
     }
 
+    if (a.debug_stop == 2) return;
     // ---- phase C1: link = the border that owns the crack met when scanning left from the start ------------------
     //   outer border: nearest foreground pixel left of the start on the same row -> its East crack
     //   hole border : left end of the foreground run holding the start pixel     -> its West crack
     const int nr = nrec;
-    for (int c = wv; c < nr; c += 4) {
+    for (int c = wv; c < nr; c += NWAVES) {
         const int r_is_hole = uni(recs[c].is_hole), r_sx = uni(recs[c].sx), y = uni(recs[c].sy);
         // hole: nearest background pixel at/left of the start; outer: nearest foreground pixel left of it.
         // The words of the row up to that column are examined 64 at a time, one per lane, right to left.
@@ -384,14 +402,15 @@ __global__ __launch_bounds__(256) void contours_kernel(ContourArgs a)
         return;
     }
 
+    if (a.debug_stop == 3) return;
     // ---- phase C2: parents (Suzuki's table: same kind -> the link's parent, else the link itself) -----------
-    for (int c = tid; c < nrec; c += 256) {
+    for (int c = tid; c < nrec; c += NTHREADS) {
         int me = recs[c].is_hole, j = recs[c].link, guard = 0;
         while (j >= 0 && recs[j].is_hole == me && guard++ < MAXR) j = recs[j].link;
         recs[c].parent = j;
     }
     __syncthreads();
-    for (int c = tid; c < nrec; c += 256) {
+    for (int c = tid; c < nrec; c += NTHREADS) {
         if (!recs[c].kept) continue;
         int slot = atomicAdd(&nkept, 1);
         if (slot >= MAXK) continue;
@@ -409,7 +428,7 @@ __global__ __launch_bounds__(256) void contours_kernel(ContourArgs a)
     }
 
     // ---- phase C3: position in the pre-order walk with siblings in reverse discovery order -------------------
-    for (int c = tid; c < nkept; c += 256) {
+    for (int c = tid; c < nkept; c += NTHREADS) {
         int rank = 0, da = kept_depth[c];
         for (int o = 0; o < nkept; o++) {
             if (o == c) continue;
@@ -430,14 +449,14 @@ __global__ __launch_bounds__(256) void contours_kernel(ContourArgs a)
     }
     if (tid == 0) *out_count = nkept;
     if (a.dbg) {
-        for (int c = tid; c < nrec && c < a.dbg_cap; c += 256) a.dbg[(size_t)image * a.dbg_cap + c] = recs[c];
+        for (int c = tid; c < nrec && c < a.dbg_cap; c += NTHREADS) a.dbg[(size_t)image * a.dbg_cap + c] = recs[c];
         if (tid == 0) a.dbg_count[image] = nrec;
     }
 }
 
 void launch_contours(const ContourArgs& a, hipStream_t s)
 {
-    hipLaunchKernelGGL(contours_kernel, dim3(a.n_images), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(contours_kernel, dim3(a.n_images), dim3(NTHREADS), 0, s, a);
 }
 
 } // namespace mocap

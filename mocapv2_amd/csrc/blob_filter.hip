@@ -42,36 +42,18 @@ __device__ __forceinline__ uint32_t load_u16(const uint8_t* p)
     return v;
 }
 
-// one undistorted pixel (cv::remap, INTER_LINEAR, BORDER_CONSTANT 0) through the packed (dx,dy) map
-__device__ __forceinline__ uint32_t remap_px(const uint8_t* __restrict__ img, int pitch, int H, int W,
-                                             uint32_t m, int x, int y)
+// One undistorted pixel (cv::remap, INTER_LINEAR, BORDER_CONSTANT 0) from the two set-up tables: `m` places the
+// 2x2 tap window (already clamped into the image), `w` holds the four blend weights with border handling baked in
+// (a tap outside the image weighs 0).  Taps with zero weight are not read.  General form, used off the hot path.
+__device__ __forceinline__ uint32_t remap_px(const uint8_t* __restrict__ img, int pitch, uint32_t m, uint32_t w, int x, int y)
 {
-    int dx = (int)(int16_t)(m & 0xffffu), dy = (int)m >> 16;
-    int iu = 32 * x + dx, iv = 32 * y + dy;
-    int sx = iu >> 5, sy = iv >> 5;
-    uint32_t a = iu & 31, b = iv & 31;
-    uint32_t p00, p01, p10, p11;
-    if ((unsigned)sx < (unsigned)(W - 1) && (unsigned)sy < (unsigned)(H - 1)) { // all four taps inside (the common case)
-        const uint8_t* r = img + (size_t)sy * pitch + sx;
-        uint32_t t0 = load_u16(r), t1 = load_u16(r + pitch);
-        p00 = t0 & 0xffu; p01 = t0 >> 8; p10 = t1 & 0xffu; p11 = t1 >> 8;
-    } else {
-        p00 = p01 = p10 = p11 = 0;
-        bool x0ok = (unsigned)sx < (unsigned)W, x1ok = (unsigned)(sx + 1) < (unsigned)W;
-        if ((unsigned)sy < (unsigned)H) {
-            const uint8_t* r = img + (size_t)sy * pitch;
-            if (x0ok) p00 = r[sx];
-            if (x1ok) p01 = r[sx + 1];
-        }
-        if ((unsigned)(sy + 1) < (unsigned)H) {
-            const uint8_t* r = img + (size_t)(sy + 1) * pitch;
-            if (x0ok) p10 = r[sx];
-            if (x1ok) p11 = r[sx + 1];
-        }
-    }
-    uint32_t na = 32u - a;
-    uint32_t top = __umul24(p00, na) + __umul24(p01, a), bot = __umul24(p10, na) + __umul24(p11, a);
-    return ((__umul24(top, 32u - b) + __umul24(bot, b)) * 32u + (1u << 14)) >> 15;
+    int sx = x + (int)(int16_t)(m & 0xffffu), sy = y + ((int)m >> 16);
+    uint32_t wx0 = w & 0xffu, wx1 = (w >> 8) & 0xffu, wy1 = (w >> 16) & 0xffu, wy0 = w >> 24;
+    const uint8_t* r = img + (size_t)sy * pitch + sx;
+    uint32_t p00 = (wx0 && wy0) ? r[0] : 0u, p01 = (wx1 && wy0) ? r[1] : 0u;
+    uint32_t p10 = (wx0 && wy1) ? r[pitch] : 0u, p11 = (wx1 && wy1) ? r[pitch + 1] : 0u;
+    uint32_t top = p00 * wx0 + p01 * wx1, bot = p10 * wx0 + p11 * wx1;
+    return (top * wy0 + bot * wy1 + 512u) >> 10; // == (sum of 32*w*p + 2^14) >> 15
 }
 
 // per-lane column constants of a 4-pixel group starting at column xl
@@ -110,17 +92,11 @@ __device__ __forceinline__ uint32_t fetch_src4(const FilterArgs& a, const uint8_
         if ((unsigned)y >= (unsigned)a.H) return 0u;
         uint32_t out = 0;
         const uint32_t* mrow = map + (size_t)yc * a.W;
-        if (lc.interior) {
-            uint4 m;
-            __builtin_memcpy(&m, mrow + xl, 16);
-            out = remap_px(img, a.pitch, a.H, a.W, m.x, xl, yc) | (remap_px(img, a.pitch, a.H, a.W, m.y, xl + 1, yc) << 8) |
-                  (remap_px(img, a.pitch, a.H, a.W, m.z, xl + 2, yc) << 16) | (remap_px(img, a.pitch, a.H, a.W, m.w, xl + 3, yc) << 24);
-        } else {
+        const uint32_t* wrow = a.mapw + (map - a.map) + (size_t)yc * a.W;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                int x = xl + k;
-                if ((unsigned)x < (unsigned)a.W) out |= remap_px(img, a.pitch, a.H, a.W, mrow[x], x, yc) << (8 * k);
-            }
+        for (int k = 0; k < 4; k++) {
+            int x = xl + k;
+            if ((unsigned)x < (unsigned)a.W) out |= remap_px(img, a.pitch, mrow[x], wrow[x], x, yc) << (8 * k);
         }
         return out;
     } else {
@@ -146,10 +122,10 @@ __device__ __forceinline__ uint32_t finish_src4(uint32_t raw, bool row_ok, const
 
 // ---- software-pipelined remap (three stages, each one source row apart in time) -----------------------------
 //   A: issue the load of the row's four packed map words          (8 rows ahead of use)
-//   B: decode them, issue the 2x2 tap loads, build blend weights  (4 rows ahead of use)
+//   B: decode them, issue the 2x2 tap loads and the weight load    (4 rows ahead of use)
 //   C: blend the taps                                             (at use)
-// so that neither memory latency is exposed.  Pixels whose taps are not all inside the image (image border only)
-// are resolved synchronously in stage B and carried as (value, identity weights).
+// so that neither memory latency is exposed.  Border handling lives in the tables (tap window clamped into the
+// image, weights of outside taps zero), so the stages contain no image-edge logic at all.
 struct MapSlot { uint4 m; };
 struct TapSlot { uint32_t t0[4], t1[4], w[4]; };
 
@@ -160,52 +136,24 @@ __device__ __forceinline__ void remap_issue_map(MapSlot& ms, const uint32_t* __r
     __builtin_memcpy(&ms.m, map + ((uint32_t)rc * (uint32_t)W + (uint32_t)lc.addr_x), 16);
 }
 
-// blend weights of one axis when the 2-tap window [s, s+1] was loaded at the clamped position sc:
-// a tap that fell outside the image reads 0 (BORDER_CONSTANT), i.e. its weight moves to nothing
-__device__ __forceinline__ void edge_weights(int s, int sc, uint32_t f, uint32_t& w0, uint32_t& w1)
+__device__ __forceinline__ void remap_issue_taps(TapSlot& ts, const MapSlot& ms, const uint8_t* __restrict__ img,
+                                                 const uint32_t* __restrict__ mapw, int pitch, int H, int W, int row,
+                                                 const int xq[4], const LaneCols& lc)
 {
-    int d = s - sc;
-    uint32_t nf = 32u - f;
-    w0 = d == 0 ? nf : (d == -1 ? f : 0u);
-    w1 = d == 0 ? f : (d == 1 ? nf : 0u);
-}
-
-__device__ __forceinline__ void remap_issue_taps(TapSlot& ts, const MapSlot& ms, const uint8_t* __restrict__ img, int pitch,
-                                                 int H, int W, int row, const int xq[4])
-{
-    // rows outside the image contribute zeros: same loads (row clamped), weights forced to 0 -- no branch around
-    // the loads, so the compiler's in-flight counts stay exact
-    const bool row_ok = (unsigned)row < (unsigned)H;
-    const uint32_t wmask = row_ok ? 0xffffffffu : 0u;
+    // Rows outside the image contribute zeros; their loads are simply those of the nearest row (no branch around
+    // loads: the compiler's in-flight counts stay exact) and next_row() discards the result.
     row = row < 0 ? 0 : (row > H - 1 ? H - 1 : row);
-    const uint8_t* base = img;
     const uint32_t mm[4] = {ms.m.x, ms.m.y, ms.m.z, ms.m.w};
-    bool bad = false;
+    uint4 wv4;
+    __builtin_memcpy(&wv4, mapw + ((uint32_t)row * (uint32_t)W + (uint32_t)lc.addr_x), 16);
+    ts.w[0] = wv4.x; ts.w[1] = wv4.y; ts.w[2] = wv4.z; ts.w[3] = wv4.w;
 #pragma unroll
-    for (int k = 0; k < 4; k++) { // no branch around the loads: the compiler keeps exact in-flight counts
+    for (int k = 0; k < 4; k++) {
         uint32_t m = mm[k];
-        int iu = 32 * xq[k] + (int)(int16_t)(m & 0xffffu), iv = 32 * row + ((int)m >> 16);
-        int sx = iu >> 5, sy = iv >> 5;
-        uint32_t a = iu & 31, b = iv & 31;
-        int sxc = max(0, min(sx, W - 2)), syc = max(0, min(sy, H - 2));
-        bad |= (sx != sxc) | (sy != syc);
-        uint32_t off0 = __umul24((uint32_t)syc, (uint32_t)pitch) + (uint32_t)sxc, off1 = off0 + (uint32_t)pitch;
-        ts.t0[k] = load_u16(base + off0);
-        ts.t1[k] = load_u16(base + off1);
-        ts.w[k] = ((0x20000020u + __umul24(a, 0xffu)) - __umul24(b, 0xff0000u)) & wmask; // bytes: 32-a | a | b | 32-b
-    }
-    if (__any(bad)) { // wave-uniform, image border only: some tap fell outside the image
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            uint32_t m = mm[k];
-            int iu = 32 * xq[k] + (int)(int16_t)(m & 0xffffu), iv = 32 * row + ((int)m >> 16);
-            int sx = iu >> 5, sy = iv >> 5;
-            int sxc = sx < 0 ? 0 : (sx > W - 2 ? W - 2 : sx), syc = sy < 0 ? 0 : (sy > H - 2 ? H - 2 : sy);
-            uint32_t wx0, wx1, wy0, wy1;
-            edge_weights(sx, sxc, iu & 31, wx0, wx1);
-            edge_weights(sy, syc, iv & 31, wy0, wy1);
-            ts.w[k] = (wx0 | (wx1 << 8) | (wy1 << 16) | (wy0 << 24)) & wmask;
-        }
+        int sx = xq[k] + (int)(int16_t)(m & 0xffffu), sy = row + ((int)m >> 16); // inside the image by construction
+        uint32_t off0 = __umul24((uint32_t)sy, (uint32_t)pitch) + (uint32_t)sx, off1 = off0 + (uint32_t)pitch;
+        ts.t0[k] = load_u16(img + off0);
+        ts.t1[k] = load_u16(img + off1);
     }
 }
 
@@ -231,7 +179,7 @@ __device__ __forceinline__ int taps5(int v, int n)
 }
 
 template <int J> struct IC { static constexpr int value = J; };
-constexpr int STAGE_ROWS = 136; // >= rows_per_chunk
+
 
 template <bool REMAP, bool TINY, bool PIPE>
 __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
@@ -239,9 +187,6 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
     __shared__ uint32_t lut[256];
     __shared__ uint2 hring[4][8][64];
     __shared__ uint32_t cring[4][8][64];
-    // output staging: the chunk's mask bytes wait here and are written out after the last load, so that no store
-    // is in flight while loads are (the compiler drains the whole load queue at every use otherwise)
-    __shared__ __attribute__((aligned(4))) uint8_t ostage[4][PIPE ? STAGE_ROWS : 1][32];
 
     // lut[w]: byte k = number of set bits among bits k..k+4 of the 8-bit window w
     {
@@ -278,6 +223,7 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
 
     const uint8_t* __restrict__ img = a.src + (size_t)image * a.image_stride;
     const uint32_t* __restrict__ map = REMAP ? a.map + (size_t)slot * a.H * a.W : nullptr;
+    const uint32_t* __restrict__ mapw = REMAP ? a.mapw + (size_t)slot * a.H * a.W : nullptr;
     uint8_t* __restrict__ mrow_base = (uint8_t*)(a.mask + (size_t)image * a.H * a.words_per_row);
     const int row_bytes = a.words_per_row * 4;
 
@@ -327,13 +273,13 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
         remap_issue_map(mq[0], map, y0 + 1, a.H, a.W, lc);
         remap_issue_map(mq[1], map, y0 + 2, a.H, a.W, lc);
         remap_issue_map(mq[2], map, y0 + 3, a.H, a.W, lc);
-        remap_issue_taps(tq[3], mq[3], img, a.pitch, a.H, a.W, y0, xq);
+        remap_issue_taps(tq[3], mq[3], img, mapw, a.pitch, a.H, a.W, y0, xq, lc);
         remap_issue_map(mq[3], map, y0 + 4, a.H, a.W, lc);
-        remap_issue_taps(tq[0], mq[0], img, a.pitch, a.H, a.W, y0 + 1, xq);
+        remap_issue_taps(tq[0], mq[0], img, mapw, a.pitch, a.H, a.W, y0 + 1, xq, lc);
         remap_issue_map(mq[0], map, y0 + 5, a.H, a.W, lc);
-        remap_issue_taps(tq[1], mq[1], img, a.pitch, a.H, a.W, y0 + 2, xq);
+        remap_issue_taps(tq[1], mq[1], img, mapw, a.pitch, a.H, a.W, y0 + 2, xq, lc);
         remap_issue_map(mq[1], map, y0 + 6, a.H, a.W, lc);
-        remap_issue_taps(tq[2], mq[2], img, a.pitch, a.H, a.W, y0 + 3, xq);
+        remap_issue_taps(tq[2], mq[2], img, mapw, a.pitch, a.H, a.W, y0 + 3, xq, lc);
         remap_issue_map(mq[2], map, y0 + 7, a.H, a.W, lc);
     } else {
 #pragma unroll
@@ -348,7 +294,8 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
         if (PIPE) {
             constexpr int S = J & 3;
             uint32_t B = remap_combine(tq[S], lc);
-            remap_issue_taps(tq[S], mq[S], img, a.pitch, a.H, a.W, row + 4, xq);
+            if ((unsigned)row >= (unsigned)a.H) B = 0u; // wave-uniform select: rows outside the image are zero
+            remap_issue_taps(tq[S], mq[S], img, mapw, a.pitch, a.H, a.W, row + 4, xq, lc);
             remap_issue_map(mq[S], map, row + 8, a.H, a.W, lc);
             return B;
         } else {
@@ -410,12 +357,9 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
         lacc |= (mn != 0u ? 1u : 0u) << (((on ? row : r0) - r0) >> 3); // rows not yet valid have mn from a partial window: harmless superset
         uint32_t odd = lane_from_next(mn);
         uint32_t byte = (mn & 0xfu) | ((odd & 0xfu) << 4);
-        if (PIPE) {
-            if (stores && on) ostage[wv][row - r0][(lane - 2) >> 1] = (uint8_t)byte;
-        } else {
-            // plain path: direct byte store (the compiler keeps counted vmcnt waits around this exec-masked store)
-            if (stores && on) mrow_base[(size_t)row * row_bytes + out_byte] = (uint8_t)byte;
-        }
+        // direct byte store: all loads here are global-address-space loads, so the compiler keeps counted vmcnt
+        // waits around this exec-masked store and the load pipeline stays full
+        if (stores && on) mrow_base[(size_t)row * row_bytes + out_byte] = (uint8_t)byte;
     };
 
     // ---- set-up: source rows kfirst-2 .. kfirst+2 (ring slots 3..7), first threshold row, replicated top rows ----
@@ -481,21 +425,6 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
             if (__ballot(out_lane && ((lacc >> g) & 1u)) != 0ull) cellmask |= 1u << g;
         if (lane == 0) a.cells[((size_t)image * a.n_cgroups * 4 + (cgroup * 4 + wv)) * a.n_strips + strip] = cellmask;
     }
-    // ---- write the staged rows out: 15 two-byte stores per row, two rows per wave instruction ----
-    if (PIPE) {
-        const int n_rows = r1 - r0;
-        const int half = lane >> 5, pair = lane & 31;
-        const int byte0 = strip * 30 + 2 * pair;
-        const bool lane_ok = pair < 15 && byte0 < ((a.W + 7) >> 3);
-        for (int i = half; i < n_rows; i += 2) {
-            uint16_t v = *(const uint16_t*)&ostage[wv][i][2 * pair];
-            if (lane_ok) {
-                uint8_t* dst = mrow_base + (size_t)(r0 + i) * row_bytes + byte0;
-                if (byte0 + 1 < ((a.W + 7) >> 3)) *(uint16_t*)dst = v; // byte0 is even: aligned; padding bytes are never written
-                else *dst = (uint8_t)v;
-            }
-        }
-    }
 }
 
 // ---- map construction: cv::initUndistortRectifyMap as called by cv::undistort (stripe by stripe) -------------
@@ -530,6 +459,7 @@ __global__ void undistort_map_kernel(MapArgs m)
     double k1 = m.dist[0], k2 = m.dist[1], p1 = m.dist[2], p2 = m.dist[3], k3 = m.dist[4];
     double _x = i * ir[1] + ir[2], _y = i * ir[4] + ir[5], _w = i * ir[7] + ir[8];
     uint32_t* out = m.map + (size_t)row * m.W;
+    uint32_t* outw = m.mapw + (size_t)row * m.W;
     uint32_t flags = 0;
     for (int j = 0; j < m.W; j++, _x += ir[0], _y += ir[3], _w += ir[6]) {
         double w = 1. / _w, x = _x * w, y = _y * w;
@@ -541,15 +471,26 @@ __global__ void undistort_map_kernel(MapArgs m)
         double u = fx * xd + u0;
         double v = fy * yd + v0;
         double ru = __builtin_rint(u * 32), rv = __builtin_rint(v * 32); // round half to even (cvRound)
-        double ddx = ru - 32.0 * j, ddy = rv - 32.0 * row;
-        if (!(ddx >= -32768.0 && ddx <= 32767.0 && ddy >= -32768.0 && ddy <= 32767.0)) {
-            flags |= 2u; // displacement beyond +-1024 px: not representable in the packed map
-            ddx = ddx < 0 ? -32768.0 : 32767.0;
-            ddy = ddy < 0 ? -32768.0 : 32767.0;
-        }
-        int dx = (int)ddx, dy = (int)ddy;
-        if (dx | dy) flags |= 1u;
+        // saturate_cast<int>, then the (short) casts of the integer parts that cv::remap's fixed-point map applies
+        ru = ru > 2147483647.0 ? 2147483647.0 : (ru < -2147483648.0 ? -2147483648.0 : ru);
+        rv = rv > 2147483647.0 ? 2147483647.0 : (rv < -2147483648.0 ? -2147483648.0 : rv);
+        int iu = (int)ru, iv = (int)rv;
+        int sx = (int)(int16_t)(iu >> 5), sy = (int)(int16_t)(iv >> 5);
+        uint32_t a = iu & 31, b = iv & 31;
+        // 2x2 tap window clamped into the image; taps that fall outside read 0 (BORDER_CONSTANT): weight 0
+        int sxc = sx < 0 ? 0 : (sx > m.W - 2 ? m.W - 2 : sx), syc = sy < 0 ? 0 : (sy > m.H - 2 ? m.H - 2 : sy);
+        if (sxc < 0) sxc = 0;
+        if (syc < 0) syc = 0;
+        int ddx = sx - sxc, ddy = sy - syc;
+        uint32_t wx0 = ddx == 0 ? 32u - a : (ddx == -1 ? a : 0u), wx1 = ddx == 0 ? a : (ddx == 1 ? 32u - a : 0u);
+        uint32_t wy0 = ddy == 0 ? 32u - b : (ddy == -1 ? b : 0u), wy1 = ddy == 0 ? b : (ddy == 1 ? 32u - b : 0u);
+        if (sxc + 1 > m.W - 1) wx1 = 0; // one-column / one-row images: the second tap does not exist
+        if (syc + 1 > m.H - 1) wy1 = 0;
+        int dx = sxc - j, dy = syc - row; // |.| < 32768 because both ends are inside the image
+        uint32_t wq = wx0 | (wx1 << 8) | (wy1 << 16) | (wy0 << 24);
+        if (iu != 32 * j || iv != 32 * row) flags |= 1u; // anything but the identity map
         out[j] = ((uint32_t)dx & 0xffffu) | ((uint32_t)dy << 16);
+        outw[j] = wq;
     }
     if (flags) atomicOr(m.flags, flags);
 }
@@ -573,11 +514,12 @@ __global__ void box_blur_kernel(const uint8_t* __restrict__ src, uint8_t* __rest
 
 // cv.undistort of one image through the packed map
 __global__ void undistort_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int H, int W,
-                                 int spitch, int dpitch, const uint32_t* __restrict__ map)
+                                 int spitch, int dpitch, const uint32_t* __restrict__ map,
+                                 const uint32_t* __restrict__ mapw)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= W || y >= H) return;
-    dst[(size_t)y * dpitch + x] = (uint8_t)remap_px(src, spitch, H, W, map[(size_t)y * W + x], x, y);
+    dst[(size_t)y * dpitch + x] = (uint8_t)remap_px(src, spitch, map[(size_t)y * W + x], mapw[(size_t)y * W + x], x, y);
 }
 
 // bit mask -> {0,255} image
@@ -661,9 +603,10 @@ void launch_box_blur(const uint8_t* src, uint8_t* dst, int H, int W, int sp, int
 {
     hipLaunchKernelGGL(box_blur_kernel, grid2d(W, H), dim3(64, 4), 0, s, src, dst, H, W, sp, dp, ksize);
 }
-void launch_undistort(const uint8_t* src, uint8_t* dst, int H, int W, int sp, int dp, const uint32_t* map, hipStream_t s)
+void launch_undistort(const uint8_t* src, uint8_t* dst, int H, int W, int sp, int dp, const uint32_t* map, const uint32_t* mapw,
+                      hipStream_t s)
 {
-    hipLaunchKernelGGL(undistort_kernel, grid2d(W, H), dim3(64, 4), 0, s, src, dst, H, W, sp, dp, map);
+    hipLaunchKernelGGL(undistort_kernel, grid2d(W, H), dim3(64, 4), 0, s, src, dst, H, W, sp, dp, map, mapw);
 }
 void launch_mask_expand(const uint32_t* mask, int wpr, uint8_t* dst, int H, int W, int dp, hipStream_t s)
 {

@@ -13,7 +13,9 @@ struct FilterArgs {
     uint32_t* mask;       // [n_images][H][words_per_row], bit b of word k = pixel 32k+b
     int words_per_row;
     uint32_t* cells;      // [n_images][n_cgroups*4][n_strips]: bit g = rows 8g..8g+7 of the chunk have set pixels in the strip
-    const uint32_t* map;  // [cam_mod][H][W] packed (dx | dy<<16) in 1/32 px (remap variant only)
+    // undistort tables of the first slot used (remap variant only), each [cam_mod][H][W]:
+    const uint32_t* map;  //   tap position: (sx - x) | (sy - y) << 16, the 2x2 tap window clamped into the image
+    const uint32_t* mapw; //   blend weights 32*(wx0 | wx1<<8 | wy1<<16 | wy0<<24)/32, taps outside the image weigh 0
     int cam_mod;          // undistort slot of image n = n % cam_mod (map already points at the first slot)
     int n_images, n_steps; // n_steps = ceil(n_images / cam_mod)
     int thr_mul;          // floor(thresh)+1: blurred > thresh  <=>  S >= thr_mul * taps
@@ -23,8 +25,9 @@ struct FilterArgs {
 struct MapArgs {
     double K[9], dist[5];
     int H, W;
-    uint32_t* map;   // [H][W]
-    uint32_t* flags; // bit0: map is not the identity, bit1: displacement not representable
+    uint32_t* map;   // [H][W] tap positions (see FilterArgs)
+    uint32_t* mapw;  // [H][W] blend weights
+    uint32_t* flags; // bit0: the table is not the identity
 };
 
 // one border found by the contour kernel (also the debug record compared with the oracle in tests)
@@ -56,6 +59,7 @@ struct ContourArgs {
     int max_steps;
     const uint32_t* cells; // occupancy written by the filter kernel (see FilterArgs), or null = scan every row
     int rows_per_chunk, n_chunks, n_strips;
+    int debug_stop;
 };
 
 enum { BLOB_ERR_CANDIDATES = -2, BLOB_ERR_CONTOURS = -3, BLOB_ERR_STEPS = -4, BLOB_ERR_DEPTH = -5 };
@@ -64,7 +68,8 @@ void launch_filter_mask(const FilterArgs& a, bool remap, hipStream_t s);
 void launch_undistort_map(const MapArgs& m, hipStream_t s);
 void launch_contours(const ContourArgs& a, hipStream_t s);
 void launch_box_blur(const uint8_t* src, uint8_t* dst, int H, int W, int sp, int dp, int ksize, hipStream_t s);
-void launch_undistort(const uint8_t* src, uint8_t* dst, int H, int W, int sp, int dp, const uint32_t* map, hipStream_t s);
+void launch_undistort(const uint8_t* src, uint8_t* dst, int H, int W, int sp, int dp, const uint32_t* map, const uint32_t* mapw,
+                      hipStream_t s);
 void launch_mask_expand(const uint32_t* mask, int wpr, uint8_t* dst, int H, int W, int dp, hipStream_t s);
 void launch_median5(const uint8_t* src, uint8_t* dst, int H, int W, int sp, int dp, int ithresh, int apply, hipStream_t s);
 void launch_demosaic(const uint8_t* bayer, uint8_t* bgr, int H, int W, int sp, hipStream_t s);
