@@ -44,6 +44,8 @@ struct mocap_ctx {
     uint32_t* maps;           // [2][n_slots][H][W]: tap positions, then blend weights
     uint32_t* map_flags;      // [n_slots] device, followed by 256 trash bytes
     std::vector<int> slot_state; // 0 unset, 1 identity, 2 remap
+    std::vector<int> slot_mode;  // remap kernel variant the slot's table admits: 2 per-pixel, 3 pipelined gather, 4 LDS-staged
+    uint2* spans;             // [n_slots][n_strips][H] source row / column spans per strip row
     uint32_t* mask; size_t mask_images;
     uint32_t* cells; size_t cells_images; // occupancy cells written by the filter kernel for c->mask
     CameraTable* cams; int n_cam, n_F;
@@ -54,6 +56,59 @@ struct mocap_ctx {
 };
 
 static int set_device(mocap_ctx* c) { HIP_TRY(hipSetDevice(c->device)); return 0; }
+
+struct Tiling { int rows, n_cgroups, n_strips; };
+static Tiling tiling(const mocap_ctx* c)
+{
+    Tiling t;
+    t.rows = 135; // <= 136 so that a chunk's 8-row groups fit one 32-bit occupancy word
+    if (c->H < 4 * 32) t.rows = (c->H + 3) / 4 > 8 ? (c->H + 3) / 4 : 8;
+    t.n_cgroups = (c->H + 4 * t.rows - 1) / (4 * t.rows);
+    t.n_strips = (c->W + 239) / 240;
+    return t;
+}
+
+// Can the LDS-staged remap kernel serve this slot?  Replays, per (strip, chunk), the kernel's ring schedule on the
+// span table: ring width, rows resident when they are read, at most two new rows per step.
+static bool lds_remap_ok(const mocap_ctx* c, const std::vector<uint2>& sp)
+{
+    if (c->W < 8 || (c->W & 3) || c->H < 2) return false;
+    Tiling t = tiling(c);
+    const int H = c->H, Hm1 = H - 1;
+    auto clampr = [&](int r) { return r < 0 ? 0 : (r > Hm1 ? Hm1 : r); };
+    for (int st = 0; st < t.n_strips; st++) {
+        const uint2* s = sp.data() + (size_t)st * H;
+        auto smin = [&](int r) { return (int)(s[clampr(r)].x & 0xffffu); };
+        auto smax = [&](int r) { return (int)(s[clampr(r)].x >> 16); };
+        for (int ch = 0; ch * t.rows < H; ch++) {
+            int r0 = ch * t.rows, r1 = r0 + t.rows < H ? r0 + t.rows : H;
+            int kfirst = clampr(r0 - 2), ke = r1 + 1 < Hm1 ? r1 + 1 : Hm1;
+            int y0 = kfirst - 2, last = (ke > kfirst ? ke : kfirst) + 2;
+            int xmin = 0x7fff, xmax = 0;
+            for (int r = clampr(y0); r <= clampr(last); r++) {
+                int lo = (int)(s[r].y & 0xffffu), hi = (int)(s[r].y >> 16);
+                xmin = lo < xmin ? lo : xmin; xmax = hi > xmax ? hi : xmax;
+            }
+            if (xmax - (xmin & ~7) + 1 > RING_W) return false;
+            int hi_w = smax(y0);
+            for (int r = y0; r <= y0 + RING_LOOKAHEAD - 1; r++) hi_w = smax(r) > hi_w ? smax(r) : hi_w; // prologue fill
+            if (hi_w - smin(y0) + 1 > RING_H) return false;
+            int loaded = hi_w;
+            for (int r = y0; r <= last + 1; r++) { // r = row whose taps are read; requests run RING_LOOKAHEAD rows ahead
+                int need = smax(r + RING_LOOKAHEAD);
+                if (need - loaded > 2) return false;
+                loaded = need > loaded ? need : loaded;
+                // rows written by the time row r+1 is read: everything requested up to step r-4, i.e. need of rows <= r+1
+                int written = hi_w;
+                for (int q = y0; q <= r + 1; q++) written = smax(q) > written ? smax(q) : written;
+                if (smax(r + 1) > written || smin(r + 1) < written - (RING_H - 1)) return false;
+                // and nothing still needed may be overwritten by what is already requested (<= loaded)
+                if (smin(r + 1) < loaded - (RING_H - 1)) return false;
+            }
+        }
+    }
+    return true;
+}
 
 extern "C" {
 
@@ -71,9 +126,10 @@ int mocap_ctx_create(int device_id, int width, int height, int n_slots, mocap_ct
     mocap_ctx* c = new mocap_ctx();
     c->device = device_id; c->W = width; c->H = height; c->n_slots = n_slots; c->wpr = (width + 31) / 32;
     c->prm = mocap_blob_params{5, 5, 255 * 0.85, 500.0, 0.5};
-    c->maps = nullptr; c->map_flags = nullptr; c->mask = nullptr; c->mask_images = 0; c->cells = nullptr; c->cells_images = 0;
+    c->maps = nullptr; c->spans = nullptr; c->map_flags = nullptr; c->mask = nullptr; c->mask_images = 0; c->cells = nullptr; c->cells_images = 0;
     c->cams = nullptr; c->n_cam = 0; c->n_F = 0; c->scratch = nullptr; c->scratch_elems = 0; c->profiling = false;
     c->slot_state.assign(n_slots, 0);
+    c->slot_mode.assign(n_slots, 2);
     hipError_t e = hipMalloc(&c->map_flags, sizeof(uint32_t) * n_slots + 256);
     if (e == hipSuccess) e = hipMemset(c->map_flags, 0, sizeof(uint32_t) * n_slots);
     if (e == hipSuccess) e = hipMalloc(&c->cams, sizeof(CameraTable));
@@ -92,6 +148,7 @@ int mocap_ctx_destroy(mocap_ctx_t c)
     (void)hipSetDevice(c->device);
     for (auto& v : c->ev) for (auto& p : v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (c->maps) (void)hipFree(c->maps);
+    if (c->spans) (void)hipFree(c->spans);
     if (c->map_flags) (void)hipFree(c->map_flags);
     if (c->mask) (void)hipFree(c->mask);
     if (c->cells) (void)hipFree(c->cells);
@@ -140,6 +197,19 @@ int mocap_set_undistort(mocap_ctx_t c, int slot, const double K[9], const double
     uint32_t flags = 0;
     HIP_TRY(hipMemcpy(&flags, m.flags, sizeof(flags), hipMemcpyDeviceToHost));
     c->slot_state[slot] = (flags & 1u) ? 2 : 1;
+    c->slot_mode[slot] = 2;
+    if (c->slot_state[slot] == 2) {
+        Tiling tl = tiling(c);
+        size_t nsp = (size_t)tl.n_strips * c->H;
+        if (!c->spans) HIP_TRY(hipMalloc(&c->spans, sizeof(uint2) * nsp * c->n_slots));
+        SpanArgs sa{m.map, c->spans + nsp * slot, c->H, c->W, tl.n_strips};
+        launch_remap_spans(sa, 0);
+        HIP_TRY(hipGetLastError());
+        std::vector<uint2> sp(nsp);
+        HIP_TRY(hipMemcpy(sp.data(), sa.spans, sizeof(uint2) * nsp, hipMemcpyDeviceToHost));
+        if (lds_remap_ok(c, sp)) c->slot_mode[slot] = 4;
+        else if (c->W >= 4 && (c->W & 3) == 0 && c->H >= 2) c->slot_mode[slot] = 3;
+    }
     if (identity_out) *identity_out = c->slot_state[slot] == 1;
     return MOCAP_OK;
 }
@@ -228,16 +298,6 @@ static int check_frames(mocap_ctx* c, const void* frames, int n_images, int cam_
     return 0;
 }
 
-struct Tiling { int rows, n_cgroups, n_strips; };
-static Tiling tiling(const mocap_ctx* c)
-{
-    Tiling t;
-    t.rows = 135; // <= 136 so that a chunk's 8-row groups fit one 32-bit occupancy word
-    if (c->H < 4 * 32) t.rows = (c->H + 3) / 4 > 8 ? (c->H + 3) / 4 : 8;
-    t.n_cgroups = (c->H + 4 * t.rows - 1) / (4 * t.rows);
-    t.n_strips = (c->W + 239) / 240;
-    return t;
-}
 static size_t cells_per_image(const mocap_ctx* c) { Tiling t = tiling(c); return (size_t)t.n_cgroups * 4 * t.n_strips; }
 
 static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mod, int slot_base, size_t image_stride,
@@ -257,7 +317,18 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
     Tiling tl = tiling(c);
     a.n_strips = tl.n_strips; a.rows_per_chunk = tl.rows; a.n_cgroups = tl.n_cgroups;
     bool remap = false;
-    for (int sl = slot_base; sl < slot_base + cam_mod; sl++) remap |= c->slot_state[sl] == 2;
+    int mode = 4;
+    for (int sl = slot_base; sl < slot_base + cam_mod; sl++) {
+        remap |= c->slot_state[sl] == 2;
+        // an identity slot inside a remapped batch has no span table: it takes the gather path with its identity table
+        int m = c->slot_state[sl] == 2 ? c->slot_mode[sl] : ((c->W >= 4 && (c->W & 3) == 0 && c->H >= 2) ? 3 : 2);
+        mode = m < mode ? m : mode;
+    }
+    // Default: the pipelined gather kernel (3).  The LDS-staged kernel (4) is bit-identical but measured slower on
+    // MI355X so far, so it is opt-in: MOCAP_REMAP_MODE=4; 2 or 3 force a simpler variant (tests).
+    { const char* e = getenv("MOCAP_REMAP_MODE"); int cap = e ? atoi(e) : 3; if (cap < 2) cap = 3; if (cap < mode) mode = cap; }
+    a.remap_mode = mode;
+    a.spans = c->spans ? c->spans + (size_t)slot_base * tiling(c).n_strips * c->H : nullptr;
     EvPair p; bool on;
     prof_begin(c, 0, s, p, on);
     launch_filter_mask(a, remap, s);
@@ -279,7 +350,6 @@ static int run_contours(mocap_ctx* c, const uint32_t* mask, const uint32_t* cell
     a.max_steps = ms > (1 << 22) ? (1 << 22) : (int)ms;
     Tiling tl = tiling(c);
     a.cells = cells; a.rows_per_chunk = tl.rows; a.n_chunks = tl.n_cgroups * 4; a.n_strips = tl.n_strips;
-    { const char* e = getenv("MOCAP_DEBUG_STOP"); a.debug_stop = e ? atoi(e) : 0; }
     EvPair p; bool on;
     prof_begin(c, 1, s, p, on);
     launch_contours(a, s);
@@ -387,6 +457,8 @@ int mocap_image_filter_u8(mocap_ctx_t c, const void* src, void* dst, int spitch,
     a.cells = c->cells;
     a.map = slot >= 0 ? c->maps + (size_t)slot * c->H * c->W : nullptr;
     a.mapw = slot >= 0 ? c->maps + (size_t)(c->n_slots + slot) * c->H * c->W : nullptr;
+    a.remap_mode = slot >= 0 ? c->slot_mode[slot] : 0;
+    a.spans = (slot >= 0 && c->spans) ? c->spans + (size_t)slot * tiling(c).n_strips * c->H : nullptr;
     a.thr_mul = ithresh + 1;
     Tiling tl = tiling(c);
     a.n_strips = tl.n_strips; a.rows_per_chunk = tl.rows; a.n_cgroups = tl.n_cgroups;

@@ -222,7 +222,6 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
     int32_t* const out_count = a.out_count + (size_t)image * a.count_stride;
     if (tid == 0) { ncand = 0; nrec = 0; nkept = 0; err = 0; ncell = 0; }
     __syncthreads();
-    if (a.debug_stop == 9) return;
 
     // ---- phase A: candidate starts -------------------------------------------------------------------------------
     // A border can only start where the mask has set pixels.  The filter kernel leaves an occupancy word per
@@ -319,7 +318,6 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
         return;
     }
 
-    if (a.debug_stop == 1) return;
     // ---- phase B: one wave follows one candidate; the raster-first ones become records ---------------------------
     const int nc = ncand;
     for (int c = wv; c < nc; c += NWAVES) {
@@ -353,7 +351,6 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
         return;
     }
 
-    if (a.debug_stop == 2) return;
     // ---- phase C1: link = the border that owns the crack met when scanning left from the start ------------------
     //   outer border: nearest foreground pixel left of the start on the same row -> its East crack
     //   hole border : left end of the foreground run holding the start pixel     -> its West crack
@@ -402,7 +399,6 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
         return;
     }
 
-    if (a.debug_stop == 3) return;
     // ---- phase C2: parents (Suzuki's table: same kind -> the link's parent, else the link itself) -----------
     for (int c = tid; c < nrec; c += NTHREADS) {
         int me = recs[c].is_hole, j = recs[c].link, guard = 0;
@@ -449,6 +445,7 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
     }
     if (tid == 0) *out_count = nkept;
     if (a.dbg) {
+        __syncthreads(); // the records' order fields are written by other threads just above
         for (int c = tid; c < nrec && c < a.dbg_cap; c += NTHREADS) a.dbg[(size_t)image * a.dbg_cap + c] = recs[c];
         if (tid == 0) a.dbg_count[image] = nrec;
     }

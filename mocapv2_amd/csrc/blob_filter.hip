@@ -171,6 +171,88 @@ __device__ __forceinline__ uint32_t remap_combine(const TapSlot& ts, const LaneC
     return out & lc.bytemask; // columns outside the image do not exist
 }
 
+// ---- LDS-staged remap -------------------------------------------------------------------------------------------
+// The per-pixel 2x2 taps of the gather variants cost one vector-memory instruction per tap row and pixel, and the
+// vector memory pipeline, not HBM, bounds them.  Here each wave keeps a ring of the most recent source rows of its
+// strip in LDS (RING_H rows x RING_W bytes, filled with coalesced 8-byte loads, one or two rows per step -- the same
+// HBM traffic as the plain path) and takes the taps from LDS.  Per step:
+//   1. rows requested 4 steps ago -> LDS        2. taps of the NEXT row: LDS -> registers
+//   3. table loads 5 rows ahead                 4. request the source rows needed 5 rows ahead
+//   5. blend THIS row from the registers filled one step ago
+struct TabSlot { uint4 m, w; };                       // tap positions and weights of one row (4 pixels)
+struct RowReq { uint2 va, vb; int qa, qb; };           // two source rows in flight (qa, qb wave-uniform)
+struct LTaps { uint32_t a0[4], b0[4], a1[4], b1[4], ph[4], w[4]; }; // dword pairs of both tap rows, byte phase, weights
+
+struct LdsRemap {
+    uint8_t* ring;     // this wave's ring (LDS)
+    int xs0;           // first source column held (multiple of 8)
+    int loaded_hi;     // highest source row requested so far
+    int nl;            // lanes that carry ring columns: ceil(width / 8)
+    uint32_t col;      // per lane: byte offset of its 8-byte column group in the image row (clamped to W-8)
+    uint32_t colsh;    // per lane: bits to shift the loaded 64-bit value right after the clamp
+};
+
+__device__ __forceinline__ void ldsr_request(RowReq& rq, LdsRemap& st, int need, const uint8_t* __restrict__ img, int pitch)
+{ // branch-free: always two loads; when nothing new is needed they re-fetch the newest row (identical bytes)
+    int qa = st.loaded_hi + 1 < need ? st.loaded_hi + 1 : need, qb = st.loaded_hi + 2 < need ? st.loaded_hi + 2 : need;
+    st.loaded_hi = st.loaded_hi > qb ? st.loaded_hi : qb;
+    rq.qa = qa; rq.qb = qb;
+    __builtin_memcpy(&rq.va, img + ((uint32_t)qa * (uint32_t)pitch + st.col), 8);
+    __builtin_memcpy(&rq.vb, img + ((uint32_t)qb * (uint32_t)pitch + st.col), 8);
+}
+
+__device__ __forceinline__ void ldsr_write(const RowReq& rq, const LdsRemap& st, int lane)
+{
+    uint64_t a = (((uint64_t)rq.va.y << 32) | rq.va.x) >> st.colsh, b = (((uint64_t)rq.vb.y << 32) | rq.vb.x) >> st.colsh;
+    if (lane < st.nl) {
+        *(uint2*)(st.ring + (rq.qa & (RING_H - 1)) * RING_W + 8 * lane) = make_uint2((uint32_t)a, (uint32_t)(a >> 32));
+        *(uint2*)(st.ring + (rq.qb & (RING_H - 1)) * RING_W + 8 * lane) = make_uint2((uint32_t)b, (uint32_t)(b >> 32));
+    }
+}
+
+__device__ __forceinline__ void ldsr_issue_tables(TabSlot& ts, const uint32_t* __restrict__ map, const uint32_t* __restrict__ mapw,
+                                                  int row, int H, int W, const LaneCols& lc)
+{
+    int rc = row < 0 ? 0 : (row > H - 1 ? H - 1 : row);
+    uint32_t off = (uint32_t)rc * (uint32_t)W + (uint32_t)lc.addr_x;
+    __builtin_memcpy(&ts.m, map + off, 16);
+    __builtin_memcpy(&ts.w, mapw + off, 16);
+}
+
+__device__ __forceinline__ void ldsr_read_taps(LTaps& t, const TabSlot& ts, const LdsRemap& st, int row, int H, const int xq[4])
+{
+    row = row < 0 ? 0 : (row > H - 1 ? H - 1 : row);
+    const uint32_t mm[4] = {ts.m.x, ts.m.y, ts.m.z, ts.m.w};
+    t.w[0] = ts.w.x; t.w[1] = ts.w.y; t.w[2] = ts.w.z; t.w[3] = ts.w.w;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t m = mm[k];
+        int sx = xq[k] + (int)(int16_t)(m & 0xffffu), sy = row + ((int)m >> 16);
+        uint32_t cx = (uint32_t)(sx - st.xs0);
+        uint32_t A0 = (uint32_t)(sy & (RING_H - 1)) * RING_W + cx, A1 = (uint32_t)((sy + 1) & (RING_H - 1)) * RING_W + cx;
+        const uint32_t* p0 = (const uint32_t*)(st.ring + (A0 & ~3u));
+        const uint32_t* p1 = (const uint32_t*)(st.ring + (A1 & ~3u));
+        t.a0[k] = p0[0]; t.b0[k] = p0[1];
+        t.a1[k] = p1[0]; t.b1[k] = p1[1];
+        t.ph[k] = A0 & 3u; // RING_W is a multiple of 4: both rows share the byte phase
+    }
+}
+
+__device__ __forceinline__ uint32_t ldsr_combine(const LTaps& t, const LaneCols& lc)
+{
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t w = t.w[k], wx = w & 0xffffu;
+        uint32_t t0 = __builtin_amdgcn_alignbyte(t.b0[k], t.a0[k], t.ph[k]), t1 = __builtin_amdgcn_alignbyte(t.b1[k], t.a1[k], t.ph[k]);
+        uint32_t top = dot4(t0, wx, 0u), bot = dot4(t1, wx, 0u);
+        uint32_t r = __umul24(top, w >> 24) + 512u;
+        r += __umul24(bot, (w >> 16) & 0xffu);
+        out |= (r >> 10) << (8 * k);
+    }
+    return out & lc.bytemask;
+}
+
 // number of in-image taps of a 5-wide window centred on v
 __device__ __forceinline__ int taps5(int v, int n)
 {
@@ -181,12 +263,13 @@ __device__ __forceinline__ int taps5(int v, int n)
 template <int J> struct IC { static constexpr int value = J; };
 
 
-template <bool REMAP, bool TINY, bool PIPE>
+template <bool REMAP, bool TINY, bool PIPE, bool LDSR>
 __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
 {
     __shared__ uint32_t lut[256];
     __shared__ uint2 hring[4][8][64];
     __shared__ uint32_t cring[4][8][64];
+    __shared__ __attribute__((aligned(16))) uint8_t sring[LDSR ? 4 : 1][LDSR ? RING_H * RING_W : 16];
 
     // lut[w]: byte k = number of set bits among bits k..k+4 of the 8-bit window w
     {
@@ -265,9 +348,62 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
     TapSlot tq[4];
     int xq[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) { int x = xl + k; xq[k] = x < 0 ? 0 : (x > a.W - 1 ? a.W - 1 : x); }
+    // columns the lane's four table words belong to (lanes outside the image read the nearest in-image group:
+    // their taps stay inside the image, their result is masked out)
+    for (int k = 0; k < 4; k++) xq[k] = lc.addr_x + k;
     const int y0 = kfirst - 2;
-    if (PIPE) {
+    TabSlot tabs[4];
+    RowReq rq[4];
+    LTaps tb[2];
+    LdsRemap st;
+    if (LDSR) {
+        const uint2* spans = a.spans + ((size_t)slot * a.n_strips + strip) * a.H;
+        auto span_row = [&](int r) { return r < 0 ? 0 : (r > Hm1 ? Hm1 : r); };
+        // source columns this strip needs over the rows the chunk consumes: y0 .. ke+2 (clamped into the image)
+        int xmin = 0x7fff, xmax = 0;
+        const int ra = span_row(y0), rb = span_row((ke > kfirst ? ke : kfirst) + 2);
+        for (int r = ra + lane; r <= rb; r += 64) {
+            uint32_t xs = spans[r].y;
+            int lo = (int)(xs & 0xffffu), hi = (int)(xs >> 16);
+            xmin = lo < xmin ? lo : xmin; xmax = hi > xmax ? hi : xmax;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            int o1 = __shfl_xor(xmin, d), o2 = __shfl_xor(xmax, d);
+            xmin = o1 < xmin ? o1 : xmin; xmax = o2 > xmax ? o2 : xmax;
+        }
+        st.ring = &sring[wv][0];
+        st.xs0 = __builtin_amdgcn_readfirstlane(xmin) & ~7;
+        st.nl = (__builtin_amdgcn_readfirstlane(xmax) - st.xs0 + 8) >> 3;
+        {
+            int c = st.xs0 + 8 * lane, cc = c < a.W - 8 ? c : a.W - 8;
+            st.col = (uint32_t)cc;
+            int sh = 8 * (c - cc);
+            st.colsh = (uint32_t)(sh > 63 ? 63 : sh);
+        }
+        // first tables, then the ring rows the first five rows of the pipeline need, synchronously
+        ldsr_issue_tables(tabs[3], map, mapw, y0, a.H, a.W, lc);
+        const int first = (int)(spans[span_row(y0)].x & 0xffffu);
+        const int upto = (int)(spans[span_row(y0 + RING_LOOKAHEAD - 1)].x >> 16);
+        for (int qrow = first; qrow <= upto; ++qrow) {
+            uint2 v;
+            __builtin_memcpy(&v, img + ((uint32_t)qrow * (uint32_t)a.pitch + st.col), 8);
+            uint64_t vv = (((uint64_t)v.y << 32) | v.x) >> st.colsh;
+            if (lane < st.nl) *(uint2*)(st.ring + (qrow & (RING_H - 1)) * RING_W + 8 * lane) = make_uint2((uint32_t)vv, (uint32_t)(vv >> 32));
+        }
+        st.loaded_hi = upto;
+        // the four request slots start as harmless re-fetches of the newest row
+        ldsr_request(rq[3], st, upto, img, a.pitch);
+        ldsr_request(rq[0], st, upto, img, a.pitch);
+        ldsr_request(rq[1], st, upto, img, a.pitch);
+        ldsr_request(rq[2], st, upto, img, a.pitch);
+        // taps of the first row; tables of the next four (row rho lives in slot (rho - y0 + 3) & 3)
+        ldsr_read_taps(tb[1], tabs[3], st, y0, a.H, xq);
+        ldsr_issue_tables(tabs[0], map, mapw, y0 + 1, a.H, a.W, lc);
+        ldsr_issue_tables(tabs[1], map, mapw, y0 + 2, a.H, a.W, lc);
+        ldsr_issue_tables(tabs[2], map, mapw, y0 + 3, a.H, a.W, lc);
+        ldsr_issue_tables(tabs[3], map, mapw, y0 + 4, a.H, a.W, lc);
+    } else if (PIPE) {
         // slot of source row rho = (rho - (y0 + 5)) & 3, so that the steady loop starts at slot 0
         remap_issue_map(mq[3], map, y0, a.H, a.W, lc);
         remap_issue_map(mq[0], map, y0 + 1, a.H, a.W, lc);
@@ -291,7 +427,18 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
     // next source row (row index `row`, queue slot J): its four pixels, and the refill of the pipeline behind it
     auto next_row = [&](auto Jc, int row) -> uint32_t {
         constexpr int J = decltype(Jc)::value;
-        if (PIPE) {
+        if (LDSR) {
+            const uint2* spans = a.spans + ((size_t)slot * a.n_strips + strip) * a.H;
+            ldsr_write(rq[J & 3], st, lane);                                         // 1
+            ldsr_read_taps(tb[(J + 1) & 1], tabs[(J + 1) & 3], st, row + 1, a.H, xq); // 2
+            ldsr_issue_tables(tabs[(J + 1) & 3], map, mapw, row + 5, a.H, a.W, lc);   // 3
+            int nr = row + RING_LOOKAHEAD;
+            nr = nr < 0 ? 0 : (nr > Hm1 ? Hm1 : nr);
+            ldsr_request(rq[J & 3], st, (int)(spans[nr].x >> 16), img, a.pitch);      // 4
+            uint32_t B = ldsr_combine(tb[J & 1], lc);                                 // 5
+            if ((unsigned)row >= (unsigned)a.H) B = 0u;
+            return B;
+        } else if (PIPE) {
             constexpr int S = J & 3;
             uint32_t B = remap_combine(tq[S], lc);
             if ((unsigned)row >= (unsigned)a.H) B = 0u; // wave-uniform select: rows outside the image are zero
@@ -580,19 +727,45 @@ __global__ void demosaic_kernel(const uint8_t* __restrict__ bayer, uint8_t* __re
     o[0] = (uint8_t)b; o[1] = (uint8_t)g; o[2] = (uint8_t)r;
 }
 
+// per (strip, row): the source rows [smin, smax] and columns [xmin, xmax] read by the strip's pixels of that row
+// (both taps included), from the tap-position table.  One thread per (strip, row); set-up time only.
+__global__ void remap_spans_kernel(SpanArgs a)
+{
+    int y = blockIdx.x * blockDim.x + threadIdx.x, strip = blockIdx.y;
+    if (y >= a.H) return;
+    int xa = strip * 240 - 8, xb = xa + 256;
+    xa = xa < 0 ? 0 : xa; xb = xb > a.W ? a.W : xb;
+    int smin = 0x7fff, smax = 0, xmin = 0x7fff, xmax = 0;
+    const uint32_t* row = a.map + (size_t)y * a.W;
+    for (int x = xa; x < xb; x++) {
+        uint32_t m = row[x];
+        int sx = x + (int)(int16_t)(m & 0xffffu), sy = y + ((int)m >> 16);
+        smin = sy < smin ? sy : smin; smax = sy + 1 > smax ? sy + 1 : smax;
+        xmin = sx < xmin ? sx : xmin; xmax = sx + 1 > xmax ? sx + 1 : xmax;
+    }
+    a.spans[(size_t)strip * a.H + y] = make_uint2((uint32_t)smin | ((uint32_t)smax << 16), (uint32_t)xmin | ((uint32_t)xmax << 16));
+}
+
 // ---- launchers -------------------------------------------------------------------------------------------------
+void launch_remap_spans(const SpanArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(remap_spans_kernel, dim3((a.H + 63) / 64, a.n_strips), dim3(64), 0, s, a);
+}
+
 void launch_filter_mask(const FilterArgs& a, bool remap, hipStream_t s)
 {
     int tiles = a.cam_mod * a.n_strips * a.n_cgroups;
     int blocks = ((tiles + 7) / 8) * 8 * a.n_steps;
-    if (remap && a.W >= 4 && (a.W & 3) == 0 && a.H >= 2)
-        hipLaunchKernelGGL((filter_mask_kernel<true, false, true>), dim3(blocks), dim3(256), 0, s, a);
+    if (remap && a.remap_mode == 4)
+        hipLaunchKernelGGL((filter_mask_kernel<true, false, false, true>), dim3(blocks), dim3(256), 0, s, a);
+    else if (remap && a.remap_mode == 3)
+        hipLaunchKernelGGL((filter_mask_kernel<true, false, true, false>), dim3(blocks), dim3(256), 0, s, a);
     else if (remap)
-        hipLaunchKernelGGL((filter_mask_kernel<true, false, false>), dim3(blocks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((filter_mask_kernel<true, false, false, false>), dim3(blocks), dim3(256), 0, s, a);
     else if (a.W >= 4)
-        hipLaunchKernelGGL((filter_mask_kernel<false, false, false>), dim3(blocks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((filter_mask_kernel<false, false, false, false>), dim3(blocks), dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL((filter_mask_kernel<false, true, false>), dim3(blocks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((filter_mask_kernel<false, true, false, false>), dim3(blocks), dim3(256), 0, s, a);
 }
 void launch_undistort_map(const MapArgs& m, hipStream_t s)
 {

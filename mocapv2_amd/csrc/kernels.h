@@ -16,6 +16,9 @@ struct FilterArgs {
     // undistort tables of the first slot used (remap variant only), each [cam_mod][H][W]:
     const uint32_t* map;  //   tap position: (sx - x) | (sy - y) << 16, the 2x2 tap window clamped into the image
     const uint32_t* mapw; //   blend weights 32*(wx0 | wx1<<8 | wy1<<16 | wy0<<24)/32, taps outside the image weigh 0
+    const uint2* spans;   //   per (slot, strip, row): x = smin | smax<<16, y = xmin | xmax<<16 (source rows / columns the
+                          //   strip's pixels of that row read); used by the LDS-staged remap variant
+    int remap_mode;       // 0 plain / 2 per-pixel gather, 3 pipelined gather, 4 LDS-staged
     int cam_mod;          // undistort slot of image n = n % cam_mod (map already points at the first slot)
     int n_images, n_steps; // n_steps = ceil(n_images / cam_mod)
     int thr_mul;          // floor(thresh)+1: blurred > thresh  <=>  S >= thr_mul * taps
@@ -59,12 +62,14 @@ struct ContourArgs {
     int max_steps;
     const uint32_t* cells; // occupancy written by the filter kernel (see FilterArgs), or null = scan every row
     int rows_per_chunk, n_chunks, n_strips;
-    int debug_stop;
 };
 
 enum { BLOB_ERR_CANDIDATES = -2, BLOB_ERR_CONTOURS = -3, BLOB_ERR_STEPS = -4, BLOB_ERR_DEPTH = -5 };
 
 void launch_filter_mask(const FilterArgs& a, bool remap, hipStream_t s);
+struct SpanArgs { const uint32_t* map; uint2* spans; int H, W, n_strips; };
+void launch_remap_spans(const SpanArgs& a, hipStream_t s);
+constexpr int RING_H = 32, RING_W = 288, RING_LOOKAHEAD = 5; // LDS source-row ring of the staged remap (per wave)
 void launch_undistort_map(const MapArgs& m, hipStream_t s);
 void launch_contours(const ContourArgs& a, hipStream_t s);
 void launch_box_blur(const uint8_t* src, uint8_t* dst, int H, int W, int sp, int dp, int ksize, hipStream_t s);

@@ -54,17 +54,21 @@ def test_filter_mask_identity(torch_cuda, W, H):
         assert np.array_equal(got[i], exp), f"image {i}: {np.argwhere(got[i] != exp)[:5]}"
 
 
-@pytest.mark.parametrize("W,H", [(64, 48), (250, 130), (500, 300), (960, 540)])
-@pytest.mark.parametrize("scale", [1.0, 4.0])
-def test_filter_mask_remap(torch_cuda, W, H, scale):
+@pytest.mark.parametrize("W,H", [(64, 48), (250, 130), (251, 77), (500, 300), (960, 540)])
+@pytest.mark.parametrize("scale", [1.0, 4.0, -3.0])
+@pytest.mark.parametrize("mode", ["2", "3", "4"])
+def test_filter_mask_remap(torch_cuda, monkeypatch, W, H, scale, mode):
+    """All three remap kernels (per-pixel gather, pipelined gather, LDS-staged; MOCAP_REMAP_MODE caps the variant
+    the library picks) against cv.undistort + filter as restated by the oracle; barrel, strong barrel, pincushion."""
     from gpu_util import unpack_mask
     torch = torch_cuda
+    monkeypatch.setenv("MOCAP_REMAP_MODE", mode)
     rng = np.random.default_rng(W + H)
     frames = rand_frames(rng, 2, H, W, bright=0.2, blobs=6)
     dist = np.array(MILD_DIST) * scale
     ctx, K, ident = make_ctx(W, H, dist=dist)
     assert not ident
-    # the device-built map equals the oracle's: undistorted images identical, pixel for pixel
+    # the device-built tables reproduce the oracle's undistorted image, pixel for pixel
     und = ctx.undistort(torch.from_numpy(frames[0]).cuda()).cpu().numpy()
     assert np.array_equal(und, oracle.undistort(frames[0], K, dist))
     got, _ = unpack_mask(ctx.filter_mask(torch.from_numpy(frames).cuda()), W)
