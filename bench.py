@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dist", choices=["mild", "zero"], default="mild")
     ap.add_argument("--cpu-steps", type=int, default=256, help="time steps in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-secondary", dest="secondary", action="store_false",
+                    help="skip the second timed run with the other distortion variant")
     args = ap.parse_args()
 
     import torch
@@ -97,34 +99,38 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    scene = Scene(N_CAM, WIDTH, HEIGHT, dist=MILD_DIST if args.dist == "mild" else ZERO_DIST)
-    arrays = scene_arrays(scene)
-    tracker = BatchTracker(*arrays, WIDTH, HEIGHT, T_STEPS, world=world, rank=rank, device=local_rank)
-    images = tracker.local_image_list()
-    frames_host = render_local(scene, images)
-    frames = torch.from_numpy(frames_host).cuda()
-    torch.cuda.synchronize()
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        tracker.step(frames)
-    barrier()
-    tracker.ctx.profile(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = tracker.step(frames)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    tracker.ctx.profile(False)
-    prof = tracker.ctx.profile_read()
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    def measure(dist_name):
+        """Build the scene / tracker / resident batch for one distortion variant and time K steps of it."""
+        scene = Scene(N_CAM, WIDTH, HEIGHT, dist=MILD_DIST if dist_name == "mild" else ZERO_DIST)
+        arrays = scene_arrays(scene)
+        tracker = BatchTracker(*arrays, WIDTH, HEIGHT, T_STEPS, world=world, rank=rank, device=local_rank)
+        images = tracker.local_image_list()
+        frames_host = render_local(scene, images)
+        frames = torch.from_numpy(frames_host).cuda()
+        torch.cuda.synchronize()
+        for _ in range(args.warmup):
+            tracker.step(frames)
+        barrier()
+        tracker.ctx.profile(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = tracker.step(frames)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        tracker.ctx.profile(False)
+        prof = tracker.ctx.profile_read()
+        if world > 1:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        return scene, arrays, tracker, images, frames_host, out, elapsed, prof
+
+    scene, arrays, tracker, images, frames_host, out, elapsed, prof = measure(args.dist)
 
     n_roots = out["n"].cpu().numpy()
     status_ok = bool((n_roots >= 0).all()) and bool((tracker.records[:, 0] >= 0).all().item())
@@ -132,10 +138,14 @@ def main():
     if rank == 0:
         frames_per_step = T_STEPS * world
         value = frames_per_step * args.steps / elapsed
-        launches = max(1, prof["filter_launches"])
-        images_per_launch = len(images) / (1 if world == 1 else len(tracker.segs))
-        filt_ms = prof["filter_ms"] / launches
-        achieved = WIDTH * HEIGHT * images_per_launch / (filt_ms * 1e-3) / 1e9
+        def roofline_of(prof, n_images, n_launch_groups):
+            launches = max(1, prof["filter_launches"])
+            per_launch = n_images / n_launch_groups
+            ms = prof["filter_ms"] / launches
+            ach = WIDTH * HEIGHT * per_launch / (ms * 1e-3) / 1e9
+            return ach, ms, per_launch
+
+        achieved, filt_ms, images_per_launch = roofline_of(prof, len(images), 1 if world == 1 else len(tracker.segs))
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "filter_traffic.json")
         if os.path.exists(tpath):  # HBM bytes per launch from the PMC pass (profiles/README.md), same workload
@@ -163,6 +173,23 @@ def main():
             "status_ok": status_ok,
             "points_per_frame": float(n_roots.mean()),
         }
+        if world == 1 and args.secondary:
+            other = "zero" if args.dist == "mild" else "mild"
+            _, _, tr2, im2, _, out2, el2, prof2 = measure(other)
+            ach2, ms2, ipl2 = roofline_of(prof2, len(im2), 1)
+            line["other_distortion_variant"] = {
+                "distortion": other, "value": round(T_STEPS * args.steps / el2, 2), "unit": "frames/s",
+                "ms_per_step": round(1e3 * el2 / args.steps, 4),
+                "roofline": {"bound": "hbm", "kernel": "filter_mask_kernel", "achieved": round(ach2, 1), "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": round(ach2 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(ms2, 4),
+                             "images_per_launch": ipl2},
+                "kernel_ms_per_step": {"filter": round(prof2["filter_ms"] / args.steps, 4),
+                                       "contours": round(prof2["contour_ms"] / args.steps, 4),
+                                       "correspond": round(prof2["corr_ms"] / args.steps, 4)},
+                "status_ok": bool((out2["n"].cpu().numpy() >= 0).all()),
+                "note": "same workload with zero lens distortion: cv.undistort is then the identity map and the "
+                        "kernel streams the frame without the remap gather (SURVEY.md section 8d lists both variants)"}
+            del tr2
         if world == 1 and args.cpu_steps > 0:
             fps, dt, n_pts, last = cpu_baseline(scene, arrays, frames_host.reshape(T_STEPS, N_CAM, HEIGHT, WIDTH), args.cpu_steps)
             line["cpu_baseline"] = {"value": round(fps, 3), "unit": "frames/s", "cores": N_CAM, "kind": "port",

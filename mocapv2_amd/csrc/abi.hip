@@ -328,6 +328,10 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
     // MI355X so far, so it is opt-in: MOCAP_REMAP_MODE=4; 2 or 3 force a simpler variant (tests).
     { const char* e = getenv("MOCAP_REMAP_MODE"); int cap = e ? atoi(e) : 3; if (cap < 2) cap = 3; if (cap < mode) mode = cap; }
     a.remap_mode = mode;
+    // time-fastest order by default: measured 4 % faster on the plain variant than strip-fastest, which in turn
+    // fetches 28 % fewer HBM bytes (profiles/README.md).  MOCAP_STRIP_ORDER=1 selects strip-fastest.
+    a.strip_fastest = 0;
+    { const char* e = getenv("MOCAP_STRIP_ORDER"); if (e) a.strip_fastest = atoi(e) != 0; }
     a.spans = c->spans ? c->spans + (size_t)slot_base * tiling(c).n_strips * c->H : nullptr;
     EvPair p; bool on;
     prof_begin(c, 0, s, p, on);
@@ -458,6 +462,7 @@ int mocap_image_filter_u8(mocap_ctx_t c, const void* src, void* dst, int spitch,
     a.map = slot >= 0 ? c->maps + (size_t)slot * c->H * c->W : nullptr;
     a.mapw = slot >= 0 ? c->maps + (size_t)(c->n_slots + slot) * c->H * c->W : nullptr;
     a.remap_mode = slot >= 0 ? c->slot_mode[slot] : 0;
+    a.strip_fastest = 0;
     a.spans = (slot >= 0 && c->spans) ? c->spans + (size_t)slot * tiling(c).n_strips * c->H : nullptr;
     a.thr_mul = ithresh + 1;
     Tiling tl = tiling(c);

@@ -287,16 +287,32 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
     }
     __syncthreads();
 
-    // block -> (tile, time step).  Blocks b and b+8 share an XCD (round-robin dispatch): all time steps of
-    // one (camera, strip, chunk group) tile are dealt to the same XCD back to back, so the tile's undistort
-    // map is fetched into that XCD's L2 once per batch instead of once per frame.
-    const int tiles = a.cam_mod * a.n_strips * a.n_cgroups;
+    // block -> (camera slot, strip, chunk group, time step).  Blocks b and b+8 share an XCD (round-robin dispatch;
+    // placement only affects speed).  Two orders:
+    //  * time-fastest: all time steps of one (slot, strip, chunk group) tile go to the same XCD back to back, so the
+    //    tile's undistort tables are fetched into that XCD's L2 once per batch instead of once per frame;
+    //  * strip-fastest: the strips of one (image, chunk group) go to the same XCD back to back, so the 128-byte
+    //    lines that two neighbouring strips share (strips overlap by 16 columns and are not line-aligned) are
+    //    fetched from HBM once.
     const int b = blockIdx.x, xcd = b & 7, q_ = b >> 3;
-    const int tile = (q_ / a.n_steps) * 8 + xcd, tstep = q_ % a.n_steps;
-    if (tile >= tiles) return;
-    const int slot = tile % a.cam_mod;
-    const int strip = (tile / a.cam_mod) % a.n_strips;
-    const int cgroup = tile / (a.cam_mod * a.n_strips);
+    int slot, strip, cgroup, tstep;
+    if (!a.strip_fastest) {
+        const int tiles = a.cam_mod * a.n_strips * a.n_cgroups;
+        const int tile = (q_ / a.n_steps) * 8 + xcd;
+        tstep = q_ % a.n_steps;
+        if (tile >= tiles) return;
+        slot = tile % a.cam_mod;
+        strip = (tile / a.cam_mod) % a.n_strips;
+        cgroup = tile / (a.cam_mod * a.n_strips);
+    } else {
+        const int groups = a.cam_mod * a.n_cgroups * a.n_steps;
+        const int grp = (q_ / a.n_strips) * 8 + xcd;
+        strip = q_ % a.n_strips;
+        if (grp >= groups) return;
+        slot = grp % a.cam_mod;
+        cgroup = (grp / a.cam_mod) % a.n_cgroups;
+        tstep = grp / (a.cam_mod * a.n_cgroups);
+    }
     const int image = tstep * a.cam_mod + slot;
     if (image >= a.n_images) return;
 
@@ -754,8 +770,14 @@ void launch_remap_spans(const SpanArgs& a, hipStream_t s)
 
 void launch_filter_mask(const FilterArgs& a, bool remap, hipStream_t s)
 {
-    int tiles = a.cam_mod * a.n_strips * a.n_cgroups;
-    int blocks = ((tiles + 7) / 8) * 8 * a.n_steps;
+    int blocks;
+    if (!a.strip_fastest) {
+        int tiles = a.cam_mod * a.n_strips * a.n_cgroups;
+        blocks = ((tiles + 7) / 8) * 8 * a.n_steps;
+    } else {
+        int groups = a.cam_mod * a.n_cgroups * a.n_steps;
+        blocks = ((groups + 7) / 8) * 8 * a.n_strips;
+    }
     if (remap && a.remap_mode == 4)
         hipLaunchKernelGGL((filter_mask_kernel<true, false, false, true>), dim3(blocks), dim3(256), 0, s, a);
     else if (remap && a.remap_mode == 3)

@@ -19,6 +19,7 @@ struct FilterArgs {
     const uint2* spans;   //   per (slot, strip, row): x = smin | smax<<16, y = xmin | xmax<<16 (source rows / columns the
                           //   strip's pixels of that row read); used by the LDS-staged remap variant
     int remap_mode;       // 0 plain / 2 per-pixel gather, 3 pipelined gather, 4 LDS-staged
+    int strip_fastest;    // block order: 1 = neighbouring strips share an XCD in time, 0 = time steps of a tile do
     int cam_mod;          // undistort slot of image n = n % cam_mod (map already points at the first slot)
     int n_images, n_steps; // n_steps = ceil(n_images / cam_mod)
     int thr_mul;          // floor(thresh)+1: blurred > thresh  <=>  S >= thr_mul * taps

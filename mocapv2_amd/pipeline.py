@@ -80,26 +80,39 @@ class BatchTracker:
             return [(c, t) for t in range(self.T) for c in range(self.n_cam)]  # time-major [T][C]
         return [(c, t) for c, t0, t1 in self.segs for t in range(t0, t1)]
 
-    def step(self, frames):
-        """frames: uint8 [per, H, W] on the GPU, ordered as local_image_list().  Returns the correspondence
-        outputs (dict of device tensors, see MocapContext.correspond) for this rank's time steps
-        [rank * T, (rank + 1) * T)."""
+    def extract(self, frames):
+        """Stage A on this rank's block.  frames: uint8 [per, H, W] on the GPU, ordered as local_image_list().
+        Fills and returns self.records ([per, REC] int32, one centroid record per image)."""
         ctx = self.ctx
         if self.world == 1:
             ctx.blob_centroids(frames, cam_mod=self.n_cam, records=self.records)
-            self.out = ctx.correspond_records(self.records, self.T, self.n_cam, t0=0, stride_t=self.n_cam, stride_c=1,
-                                              P=self.max_points, max_groups=self.max_groups, out=self.out)
-            return self.out
+            return self.records
         o = 0
         for c, t0, t1 in self.segs:
             n = t1 - t0
             ctx.blob_centroids(frames[o:o + n], cam_mod=1, slot_base=self.slot_of[c], records=self.records[o:o + n])
             o += n
-        gathered = allgather_records(self.records, self.world, self.group)  # [C * T_total, REC], camera-major
-        self.out = ctx.correspond_records(gathered, self.T, self.n_cam, t0=self.rank * self.T, stride_t=1,
-                                          stride_c=self.t_total, P=self.max_points, max_groups=self.max_groups,
-                                          out=self.out)
+        return self.records
+
+    def triangulate(self, gathered):
+        """Stage B for this rank's time steps [rank * T, (rank + 1) * T) from the records of all cameras
+        (world == 1: self.records, time-major; else the all-gathered records, camera-major)."""
+        ctx = self.ctx
+        if self.world == 1:
+            self.out = ctx.correspond_records(gathered, self.T, self.n_cam, t0=0, stride_t=self.n_cam, stride_c=1,
+                                              P=self.max_points, max_groups=self.max_groups, out=self.out)
+        else:
+            self.out = ctx.correspond_records(gathered, self.T, self.n_cam, t0=self.rank * self.T, stride_t=1,
+                                              stride_c=self.t_total, P=self.max_points, max_groups=self.max_groups,
+                                              out=self.out)
         return self.out
+
+    def step(self, frames):
+        """One pass of the hot path over this rank's block: extract -> (all-gather) -> triangulate.  Returns the
+        correspondence outputs (dict of device tensors, see MocapContext.correspond) for this rank's time steps."""
+        records = self.extract(frames)
+        gathered = allgather_records(records, self.world, self.group)  # [C * T_total, REC] camera-major when world > 1
+        return self.triangulate(gathered)
 
 
 def scene_arrays(scene):
