@@ -36,7 +36,7 @@ enum {
     MOCAP_BLOB_E_CONTOURS = -3,   /* more than 384 borders or 256 kept contours in one image */
     MOCAP_BLOB_E_STEPS = -4,      /* a border longer than the step limit */
     MOCAP_BLOB_E_DEPTH = -5,      /* a kept contour nested deeper than 8 levels */
-    MOCAP_CORR_E_GROUPS = -2      /* more than 8 candidates for one (root, camera) or > max_groups groups */
+    MOCAP_CORR_E_GROUPS = -2      /* more than 16 candidates for one (root, camera) or > max_groups groups */
 };
 
 typedef struct mocap_ctx* mocap_ctx_t;

@@ -506,6 +506,8 @@ int mocap_correspond(mocap_ctx_t c, const void* pts, long pt_st, long pt_sc, con
     if (T < 1 || C < 1 || C > 32 || P < 1 || P > 255 || max_groups < 1) return fail(MOCAP_E_INVALID, "T=%d C=%d P=%d max_groups=%d", T, C, P, max_groups);
     if (c->n_cam < C) return fail(MOCAP_E_STATE, "mocap_set_cameras: %d cameras set, %d needed", c->n_cam, C);
     if (c->n_F < C - 1) return fail(MOCAP_E_STATE, "mocap_set_fundamentals: %d matrices set, %d needed", c->n_F, C - 1);
+    if (correspond_smem_bytes(P, C) > 64 * 1024)
+        return fail(MOCAP_E_UNSUPPORTED, "P=%d points x C=%d cameras needs %zu bytes of LDS (> 64 KiB)", P, C, correspond_smem_bytes(P, C));
     if (set_device(c)) return MOCAP_E_HIP;
     size_t need = (size_t)T * P * max_groups;
     if (need > c->scratch_elems) {

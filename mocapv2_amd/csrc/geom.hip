@@ -17,7 +17,7 @@ namespace mocap {
 
 namespace {
 
-constexpr int MAXM = 8; // candidate matches kept per (root, camera)
+constexpr int MAXM = 16; // candidate matches kept per (root, camera)
 
 __device__ double np_block_sum(const double* a, int n)
 { // numpy pairwise_sum for n <= 128

@@ -129,6 +129,7 @@ struct ReprojArgs {
 enum { CORR_ERR_GROUPS = -2 };
 
 void launch_correspond(const CorrArgs& a, hipStream_t s);
+size_t correspond_smem_bytes(int P, int C);
 void launch_triangulate(const TriArgs& a, hipStream_t s);
 void launch_reproject(const ReprojArgs& a, hipStream_t s);
 
