@@ -28,7 +28,7 @@ namespace mocap {
 
 namespace {
 
-constexpr int MAXC = 2048;  // candidates per image
+constexpr int MAXC = 1024;  // candidates per image (after the run-level filters)
 constexpr int MAXR = 384;   // borders per image
 constexpr int MAXK = 256;   // kept contours per image
 constexpr int MAXD = 8;     // nesting depth of a kept contour
@@ -73,37 +73,35 @@ __device__ __forceinline__ int dir_dx(int s) { return (int)((0x901au >> (2 * s))
 __device__ __forceinline__ int dir_dy(int s) { return (int)((0xa901u >> (2 * s)) & 3u) - 1; }  // 0,-1,-1,-1,0,1,1,1
 
 struct Trace {
-    int64_t a00, a10, a01;
-    double per;
-    int npts, steps;
-    int min_fg;   // raster-minimum border pixel
-    int min_ebg;  // raster-minimum background pixel right of a border pixel whose East side was examined
-    int status;   // 0 ok, 1 aborted (not the raster-first start), 2 step limit
-    int fx, fy, px, py;
-    __device__ __forceinline__ void edge(int xp, int yp, int xi, int yi)
-    {
-        int64_t d = (int64_t)xp * yi - (int64_t)xi * yp;
-        a00 += d;
-        a10 += d * (xp + xi);
-        a01 += d * (yp + yi);
-        float dx = (float)xi - (float)xp, dy = (float)yi - (float)yp;
-        per += (double)__fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
-    }
-    __device__ __forceinline__ void vertex(int x, int y)
-    {
-        if (npts == 0) { fx = x; fy = y; }
-        else edge(px, py, x, y);
-        px = x; py = y;
-        npts++;
-    }
+    int64_t a00, a10, a01; // Green's-theorem sums over the border polygon (exact)
+    double per;            // cv.arcLength of the CHAIN_APPROX_SIMPLE polygon (float32 sqrt per segment, exact sum)
+    int npts, steps;       // SIMPLE vertex count, border steps
+    int min_fg;            // raster-minimum border pixel
+    int min_ebg;           // raster-minimum background pixel right of a border pixel whose East side was examined
+    int status;            // 0 ok, 1 aborted (not the raster-first start), 2 step limit
+    int bx0, by0, bx1, by1; // bounding box of the border pixels
 };
+
+// float32 length of a straight run of k unit steps in direction code s, as cv.arcLength computes it
+__device__ __forceinline__ double run_length(int s, int k)
+{
+    float d = (float)k;
+    float q = (s & 1) ? __fadd_rn(__fmul_rn(d, d), __fmul_rn(d, d)) : __fmul_rn(d, d);
+    return (double)__fsqrt_rn(q);
+}
 
 // Border following by one wave.  Follows the border through pixel (sx,sy) whose neighbour in direction `first`
 // (4 = W for an outer start, 0 = E for a hole start) is background.  Aborts when a border pixel with raster index
 // < abort_fg or an East-side background pixel with raster index < abort_ebg is met.  Every argument and every
 // field of T is wave-uniform.
+//
+// The polygon sums are accumulated per border step: splitting a straight polygon edge at the pixels it passes
+// through leaves a00, a10, a01 unchanged (they are exact line integrals), so no vertex list is needed.  The
+// perimeter needs the CHAIN_APPROX_SIMPLE segments: axis-parallel runs add their integer length, diagonal runs of
+// k steps are counted in a per-wave LDS histogram (`diag`, 64 bins) and turned into float32 sqrt(2k^2) terms once
+// at the end -- every term is a float32 >= 1, so their double sum is exact in any order.
 __device__ void follow(const Mask& M, int sx, int sy, int first, int top_start, int abort_fg, int abort_ebg,
-                       int max_steps, Trace& T, int lane)
+                       int max_steps, Trace& T, int lane, uint32_t* diag)
 {
     T.a00 = T.a10 = T.a01 = 0;
     T.per = 0.0;
@@ -111,6 +109,8 @@ __device__ void follow(const Mask& M, int sx, int sy, int first, int top_start, 
     T.status = 0;
     T.min_fg = sy * M.RS + sx;
     T.min_ebg = 0x7fffffff;
+    T.bx0 = T.bx1 = sx; T.by0 = T.by1 = sy;
+    diag[lane] = 0u;
 
     Window win;
     // a raster-first start sits on the top row of its border: put it near the top of the window
@@ -131,14 +131,23 @@ __device__ void follow(const Mask& M, int sx, int sy, int first, int top_start, 
     do {
         s = (s - 1) & 7;
     } while (!((n >> s) & 1u) && s != s_end);
-    if (s == s_end) { // isolated pixel
-        T.vertex(sx, sy);
+    if (s == s_end) { // isolated pixel: one vertex, zero area, zero perimeter
+        T.npts = 1;
         T.min_ebg = sy * M.RS + sx + 1;
-        T.edge(T.px, T.py, T.fx, T.fy);
         return;
     }
     const int i1x = sx + dir_dx(s), i1y = sy + dir_dy(s);
-    int prev_s = s ^ 4;
+    int prev_s = s ^ 4;       // direction of the step that will close the border (arrives at the start)
+    int run = 0;              // steps taken in direction prev_s since the last vertex
+    int first_len = -1;       // length of the run leaving the start when the start is not a vertex (merged at the end)
+    long axis = 0;            // total length of the axis-parallel segments
+    double extra = 0.0;       // diagonal runs too long for the histogram
+    auto close_run = [&](int dir, int k) {
+        if (k == 0) return;
+        if (!(dir & 1)) axis += k;
+        else if (k < 64) { if (lane == 0) atomicAdd(&diag[k], 1u); }
+        else extra += run_length(dir, k);
+    };
     for (;;) {
         s_end = s;
         // first occupied neighbour counter-clockwise from s_end+1
@@ -147,19 +156,30 @@ __device__ void follow(const Mask& M, int sx, int sy, int first, int top_start, 
         s = u & 7;
         int r = y * M.RS + x;
         if ((unsigned)(s - 1) < (unsigned)s_end) { // the East neighbour was examined and is background
-            if (r + 1 < T.min_ebg) T.min_ebg = r + 1;
+            T.min_ebg = r + 1 < T.min_ebg ? r + 1 : T.min_ebg;
             if (r + 1 < abort_ebg) { T.status = 1; return; }
         }
-        if (r < T.min_fg) T.min_fg = r;
+        T.min_fg = r < T.min_fg ? r : T.min_fg;
         if (r < abort_fg) { T.status = 1; return; }
-        if (s != prev_s) {
-            T.vertex(x, y);
+        if (s != prev_s) { // (x,y) is a CHAIN_APPROX_SIMPLE vertex
+            if (T.npts == 0 && T.steps > 0) first_len = run; // the start was not a vertex: its run is closed at the end
+            else close_run(prev_s, run);
+            T.npts++;
             prev_s = s;
+            run = 0;
         }
-        int nx = x + dir_dx(s), ny = y + dir_dy(s);
+        run++;
+        const int dx = dir_dx(s), dy = dir_dy(s);
+        const int nx = x + dx, ny = y + dy;
+        const int cross = x * dy - dx * y; // x*ny - nx*y
+        T.a00 += cross;
+        T.a10 += (int64_t)cross * (2 * x + dx);
+        T.a01 += (int64_t)cross * (2 * y + dy);
         T.steps++;
         if (nx == sx && ny == sy && x == i1x && y == i1y) break;
         if (T.steps > max_steps) { T.status = 2; return; }
+        T.bx0 = nx < T.bx0 ? nx : T.bx0; T.bx1 = nx > T.bx1 ? nx : T.bx1;
+        T.by0 = ny < T.by0 ? ny : T.by0; T.by1 = ny > T.by1 ? ny : T.by1;
         // move, keeping the three cached rows around the current pixel
         int lx = nx - win.x0, ly = ny - win.y0;
         if (lx < 1 || lx > 62 || ly < 1 || ly > 62) { // left the window: re-centre it on the new pixel
@@ -174,7 +194,17 @@ __device__ void follow(const Mask& M, int sx, int sy, int first, int top_start, 
         s = (s + 4) & 7;
         n = nbr8();
     }
-    T.edge(T.px, T.py, T.fx, T.fy); // close the polygon
+    // the run that arrives at the start, merged with the run that left it when the start is not a vertex
+    close_run(prev_s, run + (first_len > 0 ? first_len : 0));
+    // perimeter: integer part + histogram of diagonal runs (bin k = runs of k steps), reduced over the wave
+    double term = 0.0;
+    {
+        uint32_t cnt = diag[lane];
+        if (lane >= 1 && cnt) term = (double)cnt * run_length(1, lane);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) term += __shfl_xor(term, d);
+    T.per = (double)axis + extra + term;
 }
 
 // reference lib/ImageOperations.py:43-65 for one contour
@@ -213,6 +243,8 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
     __shared__ int32_t kept_path[MAXK][MAXD];
     __shared__ int8_t kept_depth[MAXK];
     __shared__ uint16_t cell_list[MAXCELL];
+    __shared__ uint32_t diag_hist[NWAVES][64]; // per-wave histogram of diagonal run lengths (see follow)
+    __shared__ int16_t rbox[MAXR][4];          // bounding box of each border: x0, y0, x1, y1
     __shared__ int ncand, nrec, nkept, err, ncell;
 
     const int image = blockIdx.x;
@@ -325,8 +357,8 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
         int is_hole = (v >> 15) & 1, x = v & 0x7fff, y = v >> 16;
         int key = y * M.RS + x;
         Trace T;
-        if (!is_hole) follow(M, x, y, 4, 1, key, -1, a.max_steps, T, lane);
-        else follow(M, x - 1, y, 0, 0, -1, key, a.max_steps, T, lane);
+        if (!is_hole) follow(M, x, y, 4, 1, key, -1, a.max_steps, T, lane, diag_hist[wv]);
+        else follow(M, x - 1, y, 0, 0, -1, key, a.max_steps, T, lane, diag_hist[wv]);
         if (T.status == 2 && lane == 0) atomicMax(&err, 1);
         if (T.status != 0) continue;
         int slot = 0;
@@ -343,6 +375,8 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
             r.perimeter = T.npts > 1 ? T.per : 0.0;
             r.link = -1; r.parent = -1; r.order = -1;
             select_contour(r, a.min_area, a.min_circ);
+            rbox[slot][0] = (int16_t)T.bx0; rbox[slot][1] = (int16_t)T.by0;
+            rbox[slot][2] = (int16_t)T.bx1; rbox[slot][3] = (int16_t)T.by1;
         }
     }
     __syncthreads();
@@ -376,17 +410,33 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
             }
         }
         if (qx < 0) { if (lane == 0) recs[c].link = -1; continue; } // nothing to the left: the frame
-        Trace T;
-        follow(M, qx, y, r_is_hole ? 4 : 0, 0, -1, -1, a.max_steps, T, lane);
-        if (T.status) { if (lane == 0) atomicMax(&err, 1); continue; }
-        int ltype = T.a00 > 0 ? 1 : 0; // hole borders run the other way round
-        int lkey = ltype ? T.min_ebg : T.min_fg;
+        // The crack's owner passes through pixel (qx, y), so its bounding box contains it, and it is never this
+        // border itself (its pixels are all raster-later than its start).  If exactly one other border's box
+        // contains the pixel, that border is the owner; only otherwise is the owner found by following it.
         int found = -2;
-        for (int jb = 0; jb < nr; jb += 64) {
-            int j = jb + lane;
-            bool hit = j < nr && recs[j].key == lkey && recs[j].is_hole == ltype;
-            uint64_t bal = __ballot(hit);
-            if (bal) { found = jb + __ffsll((long long)bal) - 1; break; }
+        {
+            int hits = 0, which = -1;
+            for (int jb = 0; jb < nr; jb += 64) {
+                int j = jb + lane;
+                bool in = j < nr && j != c && rbox[j][0] <= qx && qx <= rbox[j][2] && rbox[j][1] <= y && y <= rbox[j][3];
+                uint64_t bal = __ballot(in);
+                hits += __popcll(bal);
+                if (bal && which < 0) which = jb + __ffsll((long long)bal) - 1;
+            }
+            if (hits == 1) found = which;
+        }
+        if (found == -2) {
+            Trace T;
+            follow(M, qx, y, r_is_hole ? 4 : 0, 0, -1, -1, a.max_steps, T, lane, diag_hist[wv]);
+            if (T.status) { if (lane == 0) atomicMax(&err, 1); continue; }
+            int ltype = T.a00 > 0 ? 1 : 0; // hole borders run the other way round
+            int lkey = ltype ? T.min_ebg : T.min_fg;
+            for (int jb = 0; jb < nr; jb += 64) {
+                int j = jb + lane;
+                bool hit = j < nr && recs[j].key == lkey && recs[j].is_hole == ltype;
+                uint64_t bal = __ballot(hit);
+                if (bal) { found = jb + __ffsll((long long)bal) - 1; break; }
+            }
         }
         if (lane == 0) {
             if (found == -2) atomicMax(&err, 2);
