@@ -44,6 +44,7 @@ struct mocap_ctx {
     uint32_t* maps;           // [2][n_slots][H][W]: tap positions, then blend weights
     uint32_t* map_flags;      // [n_slots] device, followed by 256 trash bytes
     std::vector<int> slot_state; // 0 unset, 1 identity, 2 remap
+    std::vector<uint32_t> slot_wmax; // largest total blend weight of a source pixel (1024 = identity); 0 = early-out not provable
     std::vector<int> slot_mode;  // remap kernel variant the slot's table admits: 2 per-pixel, 3 pipelined gather, 4 LDS-staged
     uint2* spans;             // [n_slots][n_strips][H] source row / column spans per strip row
     uint32_t* mask; size_t mask_images;
@@ -130,6 +131,7 @@ int mocap_ctx_create(int device_id, int width, int height, int n_slots, mocap_ct
     c->cams = nullptr; c->n_cam = 0; c->n_F = 0; c->scratch = nullptr; c->scratch_elems = 0; c->profiling = false;
     c->slot_state.assign(n_slots, 0);
     c->slot_mode.assign(n_slots, 2);
+    c->slot_wmax.assign(n_slots, 0);
     hipError_t e = hipMalloc(&c->map_flags, sizeof(uint32_t) * n_slots + 256);
     if (e == hipSuccess) e = hipMemset(c->map_flags, 0, sizeof(uint32_t) * n_slots);
     if (e == hipSuccess) e = hipMalloc(&c->cams, sizeof(CameraTable));
@@ -198,6 +200,7 @@ int mocap_set_undistort(mocap_ctx_t c, int slot, const double K[9], const double
     HIP_TRY(hipMemcpy(&flags, m.flags, sizeof(flags), hipMemcpyDeviceToHost));
     c->slot_state[slot] = (flags & 1u) ? 2 : 1;
     c->slot_mode[slot] = 2;
+    c->slot_wmax[slot] = c->slot_state[slot] == 1 ? 1024u : 0u; // identity: every source pixel feeds exactly one output pixel
     if (c->slot_state[slot] == 2) {
         Tiling tl = tiling(c);
         size_t nsp = (size_t)tl.n_strips * c->H;
@@ -209,6 +212,20 @@ int mocap_set_undistort(mocap_ctx_t c, int slot, const double K[9], const double
         HIP_TRY(hipMemcpy(sp.data(), sa.spans, sizeof(uint2) * nsp, hipMemcpyDeviceToHost));
         if (lds_remap_ok(c, sp)) c->slot_mode[slot] = 4;
         else if (c->W >= 4 && (c->W & 3) == 0 && c->H >= 2) c->slot_mode[slot] = 3;
+        // statistics for the dark-tile early-out (see blob_filter.hip): total weight per source pixel, tap extents
+        uint32_t* tmp = nullptr;
+        HIP_TRY(hipMalloc(&tmp, sizeof(uint32_t) * (per + 4)));
+        hipError_t e2 = hipMemset(tmp, 0, sizeof(uint32_t) * (per + 4));
+        uint32_t st3[3] = {0, 0, 0};
+        if (e2 == hipSuccess) {
+            StatArgs sg{m.map, m.mapw, tmp, tmp + per, c->H, c->W};
+            launch_remap_stats(sg, 0);
+            e2 = hipGetLastError();
+            if (e2 == hipSuccess) e2 = hipMemcpy(st3, tmp + per, sizeof(st3), hipMemcpyDeviceToHost);
+        }
+        (void)hipFree(tmp);
+        if (e2 != hipSuccess) return fail(MOCAP_E_HIP, "undistort statistics: %s", hipGetErrorString(e2));
+        if (st3[1] <= 9 && st3[2] <= 9 && c->W >= 8) c->slot_wmax[slot] = st3[0];
     }
     if (identity_out) *identity_out = c->slot_state[slot] == 1;
     return MOCAP_OK;
@@ -328,6 +345,24 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
     // MI355X so far, so it is opt-in: MOCAP_REMAP_MODE=4; 2 or 3 force a simpler variant (tests).
     { const char* e = getenv("MOCAP_REMAP_MODE"); int cap = e ? atoi(e) : 3; if (cap < 2) cap = 3; if (cap < mode) mode = cap; }
     a.remap_mode = mode;
+    // dark-tile early-out: largest bright-pixel count per 16x16 block that still proves an all-zero mask
+    //   2 * n * (256 - 64) * Wmax < 1024 * taps_min * (2 * thr_mul - 2 * 64 + 1)     (derivation: blob_filter.hip)
+    {
+        long long wmax = 0;
+        bool ok = true, any_ident = false, any_remap = false;
+        for (int sl = slot_base; sl < slot_base + cam_mod; sl++) {
+            if (c->slot_wmax[sl] == 0) ok = false;
+            wmax = c->slot_wmax[sl] > wmax ? c->slot_wmax[sl] : wmax;
+            (c->slot_state[sl] == 2 ? any_remap : any_ident) = true;
+        }
+        if (any_ident && any_remap) ok = false; // identity slots carry no span table for the remap kernels' scan
+        auto t5 = [](int n) { return (n - 1 < 2 ? n - 1 : 2) + 1; };
+        long long rhs = 1024LL * t5(c->W) * t5(c->H) * (2LL * a.thr_mul - 127);
+        int allow = -1;
+        if (ok && wmax > 0 && rhs > 0) allow = (int)((rhs - 1) / (2LL * 192 * wmax));
+        { const char* e = getenv("MOCAP_SKIP_DARK"); if (e && atoi(e) == 0) allow = -1; }
+        a.skip_allow = allow;
+    }
     // time-fastest order by default: measured 4 % faster on the plain variant than strip-fastest, which in turn
     // fetches 28 % fewer HBM bytes (profiles/README.md).  MOCAP_STRIP_ORDER=1 selects strip-fastest.
     a.strip_fastest = 0;
@@ -463,6 +498,7 @@ int mocap_image_filter_u8(mocap_ctx_t c, const void* src, void* dst, int spitch,
     a.mapw = slot >= 0 ? c->maps + (size_t)(c->n_slots + slot) * c->H * c->W : nullptr;
     a.remap_mode = slot >= 0 ? c->slot_mode[slot] : 0;
     a.strip_fastest = 0;
+    a.skip_allow = -1; // single-image convenience path: no early-out
     a.spans = (slot >= 0 && c->spans) ? c->spans + (size_t)slot * tiling(c).n_strips * c->H : nullptr;
     a.thr_mul = ithresh + 1;
     Tiling tl = tiling(c);

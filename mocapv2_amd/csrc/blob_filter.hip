@@ -253,6 +253,32 @@ __device__ __forceinline__ uint32_t ldsr_combine(const LTaps& t, const LaneCols&
     return out & lc.bytemask;
 }
 
+// ---- dark-tile early-out ---------------------------------------------------------------------------------------
+// A thresholded pixel can only be 1 if its 5x5 box sum reaches thr_mul * taps.  Every undistorted pixel is at most
+// (sum of weight * tap + 512) >> 10 with weights summing to <= 1024, so with "bright" = source value >= 64:
+//     box sum  <=  taps * 63.5  +  (256 - 64) / 1024 * (total weight of the bright source pixels feeding the window)
+// and a source pixel's total weight over ALL output pixels is at most Wmax (measured on the table at set-up; 1024 for
+// the identity).  The taps of one 5x5 window span at most 9 source pixels in x and y (checked at set-up), i.e. they
+// lie inside some 2x2 block of 8x8-pixel cells of a fixed grid.  Hence: if no such block of the tile's source region
+// holds more than `allow` bright pixels (allow from the inequality above with the smallest tap count, computed on
+// the host), every threshold bit of the tile is 0, so is the majority, and the tile's mask rows are zero -- without
+// running the filter.  The scan below reads every source byte of the tile once (the algorithmic traffic).
+__device__ __forceinline__ uint32_t bright_count(uint32_t v)
+{ // number of bytes >= 64
+    return (uint32_t)__popc(((v | (v << 1)) & 0x80808080u));
+}
+// 2x2 block test at the end of a cell row; `cell` = this lane's cell count (0 for lanes without a cell), cells are
+// `stride` lanes apart.  Returns true if some block (this cell row + the previous one) exceeds `allow`.
+__device__ __forceinline__ bool block_exceeds(uint32_t cell, uint32_t& prev2, int stride, int lane, int allow)
+{
+    uint32_t right = (uint32_t)__shfl_down((int)cell, stride);
+    if (lane + stride > 63) right = 0;
+    uint32_t cur2 = cell + right;
+    bool hit = (int)(cur2 + prev2) > allow;
+    prev2 = cur2;
+    return __ballot(hit) != 0ull;
+}
+
 // number of in-image taps of a 5-wide window centred on v
 __device__ __forceinline__ int taps5(int v, int n)
 {
@@ -368,6 +394,94 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
     // their taps stay inside the image, their result is masked out)
     for (int k = 0; k < 4; k++) xq[k] = lc.addr_x + k;
     const int y0 = kfirst - 2;
+    if (a.skip_allow >= 0) {
+        // ---- dark-tile early-out (see the comment above bright_count) ----
+        const int allow = a.skip_allow;
+        const int last = (ke > kfirst ? ke : kfirst) + 2; // last source-image row of the filter's input this chunk consumes
+        bool bright = false;
+        uint32_t acc = 0, prev2 = 0;
+        if (REMAP) {
+            // source region of the tile from the span table: rows [smin, smax], columns [xs0, xs0 + 8 * nl)
+            const uint2* spans = a.spans + ((size_t)slot * a.n_strips + strip) * a.H;
+            int xmin = 0x7fff, xmax = 0, smin = 0x7fff, smax = 0;
+            const int ra = y0 < 0 ? 0 : y0, rb = last > Hm1 ? Hm1 : last;
+            for (int r = ra + lane; r <= rb; r += 64) {
+                uint2 sp = spans[r];
+                int lo = (int)(sp.y & 0xffffu), hi = (int)(sp.y >> 16), s0 = (int)(sp.x & 0xffffu), s1 = (int)(sp.x >> 16);
+                xmin = lo < xmin ? lo : xmin; xmax = hi > xmax ? hi : xmax;
+                smin = s0 < smin ? s0 : smin; smax = s1 > smax ? s1 : smax;
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                int o1 = __shfl_xor(xmin, d), o2 = __shfl_xor(xmax, d), o3 = __shfl_xor(smin, d), o4 = __shfl_xor(smax, d);
+                xmin = o1 < xmin ? o1 : xmin; xmax = o2 > xmax ? o2 : xmax;
+                smin = o3 < smin ? o3 : smin; smax = o4 > smax ? o4 : smax;
+            }
+            const int xs0 = __builtin_amdgcn_readfirstlane(xmin) & ~7;
+            const int nl = (__builtin_amdgcn_readfirstlane(xmax) - xs0 + 8) >> 3; // cell columns, one per lane
+            const int s_lo = __builtin_amdgcn_readfirstlane(smin), s_hi = __builtin_amdgcn_readfirstlane(smax);
+            if (nl > 64 || a.W < 8) bright = true; // region wider than one wave covers: no early-out
+            else {
+                const int c = xs0 + 8 * lane, cc = c < a.W - 8 ? c : a.W - 8;
+                const uint32_t sh = (uint32_t)(8 * (c - cc) > 63 ? 63 : 8 * (c - cc));
+                for (int rbase = s_lo & ~7; rbase <= s_hi && !bright; rbase += 8) { // one cell row = 8 source rows
+                    uint2 v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        int r = rbase + j;
+                        r = r < s_lo ? s_lo : (r > s_hi ? s_hi : r); // clamped duplicates are masked below
+                        __builtin_memcpy(&v[j], img + ((uint32_t)r * (uint32_t)a.pitch + (uint32_t)cc), 8);
+                    }
+                    acc = 0;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        int r = rbase + j;
+                        uint64_t vv = (((uint64_t)v[j].y << 32) | v[j].x) >> sh;
+                        uint32_t cnt = bright_count((uint32_t)vv) + bright_count((uint32_t)(vv >> 32));
+                        if (r >= s_lo && r <= s_hi) acc += cnt; // wave-uniform condition
+                    }
+                    if (lane >= nl) acc = 0;
+                    bright = block_exceeds(acc, prev2, 1, lane, allow);
+                }
+            }
+        } else {
+            // the plain path's source region is the tile's own input: rows [y0, last] (in the image), columns of the strip
+            const int s_lo = y0 < 0 ? 0 : y0, s_hi = last > Hm1 ? Hm1 : last;
+            if (TINY) bright = true;
+            for (int rbase = s_lo & ~7; rbase <= s_hi && !bright; rbase += 8) {
+                uint32_t v[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    int r = rbase + j;
+                    r = r < s_lo ? s_lo : (r > s_hi ? s_hi : r);
+                    v[j] = fetch_src4<false, TINY>(a, img, map, r, xl, lc);
+                }
+                acc = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    int r = rbase + j;
+                    uint32_t cnt = bright_count(finish_src4<false, TINY>(v[j], true, lc));
+                    if (r >= s_lo && r <= s_hi) acc += cnt;
+                }
+                // a cell (8 columns) = a lane pair; xbase is a multiple of 8, so pairs (2m, 2m+1) are grid-aligned
+                uint32_t cell = acc + (uint32_t)__shfl_xor((int)acc, 1);
+                bright = block_exceeds(cell, prev2, 2, lane, allow);
+            }
+        }
+        if (!bright) {
+            // all-zero tile: write the zero mask bytes (two rows per wave instruction) and an empty occupancy word
+            const int half = lane >> 5, pair = lane & 31, byte0 = strip * 30 + 2 * pair, nb = (a.W + 7) >> 3;
+            if (pair < 15 && byte0 < nb) {
+                for (int i = half; i < r1 - r0; i += 2) {
+                    uint8_t* dst = mrow_base + (size_t)(r0 + i) * row_bytes + byte0;
+                    if (byte0 + 1 < nb) *(uint16_t*)dst = 0; // byte0 is even: aligned
+                    else *dst = 0;
+                }
+            }
+            if (lane == 0) a.cells[((size_t)image * a.n_cgroups * 4 + (cgroup * 4 + wv)) * a.n_strips + strip] = 0u;
+            return;
+        }
+    }
     TabSlot tabs[4];
     RowReq rq[4];
     LTaps tb[2];
@@ -762,7 +876,48 @@ __global__ void remap_spans_kernel(SpanArgs a)
     a.spans[(size_t)strip * a.H + y] = make_uint2((uint32_t)smin | ((uint32_t)smax << 16), (uint32_t)xmin | ((uint32_t)xmax << 16));
 }
 
+// total blend weight every source pixel carries over all output pixels (scatter), for the dark-tile bound
+__global__ void remap_weight_scatter_kernel(StatArgs a)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= a.W || y >= a.H) return;
+    uint32_t m = a.map[(size_t)y * a.W + x], w = a.mapw[(size_t)y * a.W + x];
+    int sx = x + (int)(int16_t)(m & 0xffffu), sy = y + ((int)m >> 16);
+    uint32_t wx0 = w & 0xffu, wx1 = (w >> 8) & 0xffu, wy1 = (w >> 16) & 0xffu, wy0 = w >> 24;
+    uint32_t* p = a.acc + (size_t)sy * a.W + sx;
+    if (wx0 * wy0) atomicAdd(p, wx0 * wy0);
+    if (wx1 * wy0) atomicAdd(p + 1, wx1 * wy0);
+    if (wx0 * wy1) atomicAdd(p + a.W, wx0 * wy1);
+    if (wx1 * wy1) atomicAdd(p + a.W + 1, wx1 * wy1);
+}
+__global__ void remap_stats_kernel(StatArgs a)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= a.W || y >= a.H) return;
+    atomicMax(&a.stats[0], a.acc[(size_t)y * a.W + x]);
+    int x0 = 0x7fff, x1 = -1, y0 = 0x7fff, y1 = -1; // extent of the nonzero-weight taps of the 5x5 window around (x,y)
+    for (int dy = -2; dy <= 2; dy++)
+        for (int dx = -2; dx <= 2; dx++) {
+            int xx = x + dx, yy = y + dy;
+            if ((unsigned)xx >= (unsigned)a.W || (unsigned)yy >= (unsigned)a.H) continue;
+            uint32_t m = a.map[(size_t)yy * a.W + xx], w = a.mapw[(size_t)yy * a.W + xx];
+            int sx = xx + (int)(int16_t)(m & 0xffffu), sy = yy + ((int)m >> 16);
+            bool c0 = (w & 0xffu) != 0, c1 = ((w >> 8) & 0xffu) != 0, r1 = ((w >> 16) & 0xffu) != 0, r0 = (w >> 24) != 0;
+            if ((c0 || c1) && (r0 || r1)) {
+                int lo = c0 ? sx : sx + 1, hi = c1 ? sx + 1 : sx, lo2 = r0 ? sy : sy + 1, hi2 = r1 ? sy + 1 : sy;
+                x0 = lo < x0 ? lo : x0; x1 = hi > x1 ? hi : x1; y0 = lo2 < y0 ? lo2 : y0; y1 = hi2 > y1 ? hi2 : y1;
+            }
+        }
+    if (x1 >= x0) { atomicMax(&a.stats[1], (uint32_t)(x1 - x0 + 1)); atomicMax(&a.stats[2], (uint32_t)(y1 - y0 + 1)); }
+}
+
 // ---- launchers -------------------------------------------------------------------------------------------------
+static inline dim3 grid2d(int W, int H) { return dim3((W + 63) / 64, (H + 3) / 4); }
+void launch_remap_stats(const StatArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(remap_weight_scatter_kernel, grid2d(a.W, a.H), dim3(64, 4), 0, s, a);
+    hipLaunchKernelGGL(remap_stats_kernel, grid2d(a.W, a.H), dim3(64, 4), 0, s, a);
+}
 void launch_remap_spans(const SpanArgs& a, hipStream_t s)
 {
     hipLaunchKernelGGL(remap_spans_kernel, dim3((a.H + 63) / 64, a.n_strips), dim3(64), 0, s, a);
@@ -793,7 +948,6 @@ void launch_undistort_map(const MapArgs& m, hipStream_t s)
 {
     hipLaunchKernelGGL(undistort_map_kernel, dim3((m.H + 63) / 64), dim3(64), 0, s, m);
 }
-static inline dim3 grid2d(int W, int H) { return dim3((W + 63) / 64, (H + 3) / 4); }
 void launch_box_blur(const uint8_t* src, uint8_t* dst, int H, int W, int sp, int dp, int ksize, hipStream_t s)
 {
     hipLaunchKernelGGL(box_blur_kernel, grid2d(W, H), dim3(64, 4), 0, s, src, dst, H, W, sp, dp, ksize);

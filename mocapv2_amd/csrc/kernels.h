@@ -19,6 +19,8 @@ struct FilterArgs {
     const uint2* spans;   //   per (slot, strip, row): x = smin | smax<<16, y = xmin | xmax<<16 (source rows / columns the
                           //   strip's pixels of that row read); used by the LDS-staged remap variant
     int remap_mode;       // 0 plain / 2 per-pixel gather, 3 pipelined gather, 4 LDS-staged
+    int skip_allow;       // dark-tile early-out: a tile whose source region has no 16x16 block (2x2 cells of 8x8 px)
+                          //   with more than this many pixels >= 64 provably yields an all-zero mask; -1 = off
     int strip_fastest;    // block order: 1 = neighbouring strips share an XCD in time, 0 = time steps of a tile do
     int cam_mod;          // undistort slot of image n = n % cam_mod (map already points at the first slot)
     int n_images, n_steps; // n_steps = ceil(n_images / cam_mod)
@@ -69,6 +71,11 @@ enum { BLOB_ERR_CANDIDATES = -2, BLOB_ERR_CONTOURS = -3, BLOB_ERR_STEPS = -4, BL
 
 void launch_filter_mask(const FilterArgs& a, bool remap, hipStream_t s);
 struct SpanArgs { const uint32_t* map; uint2* spans; int H, W, n_strips; };
+// set-up statistics of an undistort table, for the dark-tile bound: stats[0] = largest total blend weight any source
+// pixel carries over all output pixels (1024 = one full pixel), stats[1] / stats[2] = largest x / y extent (in source
+// pixels) of the taps feeding one 5x5 output window.  acc: H*W zero-initialised scratch words.
+struct StatArgs { const uint32_t* map; const uint32_t* mapw; uint32_t* acc; uint32_t* stats; int H, W; };
+void launch_remap_stats(const StatArgs& a, hipStream_t s);
 void launch_remap_spans(const SpanArgs& a, hipStream_t s);
 constexpr int RING_H = 32, RING_W = 288, RING_LOOKAHEAD = 5; // LDS source-row ring of the staged remap (per wave)
 void launch_undistort_map(const MapArgs& m, hipStream_t s);

@@ -182,3 +182,50 @@ def test_find_dot_synthetic_frames(torch_cuda, dist):
         assert xy[i, :cnt[i]].tolist() == exp
         total += len(exp)
     assert total >= 40  # the scene really contains detectable markers
+
+
+def dark_frames(rng, n, H, W, n_discs, salt, noise_max=60):
+    """IR-like frames: dark noise, sparse salt pixels, a few saturated discs -- most tiles are provably all-zero,
+    so the dark-tile early-out decides most of the mask."""
+    img = rng.integers(0, noise_max + 1, (n, H, W), dtype=np.uint8)
+    yy, xx = np.mgrid[0:H, 0:W]
+    for i in range(n):
+        k = int(salt * H * W)
+        img[i, rng.integers(0, H, k), rng.integers(0, W, k)] = 255
+        for _ in range(n_discs):
+            cx, cy, r = rng.uniform(0, W), rng.uniform(0, H), rng.uniform(6, 24)
+            d = np.sqrt((xx - cx) ** 2 + (yy - cy) ** 2)
+            img[i] = np.maximum(img[i], (np.clip((r + 0.75 - d) / 1.5, 0, 1) * 255).astype(np.uint8))
+    return img
+
+
+@pytest.mark.parametrize("scale", [0.0, 1.0, -3.0])
+@pytest.mark.parametrize("salt,noise_max", [(0.0, 60), (0.001, 60), (0.02, 60), (0.001, 140), (0.3, 60)])
+def test_dark_tile_early_out_is_exact(torch_cuda, monkeypatch, scale, salt, noise_max):
+    """With and without the early-out the mask equals the oracle's, for dark frames with sparse / dense salt noise,
+    brighter backgrounds (the bound then rarely proves anything) and clusters of bright pixels right at the allowance."""
+    from gpu_util import unpack_mask
+    torch = torch_cuda
+    W, H = 960, 540
+    rng = np.random.default_rng(int(1000 * salt) + noise_max + int(10 * scale) + 7)
+    frames = dark_frames(rng, 3, H, W, n_discs=5, salt=salt, noise_max=noise_max)
+    # adversarial clusters: k saturated pixels packed into one cell block, k around the allowance (5..8), far from discs
+    for i, k in enumerate([4, 6, 8, 12, 20]):
+        y0, x0 = 40 + 90 * i, 30 + 7 * i
+        pts = [(y0 + a, x0 + b) for a in range(5) for b in range(5)][:k]
+        for (yy, xx) in pts:
+            frames[0, yy, xx] = 255
+    frames[1, :3, :] = 255      # saturated top rows (border taps counts)
+    frames[2, :, W - 2:] = 255  # saturated right columns
+    dist = np.array(MILD_DIST) * scale
+    exp = None
+    for skip in ["1", "0"]:
+        monkeypatch.setenv("MOCAP_SKIP_DARK", skip)
+        ctx, K, ident = make_ctx(W, H, dist=dist)
+        got, pad = unpack_mask(ctx.filter_mask(torch.from_numpy(frames).cuda()), W)
+        assert not pad.any()
+        if exp is None:
+            exp = [oracle.image_filter(frames[i] if ident else oracle.undistort(frames[i], K, dist), 0) != 0 for i in range(3)]
+        for i in range(3):
+            assert np.array_equal(got[i], exp[i]), (skip, i, np.argwhere(got[i] != exp[i])[:4])
+    assert exp[0].any()
