@@ -104,15 +104,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(dist_name):
-        """Build the scene / tracker / resident batch for one distortion variant and time K steps of it."""
-        scene = Scene(N_CAM, WIDTH, HEIGHT, dist=MILD_DIST if dist_name == "mild" else ZERO_DIST)
-        arrays = scene_arrays(scene)
-        tracker = BatchTracker(*arrays, WIDTH, HEIGHT, T_STEPS, world=world, rank=rank, device=local_rank)
-        images = tracker.local_image_list()
-        frames_host = render_local(scene, images)
-        frames = torch.from_numpy(frames_host).cuda()
-        torch.cuda.synchronize()
+    def timed(tracker, frames):
+        """W untimed + K timed steps of the resident batch, barrier + synchronize on both sides, max over ranks."""
         for _ in range(args.warmup):
             tracker.step(frames)
         barrier()
@@ -124,13 +117,26 @@ def main():
         elapsed = time.perf_counter() - t0
         tracker.ctx.profile(False)
         prof = tracker.ctx.profile_read()
+        prof["tiles"], prof["tiles_skipped"] = tracker.ctx.tile_stats()  # of the last step
         if world > 1:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
-        return scene, arrays, tracker, images, frames_host, out, elapsed, prof
+        return out, elapsed, prof
 
-    scene, arrays, tracker, images, frames_host, out, elapsed, prof = measure(args.dist)
+    def measure(dist_name):
+        """Build the scene / tracker / resident batch for one distortion variant and time K steps of it."""
+        scene = Scene(N_CAM, WIDTH, HEIGHT, dist=MILD_DIST if dist_name == "mild" else ZERO_DIST)
+        arrays = scene_arrays(scene)
+        tracker = BatchTracker(*arrays, WIDTH, HEIGHT, T_STEPS, world=world, rank=rank, device=local_rank)
+        images = tracker.local_image_list()
+        frames_host = render_local(scene, images)
+        frames = torch.from_numpy(frames_host).cuda()
+        torch.cuda.synchronize()
+        out, elapsed, prof = timed(tracker, frames)
+        return scene, arrays, tracker, images, frames_host, out, elapsed, prof, frames
+
+    scene, arrays, tracker, images, frames_host, out, elapsed, prof, frames = measure(args.dist)
 
     n_roots = out["n"].cpu().numpy()
     status_ok = bool((n_roots >= 0).all()) and bool((tracker.records[:, 0] >= 0).all().item())
@@ -172,10 +178,25 @@ def main():
                                    "correspond": round(prof["corr_ms"] / args.steps, 4)},
             "status_ok": status_ok,
             "points_per_frame": float(n_roots.mean()),
+            "dark_tile_early_out": {"tiles_per_step": prof["tiles"], "tiles_resolved_without_filtering": prof["tiles_skipped"],
+                                    "note": "exact: a (240 col x 135 row) tile whose pixels provably cannot set a mask bit is "
+                                            "answered after one read of its pixels (DESIGN.md 4.1); disabled run below"},
         }
         if world == 1 and args.secondary:
+            ref_out = {k: v.clone() for k, v in out.items()}  # the tracker reuses its output buffers
+            ref_rec = tracker.records.clone()
+            os.environ["MOCAP_SKIP_DARK"] = "0"  # same batch, early-out off: every tile runs the full filter
+            out_d, el_d, prof_d = timed(tracker, frames)
+            del os.environ["MOCAP_SKIP_DARK"]
+            ach_d, ms_d, _ = roofline_of(prof_d, len(images), 1)
+            line["without_early_out"] = {"value": round(T_STEPS * args.steps / el_d, 2), "unit": "frames/s",
+                                         "ms_per_step": round(1e3 * el_d / args.steps, 4),
+                                         "filter_avg_launch_ms": round(ms_d, 4), "roofline_frac": round(ach_d / HBM_PEAK_GBS, 4),
+                                         "same_results": bool(torch.equal(tracker.records, ref_rec) and torch.equal(out_d["n"], ref_out["n"])
+                                                              and torch.equal(out_d["xyz"], ref_out["xyz"]))}
+        if world == 1 and args.secondary:
             other = "zero" if args.dist == "mild" else "mild"
-            _, _, tr2, im2, _, out2, el2, prof2 = measure(other)
+            _, _, tr2, im2, _, out2, el2, prof2, fr2 = measure(other)
             ach2, ms2, ipl2 = roofline_of(prof2, len(im2), 1)
             line["other_distortion_variant"] = {
                 "distortion": other, "value": round(T_STEPS * args.steps / el2, 2), "unit": "frames/s",
@@ -187,9 +208,10 @@ def main():
                                        "contours": round(prof2["contour_ms"] / args.steps, 4),
                                        "correspond": round(prof2["corr_ms"] / args.steps, 4)},
                 "status_ok": bool((out2["n"].cpu().numpy() >= 0).all()),
+                "dark_tile_early_out": {"tiles_per_step": prof2["tiles"], "tiles_resolved_without_filtering": prof2["tiles_skipped"]},
                 "note": "same workload with zero lens distortion: cv.undistort is then the identity map and the "
                         "kernel streams the frame without the remap gather (SURVEY.md section 8d lists both variants)"}
-            del tr2
+            del tr2, fr2
         if world == 1 and args.cpu_steps > 0:
             fps, dt, n_pts, last = cpu_baseline(scene, arrays, frames_host.reshape(T_STEPS, N_CAM, HEIGHT, WIDTH), args.cpu_steps)
             line["cpu_baseline"] = {"value": round(fps, 3), "unit": "frames/s", "cores": N_CAM, "kind": "port",

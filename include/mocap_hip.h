@@ -147,6 +147,11 @@ MOCAP_API int mocap_reproject_batch(mocap_ctx_t ctx, const double* pts_dev, cons
 
 /* HIP-event timing of the kernels launched by mocap_blob_centroids / mocap_filter_mask on their stream.
  * mocap_profile_read synchronises, returns accumulated milliseconds and launch counts, and resets. */
+/* Dark-tile early-out of the filter kernel (a tile whose source pixels provably cannot produce a set mask bit is
+ * answered with zeros after one read of its pixels; results are identical either way; MOCAP_SKIP_DARK=0 disables it):
+ * number of (strip, chunk) tiles of the most recent mocap_blob_centroids batch and how many of them were resolved
+ * that way.  Synchronises the device. */
+MOCAP_API int mocap_tile_stats(mocap_ctx_t ctx, uint64_t* tiles, uint64_t* skipped);
 MOCAP_API int mocap_profile_enable(mocap_ctx_t ctx, int on);
 MOCAP_API int mocap_profile_read(mocap_ctx_t ctx, double* filter_ms, int* filter_launches, double* contour_ms,
                        int* contour_launches, double* corr_ms, int* corr_launches);

@@ -42,13 +42,14 @@ struct mocap_ctx {
     int device, W, H, n_slots, wpr;
     mocap_blob_params prm;
     uint32_t* maps;           // [2][n_slots][H][W]: tap positions, then blend weights
-    uint32_t* map_flags;      // [n_slots] device, followed by 256 trash bytes
+    uint32_t* map_flags;      // [n_slots] device, followed by the two early-out tile counters
     std::vector<int> slot_state; // 0 unset, 1 identity, 2 remap
     std::vector<uint32_t> slot_wmax; // largest total blend weight of a source pixel (1024 = identity); 0 = early-out not provable
     std::vector<int> slot_mode;  // remap kernel variant the slot's table admits: 2 per-pixel, 3 pipelined gather, 4 LDS-staged
     uint2* spans;             // [n_slots][n_strips][H] source row / column spans per strip row
     uint32_t* mask; size_t mask_images;
     uint32_t* cells; size_t cells_images; // occupancy cells written by the filter kernel for c->mask
+    int last_images;                       // images of the most recent batch that wrote c->cells
     CameraTable* cams; int n_cam, n_F;
     double* scratch; size_t scratch_elems;
     bool profiling;
@@ -68,6 +69,8 @@ static Tiling tiling(const mocap_ctx* c)
     t.n_strips = (c->W + 239) / 240;
     return t;
 }
+
+static size_t cells_per_image(const mocap_ctx* c) { Tiling t = tiling(c); return (size_t)t.n_cgroups * 4 * t.n_strips; }
 
 // Can the LDS-staged remap kernel serve this slot?  Replays, per (strip, chunk), the kernel's ring schedule on the
 // span table: ring width, rows resident when they are read, at most two new rows per step.
@@ -127,13 +130,13 @@ int mocap_ctx_create(int device_id, int width, int height, int n_slots, mocap_ct
     mocap_ctx* c = new mocap_ctx();
     c->device = device_id; c->W = width; c->H = height; c->n_slots = n_slots; c->wpr = (width + 31) / 32;
     c->prm = mocap_blob_params{5, 5, 255 * 0.85, 500.0, 0.5};
-    c->maps = nullptr; c->spans = nullptr; c->map_flags = nullptr; c->mask = nullptr; c->mask_images = 0; c->cells = nullptr; c->cells_images = 0;
+    c->maps = nullptr; c->spans = nullptr; c->map_flags = nullptr; c->mask = nullptr; c->mask_images = 0; c->cells = nullptr; c->cells_images = 0; c->last_images = 0;
     c->cams = nullptr; c->n_cam = 0; c->n_F = 0; c->scratch = nullptr; c->scratch_elems = 0; c->profiling = false;
     c->slot_state.assign(n_slots, 0);
     c->slot_mode.assign(n_slots, 2);
     c->slot_wmax.assign(n_slots, 0);
     hipError_t e = hipMalloc(&c->map_flags, sizeof(uint32_t) * n_slots + 256);
-    if (e == hipSuccess) e = hipMemset(c->map_flags, 0, sizeof(uint32_t) * n_slots);
+    if (e == hipSuccess) e = hipMemset(c->map_flags, 0, sizeof(uint32_t) * n_slots + 256);
     if (e == hipSuccess) e = hipMalloc(&c->cams, sizeof(CameraTable));
     if (e == hipSuccess) e = hipMemset(c->cams, 0, sizeof(CameraTable));
     if (e != hipSuccess) {
@@ -301,6 +304,26 @@ int mocap_profile_read(mocap_ctx_t c, double* fms, int* fn, double* cms, int* cn
     return MOCAP_OK;
 }
 
+int mocap_tile_stats(mocap_ctx_t c, uint64_t* tiles, uint64_t* skipped)
+{
+    if (!c) return fail(MOCAP_E_INVALID, "null context");
+    if (set_device(c)) return MOCAP_E_HIP;
+    uint64_t total = 0, full = 0;
+    if (c->cells && c->last_images > 0) {
+        HIP_TRY(hipDeviceSynchronize());
+        Tiling t = tiling(c);
+        size_t per = cells_per_image(c), n = per * (size_t)c->last_images;
+        std::vector<uint32_t> w(n);
+        HIP_TRY(hipMemcpy(w.data(), c->cells, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+        int valid_chunks = (c->H + t.rows - 1) / t.rows; // chunks that start inside the image
+        total = (uint64_t)c->last_images * valid_chunks * t.n_strips;
+        for (size_t i = 0; i < n; i++) full += w[i] >> 31;
+    }
+    if (tiles) *tiles = total;
+    if (skipped) *skipped = total - full;
+    return MOCAP_OK;
+}
+
 // ---- blob stage ------------------------------------------------------------------------------------------------
 static int check_frames(mocap_ctx* c, const void* frames, int n_images, int cam_mod, int slot_base, size_t image_stride, int pitch)
 {
@@ -315,7 +338,6 @@ static int check_frames(mocap_ctx* c, const void* frames, int n_images, int cam_
     return 0;
 }
 
-static size_t cells_per_image(const mocap_ctx* c) { Tiling t = tiling(c); return (size_t)t.n_cgroups * 4 * t.n_strips; }
 
 static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mod, int slot_base, size_t image_stride,
                       int pitch, uint32_t* mask, uint32_t* cells, hipStream_t s)
@@ -363,6 +385,7 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
         { const char* e = getenv("MOCAP_SKIP_DARK"); if (e && atoi(e) == 0) allow = -1; }
         a.skip_allow = allow;
     }
+    if (cells == c->cells) c->last_images = n_images;
     // time-fastest order by default: measured 4 % faster on the plain variant than strip-fastest, which in turn
     // fetches 28 % fewer HBM bytes (profiles/README.md).  MOCAP_STRIP_ORDER=1 selects strip-fastest.
     a.strip_fastest = 0;
@@ -402,7 +425,7 @@ static int ensure_mask(mocap_ctx* c, int n_images)
     if ((size_t)n_images <= c->mask_images) return 0;
     std::lock_guard<std::mutex> lk(c->mu);
     if ((size_t)n_images <= c->mask_images) return 0;
-    if (c->mask) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c->mask)); c->mask = nullptr; c->mask_images = 0; c->cells = nullptr; c->cells_images = 0; }
+    if (c->mask) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c->mask)); c->mask = nullptr; c->mask_images = 0; c->cells = nullptr; c->cells_images = 0; c->last_images = 0; }
     size_t bytes = sizeof(uint32_t) * (size_t)n_images * c->H * c->wpr;
     HIP_TRY(hipMalloc(&c->mask, bytes));
     HIP_TRY(hipMemset(c->mask, 0, bytes));

@@ -700,7 +700,8 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
         const int groups = (r1 - r0 + 7) >> 3;
         for (int g = 0; g < groups; g++)
             if (__ballot(out_lane && ((lacc >> g) & 1u)) != 0ull) cellmask |= 1u << g;
-        if (lane == 0) a.cells[((size_t)image * a.n_cgroups * 4 + (cgroup * 4 + wv)) * a.n_strips + strip] = cellmask;
+        // bit 31 marks a tile that went through the full filter (the early-out writes 0); bits 0..16 are the groups
+        if (lane == 0) a.cells[((size_t)image * a.n_cgroups * 4 + (cgroup * 4 + wv)) * a.n_strips + strip] = cellmask | 0x80000000u;
     }
 }
 

@@ -12,7 +12,7 @@ struct FilterArgs {
     int aligned4;         // src base, pitch and image_stride are multiples of 4
     uint32_t* mask;       // [n_images][H][words_per_row], bit b of word k = pixel 32k+b
     int words_per_row;
-    uint32_t* cells;      // [n_images][n_cgroups*4][n_strips]: bit g = rows 8g..8g+7 of the chunk have set pixels in the strip
+    uint32_t* cells;      // [n_images][n_cgroups*4][n_strips]: bit g = rows 8g..8g+7 of the chunk have set pixels in the strip; bit 31 = tile ran the full filter
     // undistort tables of the first slot used (remap variant only), each [cam_mod][H][W]:
     const uint32_t* map;  //   tap position: (sx - x) | (sy - y) << 16, the 2x2 tap window clamped into the image
     const uint32_t* mapw; //   blend weights 32*(wx0 | wx1<<8 | wy1<<16 | wy0<<24)/32, taps outside the image weigh 0

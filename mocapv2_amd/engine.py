@@ -251,6 +251,12 @@ class MocapContext:
         return mse.cpu().numpy(), ok.cpu().numpy()
 
     # ---- profiling -----------------------------------------------------------------------------------------------
+    def tile_stats(self):
+        """(tiles, tiles resolved by the dark-tile early-out) of the most recent blob_centroids batch"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        _abi.check(self.lib.mocap_tile_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def profile(self, on=True):
         _abi.check(self.lib.mocap_profile_enable(self._h, int(on)))
 
