@@ -179,7 +179,7 @@ def main():
             "status_ok": status_ok,
             "points_per_frame": float(n_roots.mean()),
             "dark_tile_early_out": {"tiles_per_step": prof["tiles"], "tiles_resolved_without_filtering": prof["tiles_skipped"],
-                                    "note": "exact: a (240 col x 135 row) tile whose pixels provably cannot set a mask bit is "
+                                    "note": "exact: a (240 col x 68 row) tile whose pixels provably cannot set a mask bit is "
                                             "answered after one read of its pixels (DESIGN.md 4.1); disabled run below"},
         }
         if world == 1 and args.secondary:

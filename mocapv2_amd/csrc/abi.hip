@@ -63,7 +63,11 @@ struct Tiling { int rows, n_cgroups, n_strips; };
 static Tiling tiling(const mocap_ctx* c)
 {
     Tiling t;
-    t.rows = 135; // <= 136 so that a chunk's 8-row groups fit one 32-bit occupancy word
+    // Rows per wave.  Must be <= 136 so that a chunk's 8-row groups fit one 32-bit occupancy word.  68 (x4 waves = 272
+    // rows per workgroup) measured best with the dark-tile early-out: finer tiles skip more of a sparse IR frame
+    // (135 -> 68 rows: 0.506 -> 0.458 ms per 384 images); dense frames pay 8 halo rows per 68 instead of per 135.
+    t.rows = 68;
+    { const char* e = getenv("MOCAP_ROWS"); if (e && atoi(e) >= 16 && atoi(e) <= 136) t.rows = atoi(e); } // A/B switch
     if (c->H < 4 * 32) t.rows = (c->H + 3) / 4 > 8 ? (c->H + 3) / 4 : 8;
     t.n_cgroups = (c->H + 4 * t.rows - 1) / (4 * t.rows);
     t.n_strips = (c->W + 239) / 240;
@@ -386,9 +390,12 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
         a.skip_allow = allow;
     }
     if (cells == c->cells) c->last_images = n_images;
-    // time-fastest order by default: measured 4 % faster on the plain variant than strip-fastest, which in turn
-    // fetches 28 % fewer HBM bytes (profiles/README.md).  MOCAP_STRIP_ORDER=1 selects strip-fastest.
-    a.strip_fastest = 0;
+    // Block order.  Remapped cameras: time-fastest, so that concurrently resident blocks work on the same tile of
+    // the same camera at different times and share its map words in L2 (8 B of tables per pixel against 1 B of
+    // image).  Plain cameras with the early-out: strip-fastest, neighbouring tiles of one image run together and the
+    // halo lines they share are fetched once (measured 0.264 -> 0.219 ms per 384 images; 0.457 -> 0.489 ms if used
+    // for the remapped variant).  MOCAP_STRIP_ORDER=0/1 overrides.
+    a.strip_fastest = (!remap && a.skip_allow >= 0) ? 1 : 0;
     { const char* e = getenv("MOCAP_STRIP_ORDER"); if (e) a.strip_fastest = atoi(e) != 0; }
     a.spans = c->spans ? c->spans + (size_t)slot_base * tiling(c).n_strips * c->H : nullptr;
     EvPair p; bool on;
