@@ -73,15 +73,19 @@ def cpu_baseline(scene, arrays, frames, n_steps):
 
 
 def main():
+    global T_STEPS
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dist", choices=["mild", "zero"], default="mild")
+    ap.add_argument("--time-steps", type=int, default=T_STEPS,
+                    help="time steps per batch and GPU (one step = one pass over time_steps x 6 resident images)")
     ap.add_argument("--cpu-steps", type=int, default=256, help="time steps in the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-secondary", dest="secondary", action="store_false",
                     help="skip the second timed run with the other distortion variant")
     args = ap.parse_args()
+    T_STEPS = args.time_steps
 
     import torch
     import torch.distributed as dist
@@ -144,21 +148,45 @@ def main():
     if rank == 0:
         frames_per_step = T_STEPS * world
         value = frames_per_step * args.steps / elapsed
-        def roofline_of(prof, n_images, n_launch_groups):
-            launches = max(1, prof["filter_launches"])
-            per_launch = n_images / n_launch_groups
-            ms = prof["filter_ms"] / launches
-            ach = WIDTH * HEIGHT * per_launch / (ms * 1e-3) / 1e9
-            return ach, ms, per_launch
+        KERNELS = (("scan", "bright_cells_kernel"), ("filter", "filter_mask_kernel"))
 
-        achieved, filt_ms, images_per_launch = roofline_of(prof, len(images), 1 if world == 1 else len(tracker.segs))
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "filter_traffic.json")
-        if os.path.exists(tpath):  # HBM bytes per launch from the PMC pass (profiles/README.md), same workload
-            with open(tpath) as f:
-                tj = json.load(f)
-            if tj.get("dist") == args.dist and tj.get("images_per_launch") == images_per_launch:
-                traffic = tj.get("hbm_bytes_per_launch")
+        def roofline_of(prof, n_images, n_launch_groups, dist_name):
+            """Roofline entries of the two HBM-bound kernels of the filter stage (HIP-event averages over the timed
+            region, recorded by the library on the launch stream); the one with the longer launches leads."""
+            per_launch = n_images / n_launch_groups
+            traffic = {}
+            tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+            if os.path.exists(tpath):  # HBM bytes per launch from the PMC passes (profiles/README.md), same workload
+                with open(tpath) as f:
+                    tj = json.load(f)
+                if tj.get("dist") == dist_name and tj.get("images_per_launch") == per_launch:
+                    traffic = tj.get("hbm_bytes_per_launch", {})
+            ent = {}
+            for key, name in KERNELS:
+                n = prof[key + "_launches"]
+                if n == 0:
+                    continue
+                ms = prof[key + "_ms"] / n
+                ach = WIDTH * HEIGHT * per_launch / (ms * 1e-3) / 1e9
+                ent[name] = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic.get(name),
+                             "avg_launch_ms": round(ms, 4), "images_per_launch": per_launch,
+                             "algorithmic_bytes_per_image": WIDTH * HEIGHT}
+            lead = max(ent, key=lambda k: ent[k]["avg_launch_ms"])
+            roof = dict(ent[lead])
+            both_ms = sum(e["avg_launch_ms"] for e in ent.values())
+            roof["other_kernels"] = {k: v for k, v in ent.items() if k != lead}
+            roof["filter_stage"] = {"kernels": list(ent), "ms_per_launch_group": round(both_ms, 4),
+                                    "achieved": round(WIDTH * HEIGHT * per_launch / (both_ms * 1e-3) / 1e9, 1),
+                                    "frac": round(WIDTH * HEIGHT * per_launch / (both_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            return roof
+
+        def kernel_ms(prof):
+            return {"scan": round(prof["scan_ms"] / args.steps, 4), "filter": round(prof["filter_ms"] / args.steps, 4),
+                    "contours": round(prof["contour_ms"] / args.steps, 4),
+                    "correspond": round(prof["corr_ms"] / args.steps, 4)}
+
+        roof = roofline_of(prof, len(images), 1 if world == 1 else len(tracker.segs), args.dist)
         line = {
             "metric": "frames/sec (6-cam 1080p)", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
@@ -169,18 +197,14 @@ def main():
                        "time_steps_per_step_per_gpu": T_STEPS, "distortion": args.dist,
                        "frames_resident_in_hbm": True,
                        "parallelism": "single launch, time-major" if world == 1 else f"camera-major blocks x{world} + 1 all-gather"},
-            "roofline": {"bound": "hbm", "kernel": "filter_mask_kernel", "achieved": round(achieved, 1),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "avg_launch_ms": round(filt_ms, 4), "images_per_launch": images_per_launch,
-                         "algorithmic_bytes_per_image": WIDTH * HEIGHT},
-            "kernel_ms_per_step": {"filter": round(prof["filter_ms"] / args.steps, 4),
-                                   "contours": round(prof["contour_ms"] / args.steps, 4),
-                                   "correspond": round(prof["corr_ms"] / args.steps, 4)},
+            "roofline": roof,
+            "kernel_ms_per_step": kernel_ms(prof),
             "status_ok": status_ok,
             "points_per_frame": float(n_roots.mean()),
             "dark_tile_early_out": {"tiles_per_step": prof["tiles"], "tiles_resolved_without_filtering": prof["tiles_skipped"],
-                                    "note": "exact: a (240 col x 68 row) tile whose pixels provably cannot set a mask bit is "
-                                            "answered after one read of its pixels (DESIGN.md 4.1); disabled run below"},
+                                    "note": "exact: bright_cells_kernel reads the frames once and counts pixels >= 64 per 8x8 cell; "
+                                            "a (240 col x 68 row) filter tile whose cells prove that no mask bit can be set is "
+                                            "answered with zeros (DESIGN.md 4.1); disabled run below"},
         }
         if world == 1 and args.secondary:
             ref_out = {k: v.clone() for k, v in out.items()}  # the tracker reuses its output buffers
@@ -188,25 +212,21 @@ def main():
             os.environ["MOCAP_SKIP_DARK"] = "0"  # same batch, early-out off: every tile runs the full filter
             out_d, el_d, prof_d = timed(tracker, frames)
             del os.environ["MOCAP_SKIP_DARK"]
-            ach_d, ms_d, _ = roofline_of(prof_d, len(images), 1)
+            roof_d = roofline_of(prof_d, len(images), 1, None)
             line["without_early_out"] = {"value": round(T_STEPS * args.steps / el_d, 2), "unit": "frames/s",
                                          "ms_per_step": round(1e3 * el_d / args.steps, 4),
-                                         "filter_avg_launch_ms": round(ms_d, 4), "roofline_frac": round(ach_d / HBM_PEAK_GBS, 4),
+                                         "filter_avg_launch_ms": roof_d["avg_launch_ms"], "roofline_frac": roof_d["frac"],
                                          "same_results": bool(torch.equal(tracker.records, ref_rec) and torch.equal(out_d["n"], ref_out["n"])
                                                               and torch.equal(out_d["xyz"], ref_out["xyz"]))}
         if world == 1 and args.secondary:
             other = "zero" if args.dist == "mild" else "mild"
             _, _, tr2, im2, _, out2, el2, prof2, fr2 = measure(other)
-            ach2, ms2, ipl2 = roofline_of(prof2, len(im2), 1)
+            roof2 = roofline_of(prof2, len(im2), 1, other)
             line["other_distortion_variant"] = {
                 "distortion": other, "value": round(T_STEPS * args.steps / el2, 2), "unit": "frames/s",
                 "ms_per_step": round(1e3 * el2 / args.steps, 4),
-                "roofline": {"bound": "hbm", "kernel": "filter_mask_kernel", "achieved": round(ach2, 1), "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": round(ach2 / HBM_PEAK_GBS, 4), "avg_launch_ms": round(ms2, 4),
-                             "images_per_launch": ipl2},
-                "kernel_ms_per_step": {"filter": round(prof2["filter_ms"] / args.steps, 4),
-                                       "contours": round(prof2["contour_ms"] / args.steps, 4),
-                                       "correspond": round(prof2["corr_ms"] / args.steps, 4)},
+                "roofline": roof2,
+                "kernel_ms_per_step": kernel_ms(prof2),
                 "status_ok": bool((out2["n"].cpu().numpy() >= 0).all()),
                 "dark_tile_early_out": {"tiles_per_step": prof2["tiles"], "tiles_resolved_without_filtering": prof2["tiles_skipped"]},
                 "note": "same workload with zero lens distortion: cv.undistort is then the identity map and the "

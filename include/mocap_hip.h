@@ -145,16 +145,17 @@ MOCAP_API int mocap_triangulate_batch(mocap_ctx_t ctx, const double* pts_dev, co
 MOCAP_API int mocap_reproject_batch(mocap_ctx_t ctx, const double* pts_dev, const uint8_t* valid_dev, const double* xyz_dev,
                           int N, int C, int compact_k, double* mse_dev, int32_t* ok_dev, void* stream);
 
-/* HIP-event timing of the kernels launched by mocap_blob_centroids / mocap_filter_mask on their stream.
- * mocap_profile_read synchronises, returns accumulated milliseconds and launch counts, and resets. */
-/* Dark-tile early-out of the filter kernel (a tile whose source pixels provably cannot produce a set mask bit is
- * answered with zeros after one read of its pixels; results are identical either way; MOCAP_SKIP_DARK=0 disables it):
- * number of (strip, chunk) tiles of the most recent mocap_blob_centroids batch and how many of them were resolved
- * that way.  Synchronises the device. */
+/* Dark-tile early-out of the filter stage: one streaming kernel counts the pixels >= 64 of every 8x8 cell of the
+ * frames; a filter tile whose source region provably cannot produce a set mask bit (bound in DESIGN.md 4.1) is then
+ * answered with zeros without reading its pixels again.  Results are identical either way; MOCAP_SKIP_DARK=0
+ * disables it.  mocap_tile_stats: number of (strip, chunk) tiles of the most recent batch and how many of them were
+ * resolved that way.  Synchronises the device. */
 MOCAP_API int mocap_tile_stats(mocap_ctx_t ctx, uint64_t* tiles, uint64_t* skipped);
+/* HIP-event timing of the kernels launched by mocap_blob_centroids / mocap_filter_mask / mocap_correspond, recorded
+ * on their stream.  mocap_profile_read synchronises, returns accumulated milliseconds and launch counts and resets:
+ * index 0 = filter_mask_kernel, 1 = contours_kernel, 2 = correspond_kernel, 3 = bright_cells_kernel. */
 MOCAP_API int mocap_profile_enable(mocap_ctx_t ctx, int on);
-MOCAP_API int mocap_profile_read(mocap_ctx_t ctx, double* filter_ms, int* filter_launches, double* contour_ms,
-                       int* contour_launches, double* corr_ms, int* corr_launches);
+MOCAP_API int mocap_profile_read(mocap_ctx_t ctx, double ms[4], int launches[4]);
 
 #ifdef __cplusplus
 }

@@ -51,7 +51,7 @@ SIGNATURES = {
     "mocap_reproject_batch": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "mocap_tile_stats": [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
     "mocap_profile_enable": [_vp, _i],
-    "mocap_profile_read": [_vp, _dp, _ip, _dp, _ip, _dp, _ip],
+    "mocap_profile_read": [_vp, _dp, _ip],
 }
 
 _lib = None

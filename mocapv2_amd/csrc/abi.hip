@@ -47,13 +47,15 @@ struct mocap_ctx {
     std::vector<uint32_t> slot_wmax; // largest total blend weight of a source pixel (1024 = identity); 0 = early-out not provable
     std::vector<int> slot_mode;  // remap kernel variant the slot's table admits: 2 per-pixel, 3 pipelined gather, 4 LDS-staged
     uint2* spans;             // [n_slots][n_strips][H] source row / column spans per strip row
+    int4* regions;            // [n_slots][n_cgroups*4][n_strips] source region of every filter tile (remap slots)
     uint32_t* mask; size_t mask_images;
     uint32_t* cells; size_t cells_images; // occupancy cells written by the filter kernel for c->mask
     int last_images;                       // images of the most recent batch that wrote c->cells
+    uint8_t* bright;                       // [mask_images][bright_rows][bright_pitch] bright-pixel counts per 8x8 cell
     CameraTable* cams; int n_cam, n_F;
     double* scratch; size_t scratch_elems;
     bool profiling;
-    std::vector<EvPair> ev[3];
+    std::vector<EvPair> ev[4];
     std::mutex mu;
 };
 
@@ -74,6 +76,8 @@ static Tiling tiling(const mocap_ctx* c)
     return t;
 }
 
+static int bright_rows(const mocap_ctx* c) { return (c->H + 7) / 8; }
+static int bright_pitch(const mocap_ctx* c) { return (((c->W + 7) / 8) + 63) & ~63; }
 static size_t cells_per_image(const mocap_ctx* c) { Tiling t = tiling(c); return (size_t)t.n_cgroups * 4 * t.n_strips; }
 
 // Can the LDS-staged remap kernel serve this slot?  Replays, per (strip, chunk), the kernel's ring schedule on the
@@ -134,7 +138,7 @@ int mocap_ctx_create(int device_id, int width, int height, int n_slots, mocap_ct
     mocap_ctx* c = new mocap_ctx();
     c->device = device_id; c->W = width; c->H = height; c->n_slots = n_slots; c->wpr = (width + 31) / 32;
     c->prm = mocap_blob_params{5, 5, 255 * 0.85, 500.0, 0.5};
-    c->maps = nullptr; c->spans = nullptr; c->map_flags = nullptr; c->mask = nullptr; c->mask_images = 0; c->cells = nullptr; c->cells_images = 0; c->last_images = 0;
+    c->maps = nullptr; c->spans = nullptr; c->regions = nullptr; c->map_flags = nullptr; c->mask = nullptr; c->mask_images = 0; c->cells = nullptr; c->cells_images = 0; c->last_images = 0; c->bright = nullptr;
     c->cams = nullptr; c->n_cam = 0; c->n_F = 0; c->scratch = nullptr; c->scratch_elems = 0; c->profiling = false;
     c->slot_state.assign(n_slots, 0);
     c->slot_mode.assign(n_slots, 2);
@@ -158,9 +162,11 @@ int mocap_ctx_destroy(mocap_ctx_t c)
     for (auto& v : c->ev) for (auto& p : v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (c->maps) (void)hipFree(c->maps);
     if (c->spans) (void)hipFree(c->spans);
+    if (c->regions) (void)hipFree(c->regions);
     if (c->map_flags) (void)hipFree(c->map_flags);
     if (c->mask) (void)hipFree(c->mask);
     if (c->cells) (void)hipFree(c->cells);
+    if (c->bright) (void)hipFree(c->bright);
     if (c->cams) (void)hipFree(c->cams);
     if (c->scratch) (void)hipFree(c->scratch);
     delete c;
@@ -217,6 +223,32 @@ int mocap_set_undistort(mocap_ctx_t c, int slot, const double K[9], const double
         HIP_TRY(hipGetLastError());
         std::vector<uint2> sp(nsp);
         HIP_TRY(hipMemcpy(sp.data(), sa.spans, sizeof(uint2) * nsp, hipMemcpyDeviceToHost));
+        {   // source region of every (chunk, strip) tile: the union of the spans of the rows the tile consumes
+            const int H = c->H, Hm1 = H - 1, nch = tl.n_cgroups * 4;
+            std::vector<int4> rg((size_t)nch * tl.n_strips);
+            for (int ch = 0; ch < nch; ch++)
+                for (int st = 0; st < tl.n_strips; st++) {
+                    int4 r = make_int4(0, -1, 0, -1); // empty: chunks that start below the image
+                    int r0 = ch * tl.rows;
+                    if (r0 < H) {
+                        int r1 = r0 + tl.rows < H ? r0 + tl.rows : H;
+                        int kfirst = r0 - 2 < 0 ? 0 : (r0 - 2 > Hm1 ? Hm1 : r0 - 2), ke = r1 + 1 < Hm1 ? r1 + 1 : Hm1;
+                        int y0 = kfirst - 2, last = (ke > kfirst ? ke : kfirst) + 2;
+                        int ra = y0 < 0 ? 0 : y0, rb = last > Hm1 ? Hm1 : last;
+                        int xmin = 0x7fff, xmax = 0, smin = 0x7fff, smax = 0;
+                        for (int y = ra; y <= rb; y++) {
+                            uint2 v = sp[(size_t)st * H + y];
+                            int lo = (int)(v.y & 0xffffu), hi = (int)(v.y >> 16), s0 = (int)(v.x & 0xffffu), s1 = (int)(v.x >> 16);
+                            xmin = lo < xmin ? lo : xmin; xmax = hi > xmax ? hi : xmax;
+                            smin = s0 < smin ? s0 : smin; smax = s1 > smax ? s1 : smax;
+                        }
+                        r = make_int4(xmin, xmax, smin, smax);
+                    }
+                    rg[(size_t)ch * tl.n_strips + st] = r;
+                }
+            if (!c->regions) HIP_TRY(hipMalloc(&c->regions, sizeof(int4) * rg.size() * c->n_slots));
+            HIP_TRY(hipMemcpy(c->regions + rg.size() * slot, rg.data(), sizeof(int4) * rg.size(), hipMemcpyHostToDevice));
+        }
         if (lds_remap_ok(c, sp)) c->slot_mode[slot] = 4;
         else if (c->W >= 4 && (c->W & 3) == 0 && c->H >= 2) c->slot_mode[slot] = 3;
         // statistics for the dark-tile early-out (see blob_filter.hip): total weight per source pixel, tap extents
@@ -285,14 +317,13 @@ int mocap_profile_enable(mocap_ctx_t c, int on)
     return MOCAP_OK;
 }
 
-int mocap_profile_read(mocap_ctx_t c, double* fms, int* fn, double* cms, int* cn, double* gms, int* gn)
+int mocap_profile_read(mocap_ctx_t c, double ms[4], int cnt[4])
 {
-    if (!c) return fail(MOCAP_E_INVALID, "null context");
+    if (!c || !ms || !cnt) return fail(MOCAP_E_INVALID, "null argument");
     if (set_device(c)) return MOCAP_E_HIP;
-    double ms[3] = {0, 0, 0};
-    int cnt[3] = {0, 0, 0};
+    for (int w = 0; w < 4; w++) { ms[w] = 0; cnt[w] = 0; }
     std::lock_guard<std::mutex> lk(c->mu);
-    for (int w = 0; w < 3; w++) {
+    for (int w = 0; w < 4; w++) {
         for (auto& p : c->ev[w]) {
             HIP_TRY(hipEventSynchronize(p.b));
             float f = 0;
@@ -302,9 +333,6 @@ int mocap_profile_read(mocap_ctx_t c, double* fms, int* fn, double* cms, int* cn
         }
         c->ev[w].clear();
     }
-    if (fms) *fms = ms[0]; if (fn) *fn = cnt[0];
-    if (cms) *cms = ms[1]; if (cn) *cn = cnt[1];
-    if (gms) *gms = ms[2]; if (gn) *gn = cnt[2];
     return MOCAP_OK;
 }
 
@@ -385,6 +413,7 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
         auto t5 = [](int n) { return (n - 1 < 2 ? n - 1 : 2) + 1; };
         long long rhs = 1024LL * t5(c->W) * t5(c->H) * (2LL * a.thr_mul - 127);
         int allow = -1;
+        if (c->W < 8 || !c->bright || cells != c->cells) ok = false; // the cell counts live beside c->cells
         if (ok && wmax > 0 && rhs > 0) allow = (int)((rhs - 1) / (2LL * 192 * wmax));
         { const char* e = getenv("MOCAP_SKIP_DARK"); if (e && atoi(e) == 0) allow = -1; }
         a.skip_allow = allow;
@@ -398,7 +427,17 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
     a.strip_fastest = (!remap && a.skip_allow >= 0) ? 1 : 0;
     { const char* e = getenv("MOCAP_STRIP_ORDER"); if (e) a.strip_fastest = atoi(e) != 0; }
     a.spans = c->spans ? c->spans + (size_t)slot_base * tiling(c).n_strips * c->H : nullptr;
+    a.bright = c->bright; a.bright_pitch = bright_pitch(c); a.bright_rows = bright_rows(c);
+    a.regions = c->regions ? c->regions + (size_t)slot_base * tl.n_cgroups * 4 * tl.n_strips : nullptr;
     EvPair p; bool on;
+    if (a.skip_allow >= 0) { // one streaming pass over the frames: bright-pixel counts per 8x8 cell
+        BrightArgs b{a.src, a.image_stride, a.pitch, a.H, a.W, n_images, c->bright, a.bright_pitch,
+                     mask, (size_t)n_images * c->H * c->wpr, ((uintptr_t)mask & 15) == 0};
+        prof_begin(c, 3, s, p, on);
+        launch_bright_cells(b, s);
+        prof_end(c, 3, s, p, on);
+        HIP_TRY(hipGetLastError());
+    }
     prof_begin(c, 0, s, p, on);
     launch_filter_mask(a, remap, s);
     prof_end(c, 0, s, p, on);
@@ -419,11 +458,31 @@ static int run_contours(mocap_ctx* c, const uint32_t* mask, const uint32_t* cell
     a.max_steps = ms > (1 << 22) ? (1 << 22) : (int)ms;
     Tiling tl = tiling(c);
     a.cells = cells; a.rows_per_chunk = tl.rows; a.n_chunks = tl.n_cgroups * 4; a.n_strips = tl.n_strips;
+    a.timing = nullptr;
+    static const bool phase_timing = getenv("MOCAP_CONTOUR_TIMING") && atoi(getenv("MOCAP_CONTOUR_TIMING")) != 0;
+    if (phase_timing) { // debugging aid: synchronous, prints the mean duration of the kernel's phases
+        HIP_TRY(hipMalloc(&a.timing, sizeof(uint64_t) * 8 * n_images));
+        HIP_TRY(hipMemsetAsync(a.timing, 0, sizeof(uint64_t) * 8 * n_images, s));
+    }
     EvPair p; bool on;
     prof_begin(c, 1, s, p, on);
     launch_contours(a, s);
     prof_end(c, 1, s, p, on);
     HIP_TRY(hipGetLastError());
+    if (phase_timing) {
+        std::vector<uint64_t> t((size_t)8 * n_images);
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipMemcpy(t.data(), a.timing, sizeof(uint64_t) * t.size(), hipMemcpyDeviceToHost));
+        (void)hipFree(a.timing);
+        double sum[4] = {0, 0, 0, 0}, mx = 0; uint64_t lo = ~0ull, hi = 0;
+        for (int i = 0; i < n_images; i++) {
+            for (int k = 0; k < 4; k++) sum[k] += (double)(t[8 * i + k + 1] - t[8 * i + k]);
+            double tot = (double)(t[8 * i + 4] - t[8 * i]); mx = tot > mx ? tot : mx;
+            lo = t[8 * i] < lo ? t[8 * i] : lo; hi = t[8 * i + 4] > hi ? t[8 * i + 4] : hi;
+        }
+        fprintf(stderr, "[contours] mean us per block: candidates %.1f follow %.1f link %.1f order %.1f | slowest block %.1f | first start to last end %.1f\n",
+                sum[0] / n_images / 100, sum[1] / n_images / 100, sum[2] / n_images / 100, sum[3] / n_images / 100, mx / 100, (double)(hi - lo) / 100);
+    }
     return 0;
 }
 
@@ -432,7 +491,7 @@ static int ensure_mask(mocap_ctx* c, int n_images)
     if ((size_t)n_images <= c->mask_images) return 0;
     std::lock_guard<std::mutex> lk(c->mu);
     if ((size_t)n_images <= c->mask_images) return 0;
-    if (c->mask) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c->mask)); c->mask = nullptr; c->mask_images = 0; c->cells = nullptr; c->cells_images = 0; c->last_images = 0; }
+    if (c->mask) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c->mask)); c->mask = nullptr; c->mask_images = 0; c->last_images = 0; }
     size_t bytes = sizeof(uint32_t) * (size_t)n_images * c->H * c->wpr;
     HIP_TRY(hipMalloc(&c->mask, bytes));
     HIP_TRY(hipMemset(c->mask, 0, bytes));
@@ -442,6 +501,10 @@ static int ensure_mask(mocap_ctx* c, int n_images)
     HIP_TRY(hipMalloc(&c->cells, cbytes));
     HIP_TRY(hipMemset(c->cells, 0, cbytes));
     c->cells_images = n_images;
+    if (c->bright) { HIP_TRY(hipFree(c->bright)); c->bright = nullptr; }
+    size_t bbytes = (size_t)n_images * bright_rows(c) * bright_pitch(c);
+    HIP_TRY(hipMalloc(&c->bright, bbytes));
+    HIP_TRY(hipMemset(c->bright, 0, bbytes));
     return 0;
 }
 
@@ -529,6 +592,7 @@ int mocap_image_filter_u8(mocap_ctx_t c, const void* src, void* dst, int spitch,
     a.remap_mode = slot >= 0 ? c->slot_mode[slot] : 0;
     a.strip_fastest = 0;
     a.skip_allow = -1; // single-image convenience path: no early-out
+    a.bright = nullptr; a.bright_pitch = 0; a.bright_rows = 0; a.regions = nullptr;
     a.spans = (slot >= 0 && c->spans) ? c->spans + (size_t)slot * tiling(c).n_strips * c->H : nullptr;
     a.thr_mul = ithresh + 1;
     Tiling tl = tiling(c);

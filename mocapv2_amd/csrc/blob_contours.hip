@@ -253,6 +253,10 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
     Mask M{a.mask + (size_t)image * a.H * a.words_per_row, a.words_per_row, a.H, a.W, a.W + 1};
     int32_t* const out_count = a.out_count + (size_t)image * a.count_stride;
     if (tid == 0) { ncand = 0; nrec = 0; nkept = 0; err = 0; ncell = 0; }
+    // optional phase clock (MOCAP_CONTOUR_TIMING=1, a debugging aid): 100 MHz ticks at the phase boundaries
+    uint64_t* const tick = a.timing ? a.timing + (size_t)image * 8 : nullptr;
+    auto stamp = [&](int i) { if (tick && tid == 0) tick[i] = wall_clock64(); };
+    stamp(0);
     __syncthreads();
 
     // ---- phase A: candidate starts -------------------------------------------------------------------------------
@@ -345,6 +349,7 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
         }
     }
     __syncthreads();
+    stamp(1);
     if (ncand > MAXC || err) {
         if (tid == 0) { *out_count = BLOB_ERR_CANDIDATES; if (a.dbg_count) a.dbg_count[image] = 0; }
         return;
@@ -380,6 +385,7 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
         }
     }
     __syncthreads();
+    stamp(2);
     if (nrec > MAXR || err) {
         if (tid == 0) { *out_count = err ? BLOB_ERR_STEPS : BLOB_ERR_CONTOURS; if (a.dbg_count) a.dbg_count[image] = 0; }
         return;
@@ -444,6 +450,7 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
         }
     }
     __syncthreads();
+    stamp(3);
     if (err) {
         if (tid == 0) { *out_count = err == 1 ? BLOB_ERR_STEPS : BLOB_ERR_CONTOURS; if (a.dbg_count) a.dbg_count[image] = 0; }
         return;
@@ -494,6 +501,7 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
         }
     }
     if (tid == 0) *out_count = nkept;
+    stamp(4);
     if (a.dbg) {
         __syncthreads(); // the records' order fields are written by other threads just above
         for (int c = tid; c < nrec && c < a.dbg_cap; c += NTHREADS) a.dbg[(size_t)image * a.dbg_cap + c] = recs[c];

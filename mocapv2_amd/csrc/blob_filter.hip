@@ -279,6 +279,58 @@ __device__ __forceinline__ bool block_exceeds(uint32_t cell, uint32_t& prev2, in
     return __ballot(hit) != 0ull;
 }
 
+// Bright-pixel counts of the fixed 8x8-pixel cell grid of every image: out[image][cell row][cell column] = number of
+// pixels >= 64 in the cell (<= 64).  One pass over the frames at streaming speed -- the only time a dark tile's pixels
+// are read.  A thread counts two cells (16 eight-byte loads in flight); consecutive lanes take consecutive cells of a
+// cell row, so a wave's loads cover 512 contiguous bytes of each of 8 image rows.
+__global__ __launch_bounds__(256) void bright_cells_kernel(BrightArgs a)
+{
+    const int ncx = (a.W + 7) >> 3, ncy = (a.H + 7) >> 3, n = ncx * ncy;
+    const int image = blockIdx.y;
+    const uint8_t* __restrict__ img = a.src + (size_t)image * a.image_stride;
+    uint8_t* __restrict__ out = a.out + (size_t)image * ncy * a.out_pitch;
+    const int i0 = blockIdx.x * 512 + threadIdx.x;
+    uint2 v[2][8];
+    int cr[2], cx[2];
+    uint32_t sh[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        int i = i0 + 256 * u;
+        i = i < n ? i : n - 1; // threads past the end recount the last cell and store the same value again
+        cr[u] = i / ncx; cx[u] = i - cr[u] * ncx;
+        const int c = 8 * cx[u], cc = c < a.W - 8 ? c : a.W - 8; // W >= 8 (checked on the host)
+        sh[u] = (uint32_t)(8 * (c - cc));
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            int r = 8 * cr[u] + j;
+            r = r < a.H ? r : a.H - 1;
+            __builtin_memcpy(&v[u][j], img + ((uint32_t)r * (uint32_t)a.pitch + (uint32_t)cc), 8);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint64_t vv = (((uint64_t)v[u][j].y << 32) | v[u][j].x) >> sh[u]; // drops the bytes left of the cell at the right edge
+            uint32_t cnt = bright_count((uint32_t)vv) + bright_count((uint32_t)(vv >> 32));
+            if (8 * cr[u] + j < a.H) acc += cnt;
+        }
+        out[(uint32_t)cr[u] * (uint32_t)a.out_pitch + (uint32_t)cx[u]] = (uint8_t)acc;
+    }
+    // side job while the loads are in flight elsewhere: clear the bit masks of the batch (16 bytes per thread and
+    // round), so that the filter kernel only writes the tiles it actually filters
+    const size_t nthreads = (size_t)gridDim.x * gridDim.y * 256;
+    const size_t g = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+    if (a.mask_aligned16) {
+        const size_t quads = a.mask_words >> 2;
+        for (size_t q = g; q < quads; q += nthreads) ((uint4*)a.mask)[q] = make_uint4(0u, 0u, 0u, 0u);
+        if (g < (a.mask_words & 3)) a.mask[(quads << 2) + g] = 0u;
+    } else {
+        for (size_t q = g; q < a.mask_words; q += nthreads) a.mask[q] = 0u;
+    }
+}
+
 // number of in-image taps of a 5-wide window centred on v
 __device__ __forceinline__ int taps5(int v, int n)
 {
@@ -297,21 +349,8 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
     __shared__ uint32_t cring[4][8][64];
     __shared__ __attribute__((aligned(16))) uint8_t sring[LDSR ? 4 : 1][LDSR ? RING_H * RING_W : 16];
 
-    // lut[w]: byte k = number of set bits among bits k..k+4 of the 8-bit window w
-    {
-        uint32_t i = threadIdx.x, v = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) v |= (uint32_t)__popc((i >> k) & 0x1fu) << (8 * k);
-        lut[i] = v;
-    }
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform: keeps the row loop scalar
-#pragma unroll
-    for (int s = 0; s < 8; s++) {
-        hring[wv][s][lane] = make_uint2(0u, 0u);
-        cring[wv][s][lane] = 0u;
-    }
-    __syncthreads();
 
     // block -> (camera slot, strip, chunk group, time step).  Blocks b and b+8 share an XCD (round-robin dispatch;
     // placement only affects speed).  Two orders:
@@ -346,13 +385,83 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
     if (r0 >= a.H) return;
     const int r1 = r0 + a.rows_per_chunk < a.H ? r0 + a.rows_per_chunk : a.H;
 
+    const int Hm1 = a.H - 1;
+    int kfirst = r0 - 2;
+    kfirst = kfirst < 0 ? 0 : (kfirst > Hm1 ? Hm1 : kfirst);
+    const int ks = r0 - 1 > 1 ? r0 - 1 : 1;                 // steady range: every iteration slides one source row
+    const int ke = r1 + 1 < Hm1 ? r1 + 1 : Hm1;
+    const int xbase = strip * 240 - 8;
+    const size_t cell_index = ((size_t)image * a.n_cgroups * 4 + (cgroup * 4 + wv)) * a.n_strips + strip;
+
+    if (a.skip_allow >= 0) {
+        // ---- dark-tile early-out (see the comment above bright_count): first thing a wave does ----
+        const int allow = a.skip_allow;
+        // source region of the tile: rows [s_lo, s_hi], columns [x_lo, x_hi] (all inside the image)
+        int s_lo, s_hi, x_lo, x_hi;
+        if (REMAP) { // from the undistort table, precomputed per (slot, chunk, strip) at set-up
+            const int4 rg = a.regions[((size_t)slot * a.n_cgroups * 4 + (cgroup * 4 + wv)) * a.n_strips + strip];
+            x_lo = rg.x; x_hi = rg.y; s_lo = rg.z; s_hi = rg.w;
+        } else {     // the plain path's source region is the tile's own input
+            const int last = (ke > kfirst ? ke : kfirst) + 2;
+            s_lo = kfirst - 2 < 0 ? 0 : kfirst - 2; s_hi = last > Hm1 ? Hm1 : last;
+            x_lo = xbase < 0 ? 0 : xbase; x_hi = xbase + 255 > a.W - 1 ? a.W - 1 : xbase + 255;
+        }
+        // 2x2-block sums over the cells (8x8 px, counted whole by bright_cells_kernel) the region touches:
+        // lane = cell column, up to 16 cell rows per round of loads
+        const int cx0 = x_lo >> 3, ncols = (x_hi >> 3) - cx0 + 1, cr0 = s_lo >> 3, cr1 = s_hi >> 3;
+        bool bright = false;
+        if (ncols > 64 || x_hi < x_lo || s_hi < s_lo) bright = true; // wider than one wave covers / empty: no early-out
+        else {
+            const bool act = lane < ncols;
+            const uint8_t* bc = a.bright + (size_t)image * a.bright_rows * a.bright_pitch + (uint32_t)(cx0 + (act ? lane : 0));
+            uint32_t prev2 = 0;
+            bool hit = false;
+            for (int cb = cr0; cb <= cr1; cb += 16) {
+                uint32_t cnt[16];
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    int cr = cb + j < cr1 ? cb + j : cr1;
+                    cnt[j] = bc[(uint32_t)cr * (uint32_t)a.bright_pitch];
+                }
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    uint32_t v = (act && cb + j <= cr1) ? cnt[j] : 0u;
+                    uint32_t right = lane_from_next(v);
+                    if (lane == 63) right = 0;
+                    uint32_t cur2 = v + right;
+                    hit |= (int)(cur2 + prev2) > allow;
+                    if (cb + j <= cr1) prev2 = cur2;
+                }
+            }
+            bright = __ballot(hit) != 0ull;
+        }
+        if (!bright) { // all-zero tile: the mask was cleared by bright_cells_kernel; publish an empty occupancy word
+            if (lane == 0) a.cells[cell_index] = 0u;
+            return;
+        }
+    }
+
+    // lut[w]: byte k = number of set bits among bits k..k+4 of the 8-bit window w.  Every wave that filters writes the
+    // whole table (identical values), so no workgroup barrier is needed and dark waves are gone before this point.
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        uint32_t i = (uint32_t)(lane + 64 * e), v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) v |= (uint32_t)__popc((i >> k) & 0x1fu) << (8 * k);
+        lut[i] = v;
+    }
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        hring[wv][s][lane] = make_uint2(0u, 0u);
+        cring[wv][s][lane] = 0u;
+    }
+
     const uint8_t* __restrict__ img = a.src + (size_t)image * a.image_stride;
     const uint32_t* __restrict__ map = REMAP ? a.map + (size_t)slot * a.H * a.W : nullptr;
     const uint32_t* __restrict__ mapw = REMAP ? a.mapw + (size_t)slot * a.H * a.W : nullptr;
     uint8_t* __restrict__ mrow_base = (uint8_t*)(a.mask + (size_t)image * a.H * a.words_per_row);
     const int row_bytes = a.words_per_row * 4;
 
-    const int xbase = strip * 240 - 8;
     const int xl = xbase + 4 * lane;
 
     // per-lane column constants
@@ -374,12 +483,6 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
     const bool stores = ((lane & 1) == 0) && lane >= 2 && lane <= 60 && out_byte < ((a.W + 7) >> 3) &&
                         out_byte < row_bytes;
 
-    const int Hm1 = a.H - 1;
-    int kfirst = r0 - 2;
-    kfirst = kfirst < 0 ? 0 : (kfirst > Hm1 ? Hm1 : kfirst);
-    const int ks = r0 - 1 > 1 ? r0 - 1 : 1;                 // steady range: every iteration slides one source row
-    const int ke = r1 + 1 < Hm1 ? r1 + 1 : Hm1;
-
     uint32_t V01 = 0, V23 = 0, Cv = 0;
     uint32_t lacc = 0; // per lane: bit g = this lane's columns have set pixels in output rows r0+8g .. r0+8g+7
     const bool out_lane = lane >= 2 && lane <= 61;
@@ -394,94 +497,6 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
     // their taps stay inside the image, their result is masked out)
     for (int k = 0; k < 4; k++) xq[k] = lc.addr_x + k;
     const int y0 = kfirst - 2;
-    if (a.skip_allow >= 0) {
-        // ---- dark-tile early-out (see the comment above bright_count) ----
-        const int allow = a.skip_allow;
-        const int last = (ke > kfirst ? ke : kfirst) + 2; // last source-image row of the filter's input this chunk consumes
-        bool bright = false;
-        uint32_t acc = 0, prev2 = 0;
-        if (REMAP) {
-            // source region of the tile from the span table: rows [smin, smax], columns [xs0, xs0 + 8 * nl)
-            const uint2* spans = a.spans + ((size_t)slot * a.n_strips + strip) * a.H;
-            int xmin = 0x7fff, xmax = 0, smin = 0x7fff, smax = 0;
-            const int ra = y0 < 0 ? 0 : y0, rb = last > Hm1 ? Hm1 : last;
-            for (int r = ra + lane; r <= rb; r += 64) {
-                uint2 sp = spans[r];
-                int lo = (int)(sp.y & 0xffffu), hi = (int)(sp.y >> 16), s0 = (int)(sp.x & 0xffffu), s1 = (int)(sp.x >> 16);
-                xmin = lo < xmin ? lo : xmin; xmax = hi > xmax ? hi : xmax;
-                smin = s0 < smin ? s0 : smin; smax = s1 > smax ? s1 : smax;
-            }
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                int o1 = __shfl_xor(xmin, d), o2 = __shfl_xor(xmax, d), o3 = __shfl_xor(smin, d), o4 = __shfl_xor(smax, d);
-                xmin = o1 < xmin ? o1 : xmin; xmax = o2 > xmax ? o2 : xmax;
-                smin = o3 < smin ? o3 : smin; smax = o4 > smax ? o4 : smax;
-            }
-            const int xs0 = __builtin_amdgcn_readfirstlane(xmin) & ~7;
-            const int nl = (__builtin_amdgcn_readfirstlane(xmax) - xs0 + 8) >> 3; // cell columns, one per lane
-            const int s_lo = __builtin_amdgcn_readfirstlane(smin), s_hi = __builtin_amdgcn_readfirstlane(smax);
-            if (nl > 64 || a.W < 8) bright = true; // region wider than one wave covers: no early-out
-            else {
-                const int c = xs0 + 8 * lane, cc = c < a.W - 8 ? c : a.W - 8;
-                const uint32_t sh = (uint32_t)(8 * (c - cc) > 63 ? 63 : 8 * (c - cc));
-                for (int rbase = s_lo & ~7; rbase <= s_hi && !bright; rbase += 8) { // one cell row = 8 source rows
-                    uint2 v[8];
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        int r = rbase + j;
-                        r = r < s_lo ? s_lo : (r > s_hi ? s_hi : r); // clamped duplicates are masked below
-                        __builtin_memcpy(&v[j], img + ((uint32_t)r * (uint32_t)a.pitch + (uint32_t)cc), 8);
-                    }
-                    acc = 0;
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        int r = rbase + j;
-                        uint64_t vv = (((uint64_t)v[j].y << 32) | v[j].x) >> sh;
-                        uint32_t cnt = bright_count((uint32_t)vv) + bright_count((uint32_t)(vv >> 32));
-                        if (r >= s_lo && r <= s_hi) acc += cnt; // wave-uniform condition
-                    }
-                    if (lane >= nl) acc = 0;
-                    bright = block_exceeds(acc, prev2, 1, lane, allow);
-                }
-            }
-        } else {
-            // the plain path's source region is the tile's own input: rows [y0, last] (in the image), columns of the strip
-            const int s_lo = y0 < 0 ? 0 : y0, s_hi = last > Hm1 ? Hm1 : last;
-            if (TINY) bright = true;
-            for (int rbase = s_lo & ~7; rbase <= s_hi && !bright; rbase += 8) {
-                uint32_t v[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    int r = rbase + j;
-                    r = r < s_lo ? s_lo : (r > s_hi ? s_hi : r);
-                    v[j] = fetch_src4<false, TINY>(a, img, map, r, xl, lc);
-                }
-                acc = 0;
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    int r = rbase + j;
-                    uint32_t cnt = bright_count(finish_src4<false, TINY>(v[j], true, lc));
-                    if (r >= s_lo && r <= s_hi) acc += cnt;
-                }
-                // a cell (8 columns) = a lane pair; xbase is a multiple of 8, so pairs (2m, 2m+1) are grid-aligned
-                uint32_t cell = acc + (uint32_t)__shfl_xor((int)acc, 1);
-                bright = block_exceeds(cell, prev2, 2, lane, allow);
-            }
-        }
-        if (!bright) {
-            // all-zero tile: write the zero mask bytes (two rows per wave instruction) and an empty occupancy word
-            const int half = lane >> 5, pair = lane & 31, byte0 = strip * 30 + 2 * pair, nb = (a.W + 7) >> 3;
-            if (pair < 15 && byte0 < nb) {
-                for (int i = half; i < r1 - r0; i += 2) {
-                    uint8_t* dst = mrow_base + (size_t)(r0 + i) * row_bytes + byte0;
-                    if (byte0 + 1 < nb) *(uint16_t*)dst = 0; // byte0 is even: aligned
-                    else *dst = 0;
-                }
-            }
-            if (lane == 0) a.cells[((size_t)image * a.n_cgroups * 4 + (cgroup * 4 + wv)) * a.n_strips + strip] = 0u;
-            return;
-        }
-    }
     TabSlot tabs[4];
     RowReq rq[4];
     LTaps tb[2];
@@ -701,7 +716,7 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
         for (int g = 0; g < groups; g++)
             if (__ballot(out_lane && ((lacc >> g) & 1u)) != 0ull) cellmask |= 1u << g;
         // bit 31 marks a tile that went through the full filter (the early-out writes 0); bits 0..16 are the groups
-        if (lane == 0) a.cells[((size_t)image * a.n_cgroups * 4 + (cgroup * 4 + wv)) * a.n_strips + strip] = cellmask | 0x80000000u;
+        if (lane == 0) a.cells[cell_index] = cellmask | 0x80000000u;
     }
 }
 
@@ -944,6 +959,11 @@ void launch_filter_mask(const FilterArgs& a, bool remap, hipStream_t s)
         hipLaunchKernelGGL((filter_mask_kernel<false, false, false, false>), dim3(blocks), dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL((filter_mask_kernel<false, true, false, false>), dim3(blocks), dim3(256), 0, s, a);
+}
+void launch_bright_cells(const BrightArgs& a, hipStream_t s)
+{
+    const int n = ((a.W + 7) >> 3) * ((a.H + 7) >> 3);
+    hipLaunchKernelGGL(bright_cells_kernel, dim3((n + 511) / 512, a.n_images), dim3(256), 0, s, a);
 }
 void launch_undistort_map(const MapArgs& m, hipStream_t s)
 {

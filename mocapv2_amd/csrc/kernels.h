@@ -21,6 +21,9 @@ struct FilterArgs {
     int remap_mode;       // 0 plain / 2 per-pixel gather, 3 pipelined gather, 4 LDS-staged
     int skip_allow;       // dark-tile early-out: a tile whose source region has no 16x16 block (2x2 cells of 8x8 px)
                           //   with more than this many pixels >= 64 provably yields an all-zero mask; -1 = off
+    const uint8_t* bright; // [n_images][bright_rows][bright_pitch] pixels >= 64 per 8x8 cell (bright_cells_kernel); used if skip_allow >= 0
+    int bright_pitch, bright_rows;
+    const int4* regions;  // remap variant: [cam_mod][n_cgroups*4][n_strips] source region (x_lo, x_hi, s_lo, s_hi) of each tile
     int strip_fastest;    // block order: 1 = neighbouring strips share an XCD in time, 0 = time steps of a tile do
     int cam_mod;          // undistort slot of image n = n % cam_mod (map already points at the first slot)
     int n_images, n_steps; // n_steps = ceil(n_images / cam_mod)
@@ -65,11 +68,18 @@ struct ContourArgs {
     int max_steps;
     const uint32_t* cells; // occupancy written by the filter kernel (see FilterArgs), or null = scan every row
     int rows_per_chunk, n_chunks, n_strips;
+    uint64_t* timing;      // optional [n_images][8] phase clock (debugging aid), else null
 };
 
 enum { BLOB_ERR_CANDIDATES = -2, BLOB_ERR_CONTOURS = -3, BLOB_ERR_STEPS = -4, BLOB_ERR_DEPTH = -5 };
 
 void launch_filter_mask(const FilterArgs& a, bool remap, hipStream_t s);
+struct BrightArgs {
+    const uint8_t* src; size_t image_stride; int pitch, H, W, n_images; // W >= 8
+    uint8_t* out; int out_pitch;                                         // cell counts [n_images][ceil(H/8)][out_pitch]
+    uint32_t* mask; size_t mask_words; int mask_aligned16;               // the batch's bit masks, cleared on the side
+};
+void launch_bright_cells(const BrightArgs& a, hipStream_t s);
 struct SpanArgs { const uint32_t* map; uint2* spans; int H, W, n_strips; };
 // set-up statistics of an undistort table, for the dark-tile bound: stats[0] = largest total blend weight any source
 // pixel carries over all output pixels (1024 = one full pixel), stats[1] / stats[2] = largest x / y extent (in source

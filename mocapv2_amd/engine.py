@@ -261,12 +261,12 @@ class MocapContext:
         _abi.check(self.lib.mocap_profile_enable(self._h, int(on)))
 
     def profile_read(self):
-        ms = [C.c_double(0) for _ in range(3)]
-        n = [C.c_int(0) for _ in range(3)]
-        _abi.check(self.lib.mocap_profile_read(self._h, C.byref(ms[0]), C.byref(n[0]), C.byref(ms[1]), C.byref(n[1]),
-                                               C.byref(ms[2]), C.byref(n[2])))
-        return {"filter_ms": ms[0].value, "filter_launches": n[0].value, "contour_ms": ms[1].value,
-                "contour_launches": n[1].value, "corr_ms": ms[2].value, "corr_launches": n[2].value}
+        """Accumulated HIP-event milliseconds / launch counts per kernel since the last read (mocap_hip.h)."""
+        ms = (C.c_double * 4)()
+        n = (C.c_int * 4)()
+        _abi.check(self.lib.mocap_profile_read(self._h, ms, n))
+        return {"filter_ms": ms[0], "filter_launches": n[0], "contour_ms": ms[1], "contour_launches": n[1],
+                "corr_ms": ms[2], "corr_launches": n[2], "scan_ms": ms[3], "scan_launches": n[3]}
 
 
 _contexts = {}
