@@ -23,7 +23,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-N_CAM, WIDTH, HEIGHT, N_MARKERS, T_STEPS = 6, 1920, 1080, 8, 64
+N_CAM, WIDTH, HEIGHT, N_MARKERS, T_STEPS = 6, 1920, 1080, 8, 256
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 
 

@@ -47,11 +47,13 @@ struct mocap_ctx {
     std::vector<uint32_t> slot_wmax; // largest total blend weight of a source pixel (1024 = identity); 0 = early-out not provable
     std::vector<int> slot_mode;  // remap kernel variant the slot's table admits: 2 per-pixel, 3 pipelined gather, 4 LDS-staged
     uint2* spans;             // [n_slots][n_strips][H] source row / column spans per strip row
-    int4* regions;            // [n_slots][n_cgroups*4][n_strips] source region of every filter tile (remap slots)
+    uint2* hull;              // [n_slots][ceil(H/8)][ceil(W/8)] per 8x8 source cell: the tiles whose source region holds it
     uint32_t* mask; size_t mask_images;
     uint32_t* cells; size_t cells_images; // occupancy cells written by the filter kernel for c->mask
     int last_images;                       // images of the most recent batch that wrote c->cells
-    uint8_t* bright;                       // [mask_images][bright_rows][bright_pitch] bright-pixel counts per 8x8 cell
+    uint8_t* tile_flags;                   // [mask_images][tiles] hot-cell marks, beside cells (see FilterArgs)
+    uint32_t* cells_ext; size_t cells_ext_images; // occupancy words of caller-owned masks (mocap_filter_mask)
+    void* cwork; size_t cwork_images;      // contour kernel workspace, contour_work_bytes() per image
     CameraTable* cams; int n_cam, n_F;
     double* scratch; size_t scratch_elems;
     bool profiling;
@@ -76,8 +78,7 @@ static Tiling tiling(const mocap_ctx* c)
     return t;
 }
 
-static int bright_rows(const mocap_ctx* c) { return (c->H + 7) / 8; }
-static int bright_pitch(const mocap_ctx* c) { return (((c->W + 7) / 8) + 63) & ~63; }
+static size_t source_cells(const mocap_ctx* c) { return (size_t)((c->H + 7) / 8) * ((c->W + 7) / 8); }
 static size_t cells_per_image(const mocap_ctx* c) { Tiling t = tiling(c); return (size_t)t.n_cgroups * 4 * t.n_strips; }
 
 // Can the LDS-staged remap kernel serve this slot?  Replays, per (strip, chunk), the kernel's ring schedule on the
@@ -138,7 +139,7 @@ int mocap_ctx_create(int device_id, int width, int height, int n_slots, mocap_ct
     mocap_ctx* c = new mocap_ctx();
     c->device = device_id; c->W = width; c->H = height; c->n_slots = n_slots; c->wpr = (width + 31) / 32;
     c->prm = mocap_blob_params{5, 5, 255 * 0.85, 500.0, 0.5};
-    c->maps = nullptr; c->spans = nullptr; c->regions = nullptr; c->map_flags = nullptr; c->mask = nullptr; c->mask_images = 0; c->cells = nullptr; c->cells_images = 0; c->last_images = 0; c->bright = nullptr;
+    c->maps = nullptr; c->spans = nullptr; c->hull = nullptr; c->cells_ext = nullptr; c->cells_ext_images = 0; c->map_flags = nullptr; c->mask = nullptr; c->mask_images = 0; c->cells = nullptr; c->cells_images = 0; c->last_images = 0; c->tile_flags = nullptr; c->cwork = nullptr; c->cwork_images = 0;
     c->cams = nullptr; c->n_cam = 0; c->n_F = 0; c->scratch = nullptr; c->scratch_elems = 0; c->profiling = false;
     c->slot_state.assign(n_slots, 0);
     c->slot_mode.assign(n_slots, 2);
@@ -162,11 +163,13 @@ int mocap_ctx_destroy(mocap_ctx_t c)
     for (auto& v : c->ev) for (auto& p : v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (c->maps) (void)hipFree(c->maps);
     if (c->spans) (void)hipFree(c->spans);
-    if (c->regions) (void)hipFree(c->regions);
+    if (c->hull) (void)hipFree(c->hull);
+    if (c->cells_ext) (void)hipFree(c->cells_ext);
     if (c->map_flags) (void)hipFree(c->map_flags);
     if (c->mask) (void)hipFree(c->mask);
     if (c->cells) (void)hipFree(c->cells);
-    if (c->bright) (void)hipFree(c->bright);
+    if (c->tile_flags) (void)hipFree(c->tile_flags);
+    if (c->cwork) (void)hipFree(c->cwork);
     if (c->cams) (void)hipFree(c->cams);
     if (c->scratch) (void)hipFree(c->scratch);
     delete c;
@@ -214,8 +217,11 @@ int mocap_set_undistort(mocap_ctx_t c, int slot, const double K[9], const double
     c->slot_state[slot] = (flags & 1u) ? 2 : 1;
     c->slot_mode[slot] = 2;
     c->slot_wmax[slot] = c->slot_state[slot] == 1 ? 1024u : 0u; // identity: every source pixel feeds exactly one output pixel
+    Tiling tl = tiling(c);
+    std::vector<uint2> sp_host; // remap slots: the span table on the host
+    const int ncx_ = (c->W + 7) / 8, ncy_ = (c->H + 7) / 8;
+    std::vector<uint32_t> edge((size_t)ncx_ * ncy_, 0); // source cells read by windows that the image border cuts: bit 0 one axis, bit 1 both
     if (c->slot_state[slot] == 2) {
-        Tiling tl = tiling(c);
         size_t nsp = (size_t)tl.n_strips * c->H;
         if (!c->spans) HIP_TRY(hipMalloc(&c->spans, sizeof(uint2) * nsp * c->n_slots));
         SpanArgs sa{m.map, c->spans + nsp * slot, c->H, c->W, tl.n_strips};
@@ -223,48 +229,78 @@ int mocap_set_undistort(mocap_ctx_t c, int slot, const double K[9], const double
         HIP_TRY(hipGetLastError());
         std::vector<uint2> sp(nsp);
         HIP_TRY(hipMemcpy(sp.data(), sa.spans, sizeof(uint2) * nsp, hipMemcpyDeviceToHost));
-        {   // source region of every (chunk, strip) tile: the union of the spans of the rows the tile consumes
-            const int H = c->H, Hm1 = H - 1, nch = tl.n_cgroups * 4;
-            std::vector<int4> rg((size_t)nch * tl.n_strips);
-            for (int ch = 0; ch < nch; ch++)
-                for (int st = 0; st < tl.n_strips; st++) {
-                    int4 r = make_int4(0, -1, 0, -1); // empty: chunks that start below the image
-                    int r0 = ch * tl.rows;
-                    if (r0 < H) {
-                        int r1 = r0 + tl.rows < H ? r0 + tl.rows : H;
-                        int kfirst = r0 - 2 < 0 ? 0 : (r0 - 2 > Hm1 ? Hm1 : r0 - 2), ke = r1 + 1 < Hm1 ? r1 + 1 : Hm1;
-                        int y0 = kfirst - 2, last = (ke > kfirst ? ke : kfirst) + 2;
-                        int ra = y0 < 0 ? 0 : y0, rb = last > Hm1 ? Hm1 : last;
-                        int xmin = 0x7fff, xmax = 0, smin = 0x7fff, smax = 0;
-                        for (int y = ra; y <= rb; y++) {
-                            uint2 v = sp[(size_t)st * H + y];
-                            int lo = (int)(v.y & 0xffffu), hi = (int)(v.y >> 16), s0 = (int)(v.x & 0xffffu), s1 = (int)(v.x >> 16);
-                            xmin = lo < xmin ? lo : xmin; xmax = hi > xmax ? hi : xmax;
-                            smin = s0 < smin ? s0 : smin; smax = s1 > smax ? s1 : smax;
-                        }
-                        r = make_int4(xmin, xmax, smin, smax);
-                    }
-                    rg[(size_t)ch * tl.n_strips + st] = r;
-                }
-            if (!c->regions) HIP_TRY(hipMalloc(&c->regions, sizeof(int4) * rg.size() * c->n_slots));
-            HIP_TRY(hipMemcpy(c->regions + rg.size() * slot, rg.data(), sizeof(int4) * rg.size(), hipMemcpyHostToDevice));
-        }
+        sp_host = sp;
         if (lds_remap_ok(c, sp)) c->slot_mode[slot] = 4;
         else if (c->W >= 4 && (c->W & 3) == 0 && c->H >= 2) c->slot_mode[slot] = 3;
         // statistics for the dark-tile early-out (see blob_filter.hip): total weight per source pixel, tap extents
         uint32_t* tmp = nullptr;
-        HIP_TRY(hipMalloc(&tmp, sizeof(uint32_t) * (per + 4)));
-        hipError_t e2 = hipMemset(tmp, 0, sizeof(uint32_t) * (per + 4));
+        const size_t edge_words = edge.size();
+        HIP_TRY(hipMalloc(&tmp, sizeof(uint32_t) * (per + 4 + edge_words)));
+        hipError_t e2 = hipMemset(tmp, 0, sizeof(uint32_t) * (per + 4 + edge_words));
         uint32_t st3[3] = {0, 0, 0};
         if (e2 == hipSuccess) {
-            StatArgs sg{m.map, m.mapw, tmp, tmp + per, c->H, c->W};
+            StatArgs sg{m.map, m.mapw, tmp, tmp + per, c->H, c->W, tmp + per + 4};
             launch_remap_stats(sg, 0);
             e2 = hipGetLastError();
             if (e2 == hipSuccess) e2 = hipMemcpy(st3, tmp + per, sizeof(st3), hipMemcpyDeviceToHost);
+            if (e2 == hipSuccess) e2 = hipMemcpy(edge.data(), tmp + per + 4, sizeof(uint32_t) * edge.size(), hipMemcpyDeviceToHost);
         }
         (void)hipFree(tmp);
         if (e2 != hipSuccess) return fail(MOCAP_E_HIP, "undistort statistics: %s", hipGetErrorString(e2));
         if (st3[1] <= 9 && st3[2] <= 9 && c->W >= 8) c->slot_wmax[slot] = st3[0];
+    }
+    {   // Dark-tile early-out tables.  Source region of every (chunk, strip) filter tile = what the tile's rows read
+        // (remap: the union of their spans; identity: the tile's own input rectangle), then per 8x8 source cell the
+        // hull (chunk range x strip range) of the tiles whose region holds the cell -- what bright_cells_kernel marks
+        // when the cell is hot.  A hull may name tiles that do not hold the cell (it is a rectangle): harmless, a
+        // marked tile is simply filtered.
+        const int H = c->H, W = c->W, Hm1 = H - 1, nch = tl.n_cgroups * 4, ncx = (W + 7) / 8, ncy = (H + 7) / 8;
+        std::vector<uint2> hull((size_t)ncx * ncy, make_uint2(0xffffu, 0xffffu)); // first = 0xffff > last = 0: no tile
+        for (int ch = 0; ch < nch && ch * tl.rows < H; ch++)
+            for (int st = 0; st < tl.n_strips; st++) {
+                int r0 = ch * tl.rows, r1 = r0 + tl.rows < H ? r0 + tl.rows : H;
+                int kfirst = r0 - 2 < 0 ? 0 : (r0 - 2 > Hm1 ? Hm1 : r0 - 2), ke = r1 + 1 < Hm1 ? r1 + 1 : Hm1;
+                int y0 = kfirst - 2, last = (ke > kfirst ? ke : kfirst) + 2;
+                int ra = y0 < 0 ? 0 : y0, rb = last > Hm1 ? Hm1 : last;
+                int xmin = 0x7fff, xmax = -1, smin = 0x7fff, smax = -1;
+                if (c->slot_state[slot] == 2) {
+                    for (int y = ra; y <= rb; y++) {
+                        uint2 v = sp_host[(size_t)st * H + y];
+                        int lo = (int)(v.y & 0xffffu), hi = (int)(v.y >> 16), s0 = (int)(v.x & 0xffffu), s1 = (int)(v.x >> 16);
+                        xmin = lo < xmin ? lo : xmin; xmax = hi > xmax ? hi : xmax;
+                        smin = s0 < smin ? s0 : smin; smax = s1 > smax ? s1 : smax;
+                    }
+                } else {
+                    int xbase = st * 240 - 8;
+                    xmin = xbase < 0 ? 0 : xbase; xmax = xbase + 255 > W - 1 ? W - 1 : xbase + 255;
+                    smin = ra; smax = rb;
+                }
+                if (xmax < xmin || smax < smin) continue;
+                xmin = xmin < 0 ? 0 : xmin; smin = smin < 0 ? 0 : smin;
+                xmax = xmax > W - 1 ? W - 1 : xmax; smax = smax > Hm1 ? Hm1 : smax;
+                for (int cr = smin >> 3; cr <= smax >> 3; cr++)
+                    for (int cx = xmin >> 3; cx <= xmax >> 3; cx++) {
+                        uint2& h = hull[(size_t)cr * ncx + cx];
+                        uint32_t c_lo = h.x & 0xffffu, c_hi = h.x >> 16, s_lo = h.y & 0xffffu, s_hi = h.y >> 16;
+                        if (c_lo > c_hi) { c_lo = c_hi = (uint32_t)ch; s_lo = s_hi = (uint32_t)st; }
+                        else {
+                            c_lo = (uint32_t)ch < c_lo ? (uint32_t)ch : c_lo; c_hi = (uint32_t)ch > c_hi ? (uint32_t)ch : c_hi;
+                            s_lo = (uint32_t)st < s_lo ? (uint32_t)st : s_lo; s_hi = (uint32_t)st > s_hi ? (uint32_t)st : s_hi;
+                        }
+                        h = make_uint2(c_lo | (c_hi << 16), s_lo | (s_hi << 16));
+                    }
+            }
+        if (c->slot_state[slot] == 1) // identity: the cut windows lie within 4 pixels of the border
+            for (int cr = 0; cr < ncy; cr++)
+                for (int cx = 0; cx < ncx; cx++)
+                {
+                    const bool xc = 8 * cx < 4 || 8 * cx + 7 >= W - 4, yc = 8 * cr < 4 || 8 * cr + 7 >= H - 4;
+                    edge[(size_t)cr * ncx + cx] = (xc && yc) ? 2u : (xc || yc) ? 1u : 0u;
+                }
+        for (size_t i = 0; i < hull.size(); i++)
+            hull[i].y |= (edge[i] & 2u) ? 0x80000000u : (edge[i] & 1u) ? 0x40000000u : 0u;
+        if (!c->hull) HIP_TRY(hipMalloc(&c->hull, sizeof(uint2) * hull.size() * c->n_slots));
+        HIP_TRY(hipMemcpy(c->hull + hull.size() * slot, hull.data(), sizeof(uint2) * hull.size(), hipMemcpyHostToDevice));
     }
     if (identity_out) *identity_out = c->slot_state[slot] == 1;
     return MOCAP_OK;
@@ -399,40 +435,45 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
     // MI355X so far, so it is opt-in: MOCAP_REMAP_MODE=4; 2 or 3 force a simpler variant (tests).
     { const char* e = getenv("MOCAP_REMAP_MODE"); int cap = e ? atoi(e) : 3; if (cap < 2) cap = 3; if (cap < mode) mode = cap; }
     a.remap_mode = mode;
+    int allow_cut1 = -1, allow_cut2 = -1;
     // dark-tile early-out: largest bright-pixel count per 16x16 block that still proves an all-zero mask
     //   2 * n * (256 - 64) * Wmax < 1024 * taps_min * (2 * thr_mul - 2 * 64 + 1)     (derivation: blob_filter.hip)
     {
         long long wmax = 0;
-        bool ok = true, any_ident = false, any_remap = false;
+        bool ok = true;
         for (int sl = slot_base; sl < slot_base + cam_mod; sl++) {
             if (c->slot_wmax[sl] == 0) ok = false;
             wmax = c->slot_wmax[sl] > wmax ? c->slot_wmax[sl] : wmax;
-            (c->slot_state[sl] == 2 ? any_remap : any_ident) = true;
         }
-        if (any_ident && any_remap) ok = false; // identity slots carry no span table for the remap kernels' scan
-        auto t5 = [](int n) { return (n - 1 < 2 ? n - 1 : 2) + 1; };
-        long long rhs = 1024LL * t5(c->W) * t5(c->H) * (2LL * a.thr_mul - 127);
+        auto t5 = [](int n) { return (n - 1 < 2 ? n - 1 : 2) + 1; }; // taps of a window at the border, per axis
+        auto t5full = [](int n) { return n < 5 ? n : 5; };
+        const long long per_tap = 1024LL * (2LL * a.thr_mul - 127);
         int allow = -1;
-        if (c->W < 8 || !c->bright || cells != c->cells) ok = false; // the cell counts live beside c->cells
-        if (ok && wmax > 0 && rhs > 0) allow = (int)((rhs - 1) / (2LL * 192 * wmax));
+        allow_cut1 = allow_cut2 = -1;
+        if (c->W < 8 || !c->tile_flags || !c->hull) ok = false;
+        if (ok && wmax > 0 && per_tap > 0) {
+            allow = (int)((per_tap * t5full(c->W) * t5full(c->H) - 1) / (2LL * 192 * wmax)); // windows with all their taps
+            const long long taps1 = t5(c->W) * t5full(c->H) < t5full(c->W) * t5(c->H) ? t5(c->W) * t5full(c->H) : t5full(c->W) * t5(c->H);
+            allow_cut1 = (int)((per_tap * taps1 - 1) / (2LL * 192 * wmax));                  // smallest window cut in one axis
+            allow_cut2 = (int)((per_tap * t5(c->W) * t5(c->H) - 1) / (2LL * 192 * wmax));    // smallest window cut in both
+        }
         { const char* e = getenv("MOCAP_SKIP_DARK"); if (e && atoi(e) == 0) allow = -1; }
         a.skip_allow = allow;
     }
     if (cells == c->cells) c->last_images = n_images;
-    // Block order.  Remapped cameras: time-fastest, so that concurrently resident blocks work on the same tile of
-    // the same camera at different times and share its map words in L2 (8 B of tables per pixel against 1 B of
-    // image).  Plain cameras with the early-out: strip-fastest, neighbouring tiles of one image run together and the
-    // halo lines they share are fetched once (measured 0.264 -> 0.219 ms per 384 images; 0.457 -> 0.489 ms if used
-    // for the remapped variant).  MOCAP_STRIP_ORDER=0/1 overrides.
-    a.strip_fastest = (!remap && a.skip_allow >= 0) ? 1 : 0;
+    // Block order: time-fastest, so that concurrently resident blocks work on the same tile of the same camera at
+    // different times and share its map words in L2 (8 B of tables per pixel against 1 B of image).  Strip-fastest
+    // (neighbouring tiles of one image together; MOCAP_STRIP_ORDER=1) fetches fewer bytes when every tile is filtered.
+    a.strip_fastest = 0;
     { const char* e = getenv("MOCAP_STRIP_ORDER"); if (e) a.strip_fastest = atoi(e) != 0; }
     a.spans = c->spans ? c->spans + (size_t)slot_base * tiling(c).n_strips * c->H : nullptr;
-    a.bright = c->bright; a.bright_pitch = bright_pitch(c); a.bright_rows = bright_rows(c);
-    a.regions = c->regions ? c->regions + (size_t)slot_base * tl.n_cgroups * 4 * tl.n_strips : nullptr;
+    const bool own_mask = mask == c->mask; // the context's mask keeps "zero unless filtered" from batch to batch
+    a.tile_flags = c->tile_flags; a.fill_dark = own_mask ? 0 : 1;
     EvPair p; bool on;
-    if (a.skip_allow >= 0) { // one streaming pass over the frames: bright-pixel counts per 8x8 cell
-        BrightArgs b{a.src, a.image_stride, a.pitch, a.H, a.W, n_images, c->bright, a.bright_pitch,
-                     mask, (size_t)n_images * c->H * c->wpr, ((uintptr_t)mask & 15) == 0};
+    if (a.skip_allow >= 0) { // one streaming pass over the frames marks the tiles that can hold set pixels
+        BrightArgs b{a.src, a.image_stride, a.pitch, a.H, a.W, n_images, cam_mod, a.skip_allow / 4, allow_cut1 / 4, allow_cut2 / 4,
+                     c->hull + (size_t)slot_base * source_cells(c), c->tile_flags, tl.n_cgroups * 4, tl.n_strips,
+                     mask, own_mask ? 0 : (size_t)n_images * c->H * c->wpr, ((uintptr_t)mask & 15) == 0};
         prof_begin(c, 3, s, p, on);
         launch_bright_cells(b, s);
         prof_end(c, 3, s, p, on);
@@ -458,6 +499,13 @@ static int run_contours(mocap_ctx* c, const uint32_t* mask, const uint32_t* cell
     a.max_steps = ms > (1 << 22) ? (1 << 22) : (int)ms;
     Tiling tl = tiling(c);
     a.cells = cells; a.rows_per_chunk = tl.rows; a.n_chunks = tl.n_cgroups * 4; a.n_strips = tl.n_strips;
+    if ((size_t)n_images > c->cwork_images) {
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (c->cwork) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c->cwork)); c->cwork = nullptr; c->cwork_images = 0; }
+        HIP_TRY(hipMalloc(&c->cwork, contour_work_bytes() * (size_t)n_images));
+        c->cwork_images = n_images;
+    }
+    a.work = c->cwork;
     a.timing = nullptr;
     static const bool phase_timing = getenv("MOCAP_CONTOUR_TIMING") && atoi(getenv("MOCAP_CONTOUR_TIMING")) != 0;
     if (phase_timing) { // debugging aid: synchronous, prints the mean duration of the kernel's phases
@@ -501,10 +549,10 @@ static int ensure_mask(mocap_ctx* c, int n_images)
     HIP_TRY(hipMalloc(&c->cells, cbytes));
     HIP_TRY(hipMemset(c->cells, 0, cbytes));
     c->cells_images = n_images;
-    if (c->bright) { HIP_TRY(hipFree(c->bright)); c->bright = nullptr; }
-    size_t bbytes = (size_t)n_images * bright_rows(c) * bright_pitch(c);
-    HIP_TRY(hipMalloc(&c->bright, bbytes));
-    HIP_TRY(hipMemset(c->bright, 0, bbytes));
+    if (c->tile_flags) { HIP_TRY(hipFree(c->tile_flags)); c->tile_flags = nullptr; }
+    size_t fbytes = (size_t)n_images * cells_per_image(c);
+    HIP_TRY(hipMalloc(&c->tile_flags, fbytes));
+    HIP_TRY(hipMemset(c->tile_flags, 0, fbytes));
     return 0;
 }
 
@@ -515,8 +563,14 @@ int mocap_filter_mask(mocap_ctx_t c, const void* frames, int n_images, int cam_m
     if (rc) return rc;
     if (!mask_dev) return fail(MOCAP_E_INVALID, "null mask");
     if (set_device(c)) return MOCAP_E_HIP;
-    if ((rc = ensure_mask(c, n_images))) return rc; // for the occupancy cells, which always live in the context
-    return run_filter(c, frames, n_images, cam_mod, slot_base, image_stride, pitch, mask_dev, c->cells, (hipStream_t)stream);
+    if ((rc = ensure_mask(c, n_images))) return rc; // for the tile flags
+    if ((size_t)n_images > c->cells_ext_images) { // occupancy words of a caller-owned mask: never mixed with the context's own
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (c->cells_ext) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c->cells_ext)); c->cells_ext = nullptr; c->cells_ext_images = 0; }
+        HIP_TRY(hipMalloc(&c->cells_ext, sizeof(uint32_t) * (size_t)n_images * cells_per_image(c)));
+        c->cells_ext_images = n_images;
+    }
+    return run_filter(c, frames, n_images, cam_mod, slot_base, image_stride, pitch, mask_dev, c->cells_ext, (hipStream_t)stream);
 }
 
 int mocap_contours_from_mask(mocap_ctx_t c, const uint32_t* mask_dev, int n_images, int32_t* out_xy, long xy_stride,
@@ -592,7 +646,7 @@ int mocap_image_filter_u8(mocap_ctx_t c, const void* src, void* dst, int spitch,
     a.remap_mode = slot >= 0 ? c->slot_mode[slot] : 0;
     a.strip_fastest = 0;
     a.skip_allow = -1; // single-image convenience path: no early-out
-    a.bright = nullptr; a.bright_pitch = 0; a.bright_rows = 0; a.regions = nullptr;
+    a.tile_flags = nullptr; a.fill_dark = 1;
     a.spans = (slot >= 0 && c->spans) ? c->spans + (size_t)slot * tiling(c).n_strips * c->H : nullptr;
     a.thr_mul = ithresh + 1;
     Tiling tl = tiling(c);

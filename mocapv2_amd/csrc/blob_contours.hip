@@ -9,17 +9,21 @@
 //     the raster-minimum of the border it lies on;
 //   * a hole border starts at the foreground pixel left of a background pixel whose W and N neighbours are
 //     foreground and that is the raster-minimum of the left-side cracks of the border.
-// Candidates are found with word-parallel bit tests on the mask.  Each candidate is then followed by ONE WAVE:
-// the wave keeps a 64 x 64 pixel window of the mask in registers (one 64-bit row per lane), the walker state
-// (position, direction, the three rows around the current pixel, the integer Green's-theorem sums) is
-// wave-uniform and lives in scalar registers, rows enter the scalar cache through v_readlane -- so a border step
-// costs a few dozen scalar instructions instead of a round trip to memory per neighbour probe.  The step itself is
-// literally the reference border-following step (same neighbour order, same CHAIN_APPROX_SIMPLE vertex rule);
-// a candidate is dropped as soon as it meets an earlier pixel of its own border.  The polygon sums are exact
-// integers (int64), the perimeter is a sum of float32 square roots held exactly in a double.
+// Candidates are found with word-parallel bit tests on the mask, guided by the occupancy words the filter kernel
+// leaves per tile.  Each candidate is then followed by ONE LANE: the lane keeps the three 64-column mask rows around
+// its current pixel in registers (a vertical move loads one new row through L1/L2), the walker state and the
+// integer Green's-theorem sums are per-lane registers, so the 64 lanes of a wave follow 64 borders at once and an
+// image needs only one small workgroup -- thousands of images are in flight on the chip at the same time, which is
+// what a batch of sparse IR frames needs (a border walk is a serial chain of ~150 instructions per step, so the
+// kernel is bound by how many walks run concurrently, not by any one of them).  The step itself is literally the
+// reference border-following step (same neighbour order, same CHAIN_APPROX_SIMPLE vertex rule); a candidate is
+// dropped as soon as it meets an earlier pixel of its own border.  The polygon sums are exact integers (int64),
+// the perimeter is a sum of float32 square roots held exactly in a double.
 // Tree order (parent = enclosing border, siblings in reverse discovery order, pre-order walk) is rebuilt from
-// "which border owns the crack left of my start pixel", found by following that border once.
-// One workgroup (16 waves) per image; the mask is 1/8 B per pixel and is read through L2.
+// "which border owns the crack left of my start pixel": from the bounding boxes when that is unambiguous, else by
+// following that border once.
+// One workgroup of 4 waves per image; the full border records live in a per-image global workspace (L2), the small
+// per-border fields the tree phases need in LDS (~13 KB per workgroup); the mask is 1/8 B per pixel, read through L2.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "kernels.h"
@@ -46,26 +50,25 @@ struct Mask {
     }
 };
 
-// 64 x 64 window of the mask held by one wave: lane r has row y0 + r, bit c of its 64-bit word is column x0 + c.
-struct Window {
-    uint32_t lo, hi; // per lane
-    int x0, y0;      // wave-uniform
-    __device__ void load(const Mask& M, int nx0, int ny0, int lane)
-    {
-        x0 = nx0; y0 = ny0;
-        int y = y0 + lane;
-        int k0 = x0 >> 5, sh = x0 & 31; // arithmetic shift = floor for negative x0
-        uint32_t w0 = M.word(y, k0), w1 = M.word(y, k0 + 1), w2 = M.word(y, k0 + 2);
-        lo = sh ? (w0 >> sh) | (w1 << (32 - sh)) : w0;
-        hi = sh ? (w1 >> sh) | (w2 << (32 - sh)) : w1;
+// columns x0 .. x0+63 of row y as a 64-bit word (bit c = column x0 + c), zero outside the image; per lane and
+// branch-free: the three words are loaded from clamped in-image positions and zeroed by select
+__device__ __forceinline__ uint64_t row64(const Mask& M, int y, int x0)
+{
+    const int k0 = x0 >> 5; // arithmetic shift = floor for negative x0
+    const uint32_t sh = (uint32_t)x0 & 31u;
+    const int yc = y < 0 ? 0 : (y > M.H - 1 ? M.H - 1 : y);
+    const uint32_t* __restrict__ rowp = M.w + (uint32_t)yc * (uint32_t)M.wpr;
+    const bool yin = (unsigned)y < (unsigned)M.H;
+    uint32_t w[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const int k = k0 + i, kc = k < 0 ? 0 : (k > M.wpr - 1 ? M.wpr - 1 : k);
+        const uint32_t keep = (yin && (unsigned)k < (unsigned)M.wpr) ? 0xffffffffu : 0u;
+        w[i] = rowp[kc] & keep; // an AND, not a select: the load stays unconditional (no branch around it)
     }
-    // the 64-bit row `r` (must be inside the window) as a wave-uniform value
-    __device__ __forceinline__ uint64_t row(int r) const
-    {
-        uint32_t a = __builtin_amdgcn_readlane(lo, r - y0), b = __builtin_amdgcn_readlane(hi, r - y0);
-        return ((uint64_t)b << 32) | a;
-    }
-};
+    const uint32_t lo = __builtin_amdgcn_alignbit(w[1], w[0], sh), hi = __builtin_amdgcn_alignbit(w[2], w[1], sh);
+    return ((uint64_t)hi << 32) | lo;
+}
 
 // step of direction code s (0=E 1=NE 2=N 3=NW 4=W 5=SW 6=S 7=SE), from packed 2-bit tables (value + 1) so that the
 // scalar walker needs no memory access per step
@@ -90,40 +93,38 @@ __device__ __forceinline__ double run_length(int s, int k)
     return (double)__fsqrt_rn(q);
 }
 
-// Border following by one wave.  Follows the border through pixel (sx,sy) whose neighbour in direction `first`
+// Border following by one LANE.  Follows the border through pixel (sx,sy) whose neighbour in direction `first`
 // (4 = W for an outer start, 0 = E for a hole start) is background.  Aborts when a border pixel with raster index
-// < abort_fg or an East-side background pixel with raster index < abort_ebg is met.  Every argument and every
-// field of T is wave-uniform.
+// < abort_fg or an East-side background pixel with raster index < abort_ebg is met.  Every lane of a wave follows
+// its own border: the walker state, the three 64-column mask rows around the current pixel and all sums live in
+// the lane's registers; a vertical move loads one new row (three mask words through L1/L2), a move near the edge of
+// the 64-column window re-centres it.
 //
 // The polygon sums are accumulated per border step: splitting a straight polygon edge at the pixels it passes
 // through leaves a00, a10, a01 unchanged (they are exact line integrals), so no vertex list is needed.  The
-// perimeter needs the CHAIN_APPROX_SIMPLE segments: axis-parallel runs add their integer length, diagonal runs of
-// k steps are counted in a per-wave LDS histogram (`diag`, 64 bins) and turned into float32 sqrt(2k^2) terms once
-// at the end -- every term is a float32 >= 1, so their double sum is exact in any order.
-__device__ void follow(const Mask& M, int sx, int sy, int first, int top_start, int abort_fg, int abort_ebg,
-                       int max_steps, Trace& T, int lane, uint32_t* diag)
+// perimeter needs the CHAIN_APPROX_SIMPLE segments: axis-parallel runs add their integer length, a diagonal run of
+// k steps adds the float32 sqrt(2k^2) -- every term is a float32 >= 1 and the total stays far below 2^29, so the
+// double sum is exact in any order.
+__device__ __forceinline__ void follow(const Mask& M, int sx, int sy, int first, int abort_fg, int abort_ebg, int max_steps,
+                                       Trace& T, const double* diag_len)
 {
-    T.a00 = T.a10 = T.a01 = 0;
-    T.per = 0.0;
-    T.npts = T.steps = 0;
+    int64_t a00 = 0, a10 = 0, a01 = 0;
+    int npts = 0, steps = 0;
+    int min_fg = sy * M.RS + sx, min_ebg = 0x7fffffff;
+    int bx0 = sx, bx1 = sx, by0 = sy, by1 = sy;
     T.status = 0;
-    T.min_fg = sy * M.RS + sx;
-    T.min_ebg = 0x7fffffff;
-    T.bx0 = T.bx1 = sx; T.by0 = T.by1 = sy;
-    diag[lane] = 0u;
+    T.per = 0.0;
 
-    Window win;
-    // a raster-first start sits on the top row of its border: put it near the top of the window
-    win.load(M, sx - 31, top_start ? sy - 2 : sy - 31, lane);
+    int x0 = sx - 31; // window columns x0 .. x0+63
     int x = sx, y = sy;
-    uint64_t rU = win.row(y - 1), rM = win.row(y), rD = win.row(y + 1);
+    uint64_t rU = row64(M, y - 1, x0), rM = row64(M, y, x0), rD = row64(M, y + 1, x0);
 
     // occupancy of the 8 neighbours of (x,y), bit s = direction code s (0=E 1=NE 2=N 3=NW 4=W 5=SW 6=S 7=SE)
     auto nbr8 = [&]() -> uint32_t {
-        int c = x - win.x0 - 1; // column x-1 at bit 0
-        uint32_t up = (uint32_t)(rU >> c) & 7u, mid = (uint32_t)(rM >> c) & 7u, dn = (uint32_t)(rD >> c) & 7u;
-        return ((mid >> 2) & 1u) | (((up >> 2) & 1u) << 1) | (((up >> 1) & 1u) << 2) | ((up & 1u) << 3) |
-               ((mid & 1u) << 4) | ((dn & 1u) << 5) | (((dn >> 1) & 1u) << 6) | (((dn >> 2) & 1u) << 7);
+        const int c = x - x0 - 1; // column x-1 at bit 0
+        const uint32_t up = (uint32_t)(rU >> c) & 7u, mid = (uint32_t)(rM >> c) & 7u, dn = (uint32_t)(rD >> c) & 7u;
+        const uint32_t up_rev = (0x73516240u >> (4u * up)) & 7u; // bit order NE, N, NW = columns x+1, x, x-1
+        return (mid >> 2) | (up_rev << 1) | ((mid & 1u) << 4) | (dn << 5);
     };
 
     uint32_t n = nbr8();
@@ -132,39 +133,39 @@ __device__ void follow(const Mask& M, int sx, int sy, int first, int top_start, 
         s = (s - 1) & 7;
     } while (!((n >> s) & 1u) && s != s_end);
     if (s == s_end) { // isolated pixel: one vertex, zero area, zero perimeter
-        T.npts = 1;
-        T.min_ebg = sy * M.RS + sx + 1;
+        T.a00 = T.a10 = T.a01 = 0;
+        T.npts = 1; T.steps = 0;
+        T.min_fg = min_fg; T.min_ebg = sy * M.RS + sx + 1;
+        T.bx0 = T.bx1 = sx; T.by0 = T.by1 = sy;
         return;
     }
     const int i1x = sx + dir_dx(s), i1y = sy + dir_dy(s);
     int prev_s = s ^ 4;       // direction of the step that will close the border (arrives at the start)
     int run = 0;              // steps taken in direction prev_s since the last vertex
-    int first_len = -1;       // length of the run leaving the start when the start is not a vertex (merged at the end)
-    long axis = 0;            // total length of the axis-parallel segments
-    double extra = 0.0;       // diagonal runs too long for the histogram
+    int first_len = 0;        // length of the run leaving the start when the start is not a vertex (merged at the end)
+    int axis = 0;             // total length of the axis-parallel segments
+    double diag = 0.0;        // total length of the diagonal segments
     auto close_run = [&](int dir, int k) {
-        if (k == 0) return;
-        if (!(dir & 1)) axis += k;
-        else if (k < 64) { if (lane == 0) atomicAdd(&diag[k], 1u); }
-        else extra += run_length(dir, k);
+        if (dir & 1) diag += k < 64 ? diag_len[k] : run_length(dir, k); // diag_len[0] = 0
+        else axis += k;
     };
+    int status = 0;
     for (;;) {
         s_end = s;
         // first occupied neighbour counter-clockwise from s_end+1
-        uint32_t rot = ((n | (n << 8)) >> (s_end + 1)) & 0xffu;
-        int u = s_end + 1 + (__ffs((int)rot) - 1);
-        s = u & 7;
-        int r = y * M.RS + x;
-        if ((unsigned)(s - 1) < (unsigned)s_end) { // the East neighbour was examined and is background
-            T.min_ebg = r + 1 < T.min_ebg ? r + 1 : T.min_ebg;
-            if (r + 1 < abort_ebg) { T.status = 1; return; }
-        }
-        T.min_fg = r < T.min_fg ? r : T.min_fg;
-        if (r < abort_fg) { T.status = 1; return; }
+        const uint32_t rot = ((n | (n << 8)) >> (s_end + 1)) & 0xffu;
+        s = (s_end + __ffs((int)rot)) & 7;
+        const int r = y * M.RS + x;
+        const bool east_bg = (unsigned)(s - 1) < (unsigned)s_end; // the East neighbour was examined and is background
+        const int re = east_bg ? r + 1 : 0x7fffffff;
+        min_ebg = re < min_ebg ? re : min_ebg;
+        min_fg = r < min_fg ? r : min_fg;
+        if (re < abort_ebg || r < abort_fg) { status = 1; break; }
         if (s != prev_s) { // (x,y) is a CHAIN_APPROX_SIMPLE vertex
-            if (T.npts == 0 && T.steps > 0) first_len = run; // the start was not a vertex: its run is closed at the end
-            else close_run(prev_s, run);
-            T.npts++;
+            const bool open_start = npts == 0 && steps > 0; // the start was not a vertex: its run is closed at the end
+            first_len = open_start ? run : first_len;
+            close_run(prev_s, open_start ? 0 : run);
+            npts++;
             prev_s = s;
             run = 0;
         }
@@ -172,39 +173,40 @@ __device__ void follow(const Mask& M, int sx, int sy, int first, int top_start, 
         const int dx = dir_dx(s), dy = dir_dy(s);
         const int nx = x + dx, ny = y + dy;
         const int cross = x * dy - dx * y; // x*ny - nx*y
-        T.a00 += cross;
-        T.a10 += (int64_t)cross * (2 * x + dx);
-        T.a01 += (int64_t)cross * (2 * y + dy);
-        T.steps++;
+        a00 += cross;
+        a10 += (int64_t)cross * (2 * x + dx);
+        a01 += (int64_t)cross * (2 * y + dy);
+        steps++;
         if (nx == sx && ny == sy && x == i1x && y == i1y) break;
-        if (T.steps > max_steps) { T.status = 2; return; }
-        T.bx0 = nx < T.bx0 ? nx : T.bx0; T.bx1 = nx > T.bx1 ? nx : T.bx1;
-        T.by0 = ny < T.by0 ? ny : T.by0; T.by1 = ny > T.by1 ? ny : T.by1;
+        if (steps > max_steps) { status = 2; break; }
+        bx0 = nx < bx0 ? nx : bx0; bx1 = nx > bx1 ? nx : bx1;
+        by0 = ny < by0 ? ny : by0; by1 = ny > by1 ? ny : by1;
         // move, keeping the three cached rows around the current pixel
-        int lx = nx - win.x0, ly = ny - win.y0;
-        if (lx < 1 || lx > 62 || ly < 1 || ly > 62) { // left the window: re-centre it on the new pixel
-            win.load(M, nx - 31, ny - 31, lane);
-            rU = win.row(ny - 1); rM = win.row(ny); rD = win.row(ny + 1);
-        } else if (ny > y) {
-            rU = rM; rM = rD; rD = win.row(ny + 1);
-        } else if (ny < y) {
-            rD = rM; rM = rU; rU = win.row(ny - 1);
+        const int lx = nx - x0;
+        if (lx < 1 || lx > 62) { // left the window: re-centre it on the new pixel (rare)
+            x0 = nx - 31;
+            rU = row64(M, ny - 1, x0); rM = row64(M, ny, x0); rD = row64(M, ny + 1, x0);
+        } else if (dy != 0) {
+            const uint64_t nw = row64(M, ny + dy, x0);
+            const bool down = dy > 0;
+            const uint64_t oU = rU, oM = rM, oD = rD;
+            rU = down ? oM : nw;
+            rM = down ? oD : oU;
+            rD = down ? nw : oM;
         }
         x = nx; y = ny;
         s = (s + 4) & 7;
         n = nbr8();
     }
+    T.status = status;
+    if (status) return;
     // the run that arrives at the start, merged with the run that left it when the start is not a vertex
-    close_run(prev_s, run + (first_len > 0 ? first_len : 0));
-    // perimeter: integer part + histogram of diagonal runs (bin k = runs of k steps), reduced over the wave
-    double term = 0.0;
-    {
-        uint32_t cnt = diag[lane];
-        if (lane >= 1 && cnt) term = (double)cnt * run_length(1, lane);
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) term += __shfl_xor(term, d);
-    T.per = (double)axis + extra + term;
+    close_run(prev_s, run + first_len);
+    T.a00 = a00; T.a10 = a10; T.a01 = a01;
+    T.npts = npts; T.steps = steps;
+    T.min_fg = min_fg; T.min_ebg = min_ebg;
+    T.bx0 = bx0; T.bx1 = bx1; T.by0 = by0; T.by1 = by1;
+    T.per = (double)axis + diag;
 }
 
 // reference lib/ImageOperations.py:43-65 for one contour
@@ -233,26 +235,38 @@ __device__ void select_contour(ContourRec& r, double min_area, double min_circ)
 
 } // namespace
 
-constexpr int NTHREADS = 1024, NWAVES = NTHREADS / 64;
+constexpr int NTHREADS = 256, NWAVES = NTHREADS / 64;
+
+// per-image workspace in global memory (L2-resident): the full border records and the ancestor paths of the kept ones
+struct ContourWork {
+    ContourRec recs[MAXR];
+    int32_t kept_path[MAXK][MAXD];
+};
 
 __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
 {
     __shared__ uint32_t cand[MAXC];
-    __shared__ ContourRec recs[MAXR];
-    __shared__ int16_t kept_idx[MAXK];
-    __shared__ int32_t kept_path[MAXK][MAXD];
-    __shared__ int8_t kept_depth[MAXK];
-    __shared__ uint16_t cell_list[MAXCELL];
-    __shared__ uint32_t diag_hist[NWAVES][64]; // per-wave histogram of diagonal run lengths (see follow)
-    __shared__ int16_t rbox[MAXR][4];          // bounding box of each border: x0, y0, x1, y1
+    // phase A: cell_list (uint16 [MAXCELL]); afterwards: rbox (int16 [MAXR][4]), kept_idx (int16 [MAXK]), kept_depth (int8 [MAXK])
+    __shared__ __attribute__((aligned(8))) uint8_t scratch[MAXCELL * 2];
+    static_assert(MAXR * 8 + MAXK * 2 + MAXK <= MAXCELL * 2, "scratch overlay");
+    __shared__ int32_t rkey[MAXR];                 // per border: discovery key, start pixel, kind, links
+    __shared__ int16_t rsx[MAXR], rsy[MAXR], rlink[MAXR], rparent[MAXR];
+    __shared__ uint8_t rhole[MAXR], rkept[MAXR];
     __shared__ int ncand, nrec, nkept, err, ncell;
+    __shared__ double diag_len[64]; // float32 length of a diagonal run of k steps, as a double
+    uint16_t* const cell_list = (uint16_t*)scratch;
+    int16_t (*const rbox)[4] = (int16_t (*)[4])scratch;          // bounding box of each border: x0, y0, x1, y1
+    int16_t* const kept_idx = (int16_t*)(scratch + MAXR * 8);
+    int8_t* const kept_depth = (int8_t*)(scratch + MAXR * 8 + MAXK * 2);
 
     const int image = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = uni(tid >> 6);
     Mask M{a.mask + (size_t)image * a.H * a.words_per_row, a.words_per_row, a.H, a.W, a.W + 1};
+    ContourWork& work = ((ContourWork*)a.work)[image];
     int32_t* const out_count = a.out_count + (size_t)image * a.count_stride;
     if (tid == 0) { ncand = 0; nrec = 0; nkept = 0; err = 0; ncell = 0; }
+    if (tid < 64) diag_len[tid] = run_length(1, tid);
     // optional phase clock (MOCAP_CONTOUR_TIMING=1, a debugging aid): 100 MHz ticks at the phase boundaries
     uint64_t* const tick = a.timing ? a.timing + (size_t)image * 8 : nullptr;
     auto stamp = [&](int i) { if (tick && tid == 0) tick[i] = wall_clock64(); };
@@ -269,22 +283,25 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
         const int R = a.rows_per_chunk, NS = a.n_strips, NCH = a.n_chunks;
         const int gpc = (R + 7) >> 3;                       // 8-row groups per chunk
         const uint32_t* cells = a.cells ? a.cells + (size_t)image * NCH * NS : nullptr;
-        auto occupied = [&](int ch, int st, int g) -> bool { // wave-divergent is fine: plain loads
-            if (!cells) return true;
-            if (ch < 0 || st < 0) return false;
-            return (cells[ch * NS + st] >> g) & 1u;
-        };
         const int n_cells = NCH * NS * gpc;
         if (cells) {
-            for (int cell = tid; cell < n_cells; cell += NTHREADS) {
-                int g = cell % gpc, st = (cell / gpc) % NS, ch = cell / (gpc * NS);
-                int ytop = ch * R + 8 * g;
-                if (ytop >= a.H || 8 * g >= R) continue;
-                bool scan = occupied(ch, st, g) || occupied(ch, st - 1, g) ||
-                            (g > 0 ? occupied(ch, st, g - 1) : occupied(ch - 1, st, gpc - 1));
-                if (!scan) continue;
-                int slot = atomicAdd(&ncell, 1);
-                if (slot < MAXCELL) cell_list[slot] = (uint16_t)cell;
+            // one task = one (chunk, strip) occupancy word: its own groups, and the groups its right and lower
+            // neighbours must scan because of it
+            for (int t = tid; t < NCH * NS; t += NTHREADS) {
+                const int ch = t / NS, st = t - ch * NS;
+                if (ch * R >= a.H) continue;
+                const uint32_t own = cells[t] & 0x7fffffffu;
+                const uint32_t left = st > 0 ? cells[t - 1] & 0x7fffffffu : 0u;
+                const uint32_t up = ch > 0 ? cells[t - NS] & 0x7fffffffu : 0u;
+                uint32_t scan = own | left | (own << 1) | ((up >> (gpc - 1)) & 1u);
+                scan &= (1u << gpc) - 1u;
+                while (scan) {
+                    const int g = __ffs((int)scan) - 1;
+                    scan &= scan - 1;
+                    if (ch * R + 8 * g >= a.H || 8 * g >= R) continue;
+                    const int slot = atomicAdd(&ncell, 1);
+                    if (slot < MAXCELL) cell_list[slot] = (uint16_t)((ch * NS + st) * gpc + g);
+                }
             }
             __syncthreads();
             if (ncell > MAXCELL && tid == 0) atomicMax(&err, 4);
@@ -355,34 +372,44 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
         return;
     }
 
-    // ---- phase B: one wave follows one candidate; the raster-first ones become records ---------------------------
+    // ---- phase B: one lane follows one candidate; the raster-first ones become records ---------------------------
     const int nc = ncand;
-    for (int c = wv; c < nc; c += NWAVES) {
-        uint32_t v = (uint32_t)uni((int)cand[c]);
-        int is_hole = (v >> 15) & 1, x = v & 0x7fff, y = v >> 16;
-        int key = y * M.RS + x;
-        Trace T;
-        if (!is_hole) follow(M, x, y, 4, 1, key, -1, a.max_steps, T, lane, diag_hist[wv]);
-        else follow(M, x - 1, y, 0, 0, -1, key, a.max_steps, T, lane, diag_hist[wv]);
-        if (T.status == 2 && lane == 0) atomicMax(&err, 1);
-        if (T.status != 0) continue;
-        int slot = 0;
-        if (lane == 0) slot = atomicAdd(&nrec, 1);
-        slot = uni(slot);
-        if (slot >= MAXR) continue;
-        if (lane == 0) {
-            ContourRec& r = recs[slot];
-            r.key = key; r.is_hole = is_hole;
-            r.sx = x - is_hole; r.sy = y;
-            r.npts = T.npts; r.steps = T.steps;
-            r.a00 = T.a00; r.a10 = T.a10; r.a01 = T.a01;
-            r.area = fabs((double)T.a00 * 0.5);
-            r.perimeter = T.npts > 1 ? T.per : 0.0;
-            r.link = -1; r.parent = -1; r.order = -1;
-            select_contour(r, a.min_area, a.min_circ);
-            rbox[slot][0] = (int16_t)T.bx0; rbox[slot][1] = (int16_t)T.by0;
-            rbox[slot][2] = (int16_t)T.bx1; rbox[slot][3] = (int16_t)T.by1;
+    {   // The walks read the mask rows below each start one row at a time, each a cache line nobody on this XCD has
+        // touched yet.  Touch them all at once first: per candidate, the 64 rows from the start downwards (one per lane).
+        uint32_t warm = 0;
+        for (int c = wv; c < nc; c += NWAVES) {
+            const uint32_t v = cand[c];
+            const int x = v & 0x7fff, y = v >> 16, k0 = (x - 32) >> 5;
+            warm |= M.word(y + lane, k0) | M.word(y + lane, k0 + 2);
         }
+        asm volatile("" ::"v"(warm)); // keeps the loads (their values are not needed)
+    }
+    for (int c = tid; c < nc; c += NTHREADS) {
+        const uint32_t v = cand[c];
+        const int is_hole = (v >> 15) & 1, x = v & 0x7fff, y = v >> 16;
+        const int key = y * M.RS + x;
+        Trace T;
+        if (!is_hole) follow(M, x, y, 4, key, -1, a.max_steps, T, diag_len);
+        else follow(M, x - 1, y, 0, -1, key, a.max_steps, T, diag_len);
+        if (T.status == 2) atomicMax(&err, 1);
+        if (T.status != 0) continue;
+        const int slot = atomicAdd(&nrec, 1);
+        if (slot >= MAXR) continue;
+        ContourRec r;
+        r.key = key; r.is_hole = is_hole;
+        r.sx = x - is_hole; r.sy = y;
+        r.npts = T.npts; r.steps = T.steps;
+        r.a00 = T.a00; r.a10 = T.a10; r.a01 = T.a01;
+        r.area = fabs((double)T.a00 * 0.5);
+        r.perimeter = T.npts > 1 ? T.per : 0.0;
+        r.link = -1; r.parent = -1; r.order = -1;
+        select_contour(r, a.min_area, a.min_circ);
+        work.recs[slot] = r;
+        rkey[slot] = key; rsx[slot] = (int16_t)r.sx; rsy[slot] = (int16_t)y;
+        rhole[slot] = (uint8_t)is_hole; rkept[slot] = (uint8_t)r.kept;
+        rlink[slot] = -1; rparent[slot] = -1;
+        rbox[slot][0] = (int16_t)T.bx0; rbox[slot][1] = (int16_t)T.by0;
+        rbox[slot][2] = (int16_t)T.bx1; rbox[slot][3] = (int16_t)T.by1;
     }
     __syncthreads();
     stamp(2);
@@ -394,9 +421,10 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
     // ---- phase C1: link = the border that owns the crack met when scanning left from the start ------------------
     //   outer border: nearest foreground pixel left of the start on the same row -> its East crack
     //   hole border : left end of the foreground run holding the start pixel     -> its West crack
+    // One wave per border (wave-uniform control flow).
     const int nr = nrec;
     for (int c = wv; c < nr; c += NWAVES) {
-        const int r_is_hole = uni(recs[c].is_hole), r_sx = uni(recs[c].sx), y = uni(recs[c].sy);
+        const int r_is_hole = rhole[c], r_sx = rsx[c], y = rsy[c];
         // hole: nearest background pixel at/left of the start; outer: nearest foreground pixel left of it.
         // The words of the row up to that column are examined 64 at a time, one per lane, right to left.
         const int xs = r_is_hole ? r_sx : r_sx - 1;
@@ -415,7 +443,7 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
                 break;
             }
         }
-        if (qx < 0) { if (lane == 0) recs[c].link = -1; continue; } // nothing to the left: the frame
+        if (qx < 0) continue; // nothing to the left: the frame (link stays -1)
         // The crack's owner passes through pixel (qx, y), so its bounding box contains it, and it is never this
         // border itself (its pixels are all raster-later than its start).  If exactly one other border's box
         // contains the pixel, that border is the owner; only otherwise is the owner found by following it.
@@ -432,21 +460,21 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
             if (hits == 1) found = which;
         }
         if (found == -2) {
-            Trace T;
-            follow(M, qx, y, r_is_hole ? 4 : 0, 0, -1, -1, a.max_steps, T, lane, diag_hist[wv]);
+            Trace T; // every lane walks the same border (uniform arguments): rare path
+            follow(M, qx, y, r_is_hole ? 4 : 0, -1, -1, a.max_steps, T, diag_len);
             if (T.status) { if (lane == 0) atomicMax(&err, 1); continue; }
             int ltype = T.a00 > 0 ? 1 : 0; // hole borders run the other way round
             int lkey = ltype ? T.min_ebg : T.min_fg;
             for (int jb = 0; jb < nr; jb += 64) {
                 int j = jb + lane;
-                bool hit = j < nr && recs[j].key == lkey && recs[j].is_hole == ltype;
+                bool hit = j < nr && rkey[j] == lkey && rhole[j] == ltype;
                 uint64_t bal = __ballot(hit);
                 if (bal) { found = jb + __ffsll((long long)bal) - 1; break; }
             }
         }
         if (lane == 0) {
             if (found == -2) atomicMax(&err, 2);
-            recs[c].link = found;
+            rlink[c] = (int16_t)found;
         }
     }
     __syncthreads();
@@ -457,22 +485,22 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
     }
 
     // ---- phase C2: parents (Suzuki's table: same kind -> the link's parent, else the link itself) -----------
-    for (int c = tid; c < nrec; c += NTHREADS) {
-        int me = recs[c].is_hole, j = recs[c].link, guard = 0;
-        while (j >= 0 && recs[j].is_hole == me && guard++ < MAXR) j = recs[j].link;
-        recs[c].parent = j;
+    for (int c = tid; c < nr; c += NTHREADS) {
+        int me = rhole[c], j = rlink[c], guard = 0;
+        while (j >= 0 && rhole[j] == me && guard++ < MAXR) j = rlink[j];
+        rparent[c] = (int16_t)j;
     }
     __syncthreads();
-    for (int c = tid; c < nrec; c += NTHREADS) {
-        if (!recs[c].kept) continue;
+    for (int c = tid; c < nr; c += NTHREADS) {
+        if (!rkept[c]) continue;
         int slot = atomicAdd(&nkept, 1);
         if (slot >= MAXK) continue;
         kept_idx[slot] = (int16_t)c;
         int chain[MAXD], d = 0, j = c;
-        while (j >= 0 && d < MAXD) { chain[d++] = recs[j].key; j = recs[j].parent; }
+        while (j >= 0 && d < MAXD) { chain[d++] = rkey[j]; j = rparent[j]; }
         if (j >= 0) { atomicMax(&err, 3); d = MAXD; }
         kept_depth[slot] = (int8_t)d;
-        for (int i = 0; i < d; i++) kept_path[slot][i] = chain[d - 1 - i]; // root first
+        for (int i = 0; i < d; i++) work.kept_path[slot][i] = chain[d - 1 - i]; // root first
     }
     __syncthreads();
     if (err || nkept > MAXK) {
@@ -486,14 +514,14 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
         for (int o = 0; o < nkept; o++) {
             if (o == c) continue;
             int db = kept_depth[o], l = 0;
-            while (l < da && l < db && kept_path[c][l] == kept_path[o][l]) l++;
+            while (l < da && l < db && work.kept_path[c][l] == work.kept_path[o][l]) l++;
             bool other_first;
             if (l == db) other_first = true;        // the other one is my ancestor
             else if (l == da) other_first = false;  // I am its ancestor
-            else other_first = kept_path[o][l] > kept_path[c][l]; // later discovery comes first
+            else other_first = work.kept_path[o][l] > work.kept_path[c][l]; // later discovery comes first
             rank += other_first;
         }
-        ContourRec& r = recs[kept_idx[c]];
+        ContourRec& r = work.recs[kept_idx[c]];
         r.order = rank;
         if (rank < a.max_blobs) {
             int32_t* o = a.out_xy + (size_t)image * a.xy_stride + (size_t)rank * 2;
@@ -504,10 +532,16 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
     stamp(4);
     if (a.dbg) {
         __syncthreads(); // the records' order fields are written by other threads just above
-        for (int c = tid; c < nrec && c < a.dbg_cap; c += NTHREADS) a.dbg[(size_t)image * a.dbg_cap + c] = recs[c];
-        if (tid == 0) a.dbg_count[image] = nrec;
+        for (int c = tid; c < nr && c < a.dbg_cap; c += NTHREADS) {
+            ContourRec r = work.recs[c];
+            r.link = rlink[c]; r.parent = rparent[c];
+            a.dbg[(size_t)image * a.dbg_cap + c] = r;
+        }
+        if (tid == 0) a.dbg_count[image] = nr;
     }
 }
+
+size_t contour_work_bytes() { return sizeof(ContourWork); }
 
 void launch_contours(const ContourArgs& a, hipStream_t s)
 {

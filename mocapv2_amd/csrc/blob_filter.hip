@@ -262,43 +262,37 @@ __device__ __forceinline__ uint32_t ldsr_combine(const LTaps& t, const LaneCols&
 // lie inside some 2x2 block of 8x8-pixel cells of a fixed grid.  Hence: if no such block of the tile's source region
 // holds more than `allow` bright pixels (allow from the inequality above with the smallest tap count, computed on
 // the host), every threshold bit of the tile is 0, so is the majority, and the tile's mask rows are zero -- without
-// running the filter.  The scan below reads every source byte of the tile once (the algorithmic traffic).
+// running the filter.  The test is made per cell: no cell of the region with more than hot = allow / 4 bright pixels.
 __device__ __forceinline__ uint32_t bright_count(uint32_t v)
 { // number of bytes >= 64
     return (uint32_t)__popc(((v | (v << 1)) & 0x80808080u));
 }
-// 2x2 block test at the end of a cell row; `cell` = this lane's cell count (0 for lanes without a cell), cells are
-// `stride` lanes apart.  Returns true if some block (this cell row + the previous one) exceeds `allow`.
-__device__ __forceinline__ bool block_exceeds(uint32_t cell, uint32_t& prev2, int stride, int lane, int allow)
-{
-    uint32_t right = (uint32_t)__shfl_down((int)cell, stride);
-    if (lane + stride > 63) right = 0;
-    uint32_t cur2 = cell + right;
-    bool hit = (int)(cur2 + prev2) > allow;
-    prev2 = cur2;
-    return __ballot(hit) != 0ull;
-}
 
-// Bright-pixel counts of the fixed 8x8-pixel cell grid of every image: out[image][cell row][cell column] = number of
-// pixels >= 64 in the cell (<= 64).  One pass over the frames at streaming speed -- the only time a dark tile's pixels
-// are read.  A thread counts two cells (16 eight-byte loads in flight); consecutive lanes take consecutive cells of a
-// cell row, so a wave's loads cover 512 contiguous bytes of each of 8 image rows.
+// One streaming pass over the frames -- the only time a dark tile's pixels are read.  A thread counts the pixels >= 64
+// of two cells of the fixed 8x8-pixel grid (16 eight-byte loads in flight; consecutive lanes take consecutive cells of
+// a cell row, so a wave's loads cover 512 contiguous bytes of each of 8 image rows).  A cell with more than `hot`
+// such pixels (4 * hot <= allow, so four dark cells can never exceed the 2x2-block bound above; `hot_edge` and
+// `hot_corner`, from the bounds of the 15- and 9-tap windows, for the cells that feed windows cut by the image
+// border in one axis or in both) marks every filter tile
+// whose source region contains it -- the hull table built at set-up says which -- by storing 1 into the tile's
+// flag byte.  Tiles left unmarked provably filter to zeros.
 __global__ __launch_bounds__(256) void bright_cells_kernel(BrightArgs a)
 {
     const int ncx = (a.W + 7) >> 3, ncy = (a.H + 7) >> 3, n = ncx * ncy;
     const int image = blockIdx.y;
     const uint8_t* __restrict__ img = a.src + (size_t)image * a.image_stride;
-    uint8_t* __restrict__ out = a.out + (size_t)image * ncy * a.out_pitch;
     const int i0 = blockIdx.x * 512 + threadIdx.x;
     uint2 v[2][8];
-    int cr[2], cx[2];
+    int ci[2], cr[2];
     uint32_t sh[2];
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         int i = i0 + 256 * u;
-        i = i < n ? i : n - 1; // threads past the end recount the last cell and store the same value again
-        cr[u] = i / ncx; cx[u] = i - cr[u] * ncx;
-        const int c = 8 * cx[u], cc = c < a.W - 8 ? c : a.W - 8; // W >= 8 (checked on the host)
+        i = i < n ? i : n - 1; // threads past the end recount the last cell (and mark the same tiles again)
+        ci[u] = i;
+        cr[u] = i / ncx;
+        const int cx = i - cr[u] * ncx;
+        const int c = 8 * cx, cc = c < a.W - 8 ? c : a.W - 8; // W >= 8 (checked on the host)
         sh[u] = (uint32_t)(8 * (c - cc));
 #pragma unroll
         for (int j = 0; j < 8; j++) {
@@ -307,6 +301,9 @@ __global__ __launch_bounds__(256) void bright_cells_kernel(BrightArgs a)
             __builtin_memcpy(&v[u][j], img + ((uint32_t)r * (uint32_t)a.pitch + (uint32_t)cc), 8);
         }
     }
+    const int slot = image % a.cam_mod;
+    const uint2* __restrict__ hull = a.hull + (size_t)slot * n;
+    uint8_t* __restrict__ flags = a.flags + (size_t)image * a.n_chunks * a.n_strips;
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         uint32_t acc = 0;
@@ -316,18 +313,27 @@ __global__ __launch_bounds__(256) void bright_cells_kernel(BrightArgs a)
             uint32_t cnt = bright_count((uint32_t)vv) + bright_count((uint32_t)(vv >> 32));
             if (8 * cr[u] + j < a.H) acc += cnt;
         }
-        out[(uint32_t)cr[u] * (uint32_t)a.out_pitch + (uint32_t)cx[u]] = (uint8_t)acc;
+        if ((int)acc > a.hot_corner) { // rare: a few cells per marker
+            // x = first | last << 16 chunk, y = first | last << 16 strip (first > last: none); bits 31 / 30 of y: the
+            // cell feeds windows cut by the image border in both axes / in one axis (fewer taps, smaller bound)
+            const uint2 h = hull[ci[u]];
+            if ((int)acc > ((h.y >> 31) ? a.hot_corner : ((h.y >> 30) & 1u) ? a.hot_edge : a.hot))
+                for (int ch = (int)(h.x & 0xffffu); ch <= (int)(h.x >> 16); ch++)
+                    for (int st = (int)(h.y & 0xffffu); st <= (int)((h.y >> 16) & 0x3fffu); st++) flags[ch * a.n_strips + st] = 1;
+        }
     }
-    // side job while the loads are in flight elsewhere: clear the bit masks of the batch (16 bytes per thread and
-    // round), so that the filter kernel only writes the tiles it actually filters
-    const size_t nthreads = (size_t)gridDim.x * gridDim.y * 256;
-    const size_t g = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
-    if (a.mask_aligned16) {
-        const size_t quads = a.mask_words >> 2;
-        for (size_t q = g; q < quads; q += nthreads) ((uint4*)a.mask)[q] = make_uint4(0u, 0u, 0u, 0u);
-        if (g < (a.mask_words & 3)) a.mask[(quads << 2) + g] = 0u;
-    } else {
-        for (size_t q = g; q < a.mask_words; q += nthreads) a.mask[q] = 0u;
+    if (a.mask_words) {
+        // caller-owned masks: clear them on the side (16 bytes per thread and round), the filter kernel then only
+        // writes the tiles it filters.  The context's own mask needs no clearing (see the filter kernel).
+        const size_t nthreads = (size_t)gridDim.x * gridDim.y * 256;
+        const size_t g = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+        if (a.mask_aligned16) {
+            const size_t quads = a.mask_words >> 2;
+            for (size_t q = g; q < quads; q += nthreads) ((uint4*)a.mask)[q] = make_uint4(0u, 0u, 0u, 0u);
+            if (g < (a.mask_words & 3)) a.mask[(quads << 2) + g] = 0u;
+        } else {
+            for (size_t q = g; q < a.mask_words; q += nthreads) a.mask[q] = 0u;
+        }
     }
 }
 
@@ -395,50 +401,28 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
 
     if (a.skip_allow >= 0) {
         // ---- dark-tile early-out (see the comment above bright_count): first thing a wave does ----
-        const int allow = a.skip_allow;
-        // source region of the tile: rows [s_lo, s_hi], columns [x_lo, x_hi] (all inside the image)
-        int s_lo, s_hi, x_lo, x_hi;
-        if (REMAP) { // from the undistort table, precomputed per (slot, chunk, strip) at set-up
-            const int4 rg = a.regions[((size_t)slot * a.n_cgroups * 4 + (cgroup * 4 + wv)) * a.n_strips + strip];
-            x_lo = rg.x; x_hi = rg.y; s_lo = rg.z; s_hi = rg.w;
-        } else {     // the plain path's source region is the tile's own input
-            const int last = (ke > kfirst ? ke : kfirst) + 2;
-            s_lo = kfirst - 2 < 0 ? 0 : kfirst - 2; s_hi = last > Hm1 ? Hm1 : last;
-            x_lo = xbase < 0 ? 0 : xbase; x_hi = xbase + 255 > a.W - 1 ? a.W - 1 : xbase + 255;
-        }
-        // 2x2-block sums over the cells (8x8 px, counted whole by bright_cells_kernel) the region touches:
-        // lane = cell column, up to 16 cell rows per round of loads
-        const int cx0 = x_lo >> 3, ncols = (x_hi >> 3) - cx0 + 1, cr0 = s_lo >> 3, cr1 = s_hi >> 3;
-        bool bright = false;
-        if (ncols > 64 || x_hi < x_lo || s_hi < s_lo) bright = true; // wider than one wave covers / empty: no early-out
-        else {
-            const bool act = lane < ncols;
-            const uint8_t* bc = a.bright + (size_t)image * a.bright_rows * a.bright_pitch + (uint32_t)(cx0 + (act ? lane : 0));
-            uint32_t prev2 = 0;
-            bool hit = false;
-            for (int cb = cr0; cb <= cr1; cb += 16) {
-                uint32_t cnt[16];
-#pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    int cr = cb + j < cr1 ? cb + j : cr1;
-                    cnt[j] = bc[(uint32_t)cr * (uint32_t)a.bright_pitch];
-                }
-#pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    uint32_t v = (act && cb + j <= cr1) ? cnt[j] : 0u;
-                    uint32_t right = lane_from_next(v);
-                    if (lane == 63) right = 0;
-                    uint32_t cur2 = v + right;
-                    hit |= (int)(cur2 + prev2) > allow;
-                    if (cb + j <= cr1) prev2 = cur2;
+        // bright_cells_kernel has marked every tile whose source region holds a hot cell.  An unmarked tile is all
+        // zeros.  The context's mask keeps the invariant "a tile's mask bytes are zero unless its occupancy word has
+        // bit 31 set" from batch to batch, so a dark tile only has to be cleared if it was filtered last time.
+        const uint32_t flag = a.tile_flags[cell_index];
+        if (!__builtin_amdgcn_readfirstlane((int)flag)) {
+            const uint32_t old = a.fill_dark ? 0x80000000u : a.cells[cell_index];
+            if (__builtin_amdgcn_readfirstlane((int)old) < 0) {
+                uint8_t* mrow = (uint8_t*)(a.mask + (size_t)image * a.H * a.words_per_row);
+                const int rb = a.words_per_row * 4;
+                const int half = lane >> 5, pair = lane & 31, byte0 = strip * 30 + 2 * pair, nb = (a.W + 7) >> 3;
+                if (pair < 15 && byte0 < nb) {
+                    for (int i = half; i < r1 - r0; i += 2) {
+                        uint8_t* dst = mrow + (size_t)(r0 + i) * rb + byte0;
+                        if (byte0 + 1 < nb) *(uint16_t*)dst = 0; // byte0 is even: aligned
+                        else *dst = 0;
+                    }
                 }
             }
-            bright = __ballot(hit) != 0ull;
-        }
-        if (!bright) { // all-zero tile: the mask was cleared by bright_cells_kernel; publish an empty occupancy word
             if (lane == 0) a.cells[cell_index] = 0u;
             return;
         }
+        if (lane == 0) a.tile_flags[cell_index] = 0; // ready for the next batch
     }
 
     // lut[w]: byte k = number of set bits among bits k..k+4 of the 8-bit window w.  Every wave that filters writes the
@@ -912,6 +896,9 @@ __global__ void remap_stats_kernel(StatArgs a)
     if (x >= a.W || y >= a.H) return;
     atomicMax(&a.stats[0], a.acc[(size_t)y * a.W + x]);
     int x0 = 0x7fff, x1 = -1, y0 = 0x7fff, y1 = -1; // extent of the nonzero-weight taps of the 5x5 window around (x,y)
+    // windows cut by the image border have fewer than 25 taps, hence a smaller bound: their source cells are marked
+    const uint32_t cut = ((x < 2 || x >= a.W - 2) ? 1u : 0u) + ((y < 2 || y >= a.H - 2) ? 1u : 0u); // axes cut: 0, 1, 2
+    const int ncx = (a.W + 7) >> 3;
     for (int dy = -2; dy <= 2; dy++)
         for (int dx = -2; dx <= 2; dx++) {
             int xx = x + dx, yy = y + dy;
@@ -922,6 +909,9 @@ __global__ void remap_stats_kernel(StatArgs a)
             if ((c0 || c1) && (r0 || r1)) {
                 int lo = c0 ? sx : sx + 1, hi = c1 ? sx + 1 : sx, lo2 = r0 ? sy : sy + 1, hi2 = r1 ? sy + 1 : sy;
                 x0 = lo < x0 ? lo : x0; x1 = hi > x1 ? hi : x1; y0 = lo2 < y0 ? lo2 : y0; y1 = hi2 > y1 ? hi2 : y1;
+                if (cut)
+                    for (int cy = lo2 >> 3; cy <= hi2 >> 3; cy++)
+                        for (int cx = lo >> 3; cx <= hi >> 3; cx++) atomicOr(&a.edge[cy * ncx + cx], cut);
             }
         }
     if (x1 >= x0) { atomicMax(&a.stats[1], (uint32_t)(x1 - x0 + 1)); atomicMax(&a.stats[2], (uint32_t)(y1 - y0 + 1)); }

@@ -21,9 +21,10 @@ struct FilterArgs {
     int remap_mode;       // 0 plain / 2 per-pixel gather, 3 pipelined gather, 4 LDS-staged
     int skip_allow;       // dark-tile early-out: a tile whose source region has no 16x16 block (2x2 cells of 8x8 px)
                           //   with more than this many pixels >= 64 provably yields an all-zero mask; -1 = off
-    const uint8_t* bright; // [n_images][bright_rows][bright_pitch] pixels >= 64 per 8x8 cell (bright_cells_kernel); used if skip_allow >= 0
-    int bright_pitch, bright_rows;
-    const int4* regions;  // remap variant: [cam_mod][n_cgroups*4][n_strips] source region (x_lo, x_hi, s_lo, s_hi) of each tile
+    uint8_t* tile_flags;  // [n_images][n_cgroups*4][n_strips] (indexed like cells): 1 = bright_cells_kernel found a hot cell in
+                          //   the tile's source region; read and reset by the filter kernel; used if skip_allow >= 0
+    int fill_dark;        // 1 = dark tiles always write their zeros (caller-owned mask); 0 = only if the tile's previous
+                          //   occupancy word says it was filtered (the context's own mask, see the kernel)
     int strip_fastest;    // block order: 1 = neighbouring strips share an XCD in time, 0 = time steps of a tile do
     int cam_mod;          // undistort slot of image n = n % cam_mod (map already points at the first slot)
     int n_images, n_steps; // n_steps = ceil(n_images / cam_mod)
@@ -69,6 +70,7 @@ struct ContourArgs {
     const uint32_t* cells; // occupancy written by the filter kernel (see FilterArgs), or null = scan every row
     int rows_per_chunk, n_chunks, n_strips;
     uint64_t* timing;      // optional [n_images][8] phase clock (debugging aid), else null
+    void* work;            // [n_images] per-image workspace of contour_work_bytes() each
 };
 
 enum { BLOB_ERR_CANDIDATES = -2, BLOB_ERR_CONTOURS = -3, BLOB_ERR_STEPS = -4, BLOB_ERR_DEPTH = -5 };
@@ -76,20 +78,27 @@ enum { BLOB_ERR_CANDIDATES = -2, BLOB_ERR_CONTOURS = -3, BLOB_ERR_STEPS = -4, BL
 void launch_filter_mask(const FilterArgs& a, bool remap, hipStream_t s);
 struct BrightArgs {
     const uint8_t* src; size_t image_stride; int pitch, H, W, n_images; // W >= 8
-    uint8_t* out; int out_pitch;                                         // cell counts [n_images][ceil(H/8)][out_pitch]
-    uint32_t* mask; size_t mask_words; int mask_aligned16;               // the batch's bit masks, cleared on the side
+    int cam_mod;                  // undistort slot of image n = n % cam_mod (hull already points at the first slot)
+    int hot, hot_edge, hot_corner; // a cell with more than this many pixels >= 64 is hot (4 * hot <= skip_allow); _edge /
+                                  //   _corner for cells feeding windows the image border cuts in one axis / in both
+    const uint2* hull;            // [cam_mod][cells]: tiles whose source region contains the cell (see mocap_set_undistort)
+    uint8_t* flags; int n_chunks, n_strips; // tile flags, see FilterArgs
+    uint32_t* mask; size_t mask_words; int mask_aligned16; // caller-owned bit masks to clear on the side (mask_words = 0: none)
 };
 void launch_bright_cells(const BrightArgs& a, hipStream_t s);
 struct SpanArgs { const uint32_t* map; uint2* spans; int H, W, n_strips; };
 // set-up statistics of an undistort table, for the dark-tile bound: stats[0] = largest total blend weight any source
 // pixel carries over all output pixels (1024 = one full pixel), stats[1] / stats[2] = largest x / y extent (in source
-// pixels) of the taps feeding one 5x5 output window.  acc: H*W zero-initialised scratch words.
-struct StatArgs { const uint32_t* map; const uint32_t* mapw; uint32_t* acc; uint32_t* stats; int H, W; };
+// pixels) of the taps feeding one 5x5 output window.  acc: H*W zero-initialised scratch words.  edge: zero-initialised
+// [ceil(H/8)][ceil(W/8)] words, bit 0 / bit 1 set for the 8x8 source cells read by windows that the image border cuts
+// in exactly one axis / in both.
+struct StatArgs { const uint32_t* map; const uint32_t* mapw; uint32_t* acc; uint32_t* stats; int H, W; uint32_t* edge; };
 void launch_remap_stats(const StatArgs& a, hipStream_t s);
 void launch_remap_spans(const SpanArgs& a, hipStream_t s);
 constexpr int RING_H = 32, RING_W = 288, RING_LOOKAHEAD = 5; // LDS source-row ring of the staged remap (per wave)
 void launch_undistort_map(const MapArgs& m, hipStream_t s);
 void launch_contours(const ContourArgs& a, hipStream_t s);
+size_t contour_work_bytes();
 void launch_box_blur(const uint8_t* src, uint8_t* dst, int H, int W, int sp, int dp, int ksize, hipStream_t s);
 void launch_undistort(const uint8_t* src, uint8_t* dst, int H, int W, int sp, int dp, const uint32_t* map, const uint32_t* mapw,
                       hipStream_t s);

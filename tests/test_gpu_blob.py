@@ -1,4 +1,6 @@
 """Parity of the HIP blob path (through the C-ABI) with the CPU oracle: bit-exact masks, contours, centroids."""
+import os
+
 import numpy as np
 import pytest
 
@@ -229,3 +231,60 @@ def test_dark_tile_early_out_is_exact(torch_cuda, monkeypatch, scale, salt, nois
         for i in range(3):
             assert np.array_equal(got[i], exp[i]), (skip, i, np.argwhere(got[i] != exp[i])[:4])
     assert exp[0].any()
+
+
+@pytest.mark.parametrize("scale", [0.0, 1.0])
+def test_context_mask_stays_consistent_across_batches(torch_cuda, scale):
+    """The context's own mask is not cleared between batches: a tile filtered in one batch and dark in the next must
+    be cleared on demand, a tile dark twice must stay untouched.  Batches with discs in different places, an all-dark
+    batch, a shorter batch and a run with the early-out switched off are interleaved; every result must equal the
+    oracle's _find_dot on the same frames."""
+    torch = torch_cuda
+    from mocapv2_amd.engine import MocapContext
+    W, H = 960, 540
+    sc = Scene(1, width=W, height=H, dist=np.array(MILD_DIST) * scale)
+    ctx = MocapContext(W, H, n_slots=1)
+    ctx.set_undistort(0, sc.K, sc.dist)
+    rng = np.random.default_rng(77)
+    batches = [dark_frames(rng, 4, H, W, n_discs=4, salt=0.001) for _ in range(3)]
+    batches.insert(2, rng.integers(0, 50, (4, H, W), dtype=np.uint8))     # nothing bright at all
+    batches.append(batches[0][:2])                                         # fewer images than before
+    batches.append(dark_frames(rng, 4, H, W, n_discs=6, salt=0.0))
+    seen = 0
+    for b, frames in enumerate(batches):
+        if b == 4:
+            os.environ["MOCAP_SKIP_DARK"] = "0"
+        try:
+            xy, cnt = ctx.record_views(ctx.blob_centroids(torch.from_numpy(frames).cuda()))
+        finally:
+            os.environ.pop("MOCAP_SKIP_DARK", None)
+        xy, cnt = xy.cpu().numpy(), cnt.cpu().numpy()
+        for i in range(len(frames)):
+            exp = oracle.find_dot(frames[i], sc.K, sc.dist)
+            assert cnt[i] == len(exp), (b, i, cnt[i], exp)
+            assert xy[i, :cnt[i]].tolist() == exp, (b, i)
+            seen += len(exp)
+    assert seen > 10
+
+
+def test_mixed_identity_and_remapped_cameras_in_one_batch(torch_cuda):
+    """cam_mod = 2 with one undistorted and one identity camera: both take the same launch (and the early-out)."""
+    torch = torch_cuda
+    from mocapv2_amd.engine import MocapContext
+    W, H = 640, 360
+    sc = Scene(2, width=W, height=H, dist=MILD_DIST)
+    ctx = MocapContext(W, H, n_slots=2)
+    ctx.set_undistort(0, sc.K, sc.dist)
+    ctx.set_undistort(1, sc.K, ZERO_DIST)
+    rng = np.random.default_rng(5)
+    frames = dark_frames(rng, 6, H, W, n_discs=3, salt=0.001)
+    xy, cnt = ctx.record_views(ctx.blob_centroids(torch.from_numpy(frames).cuda(), cam_mod=2))
+    xy, cnt = xy.cpu().numpy(), cnt.cpu().numpy()
+    total = 0
+    for i in range(6):
+        exp = oracle.find_dot(frames[i], sc.K, sc.dist if i % 2 == 0 else np.array(ZERO_DIST))
+        assert cnt[i] == len(exp) and xy[i, :cnt[i]].tolist() == exp, i
+        total += len(exp)
+    assert total > 0
+    tiles, skipped = ctx.tile_stats()
+    assert 0 < skipped < tiles
