@@ -51,7 +51,8 @@ struct mocap_ctx {
     uint32_t* mask; size_t mask_images;
     uint32_t* cells; size_t cells_images; // occupancy cells written by the filter kernel for c->mask
     int last_images;                       // images of the most recent batch that wrote c->cells
-    uint8_t* tile_flags;                   // [mask_images][tiles] hot-cell marks, beside cells (see FilterArgs)
+    uint32_t* tile_rows;                   // [mask_images][tiles][2] reachable mask rows per tile, beside cells (see FilterArgs)
+    uint16_t* dil;                         // [n_slots][tiles] vertical reach of a source row per tile (see BrightArgs)
     uint32_t* cells_ext; size_t cells_ext_images; // occupancy words of caller-owned masks (mocap_filter_mask)
     void* cwork; size_t cwork_images;      // contour kernel workspace, contour_work_bytes() per image
     CameraTable* cams; int n_cam, n_F;
@@ -139,7 +140,7 @@ int mocap_ctx_create(int device_id, int width, int height, int n_slots, mocap_ct
     mocap_ctx* c = new mocap_ctx();
     c->device = device_id; c->W = width; c->H = height; c->n_slots = n_slots; c->wpr = (width + 31) / 32;
     c->prm = mocap_blob_params{5, 5, 255 * 0.85, 500.0, 0.5};
-    c->maps = nullptr; c->spans = nullptr; c->hull = nullptr; c->cells_ext = nullptr; c->cells_ext_images = 0; c->map_flags = nullptr; c->mask = nullptr; c->mask_images = 0; c->cells = nullptr; c->cells_images = 0; c->last_images = 0; c->tile_flags = nullptr; c->cwork = nullptr; c->cwork_images = 0;
+    c->maps = nullptr; c->spans = nullptr; c->hull = nullptr; c->cells_ext = nullptr; c->cells_ext_images = 0; c->map_flags = nullptr; c->mask = nullptr; c->mask_images = 0; c->cells = nullptr; c->cells_images = 0; c->last_images = 0; c->tile_rows = nullptr; c->dil = nullptr; c->cwork = nullptr; c->cwork_images = 0;
     c->cams = nullptr; c->n_cam = 0; c->n_F = 0; c->scratch = nullptr; c->scratch_elems = 0; c->profiling = false;
     c->slot_state.assign(n_slots, 0);
     c->slot_mode.assign(n_slots, 2);
@@ -168,7 +169,8 @@ int mocap_ctx_destroy(mocap_ctx_t c)
     if (c->map_flags) (void)hipFree(c->map_flags);
     if (c->mask) (void)hipFree(c->mask);
     if (c->cells) (void)hipFree(c->cells);
-    if (c->tile_flags) (void)hipFree(c->tile_flags);
+    if (c->tile_rows) (void)hipFree(c->tile_rows);
+    if (c->dil) (void)hipFree(c->dil);
     if (c->cwork) (void)hipFree(c->cwork);
     if (c->cams) (void)hipFree(c->cams);
     if (c->scratch) (void)hipFree(c->scratch);
@@ -256,6 +258,7 @@ int mocap_set_undistort(mocap_ctx_t c, int slot, const double K[9], const double
         // marked tile is simply filtered.
         const int H = c->H, W = c->W, Hm1 = H - 1, nch = tl.n_cgroups * 4, ncx = (W + 7) / 8, ncy = (H + 7) / 8;
         std::vector<uint2> hull((size_t)ncx * ncy, make_uint2(0xffffu, 0xffffu)); // first = 0xffff > last = 0: no tile
+        std::vector<uint16_t> dil((size_t)nch * tl.n_strips, 4); // rows a source row can reach: map displacement + blur 2 + median 2
         for (int ch = 0; ch < nch && ch * tl.rows < H; ch++)
             for (int st = 0; st < tl.n_strips; st++) {
                 int r0 = ch * tl.rows, r1 = r0 + tl.rows < H ? r0 + tl.rows : H;
@@ -264,12 +267,18 @@ int mocap_set_undistort(mocap_ctx_t c, int slot, const double K[9], const double
                 int ra = y0 < 0 ? 0 : y0, rb = last > Hm1 ? Hm1 : last;
                 int xmin = 0x7fff, xmax = -1, smin = 0x7fff, smax = -1;
                 if (c->slot_state[slot] == 2) {
+                    int disp = 0; // largest |source row - output row| over the rows the tile consumes
                     for (int y = ra; y <= rb; y++) {
                         uint2 v = sp_host[(size_t)st * H + y];
                         int lo = (int)(v.y & 0xffffu), hi = (int)(v.y >> 16), s0 = (int)(v.x & 0xffffu), s1 = (int)(v.x >> 16);
                         xmin = lo < xmin ? lo : xmin; xmax = hi > xmax ? hi : xmax;
                         smin = s0 < smin ? s0 : smin; smax = s1 > smax ? s1 : smax;
+                        if (s1 >= s0) {
+                            disp = y - s0 > disp ? y - s0 : disp;
+                            disp = s1 - y > disp ? s1 - y : disp;
+                        }
                     }
+                    dil[(size_t)ch * tl.n_strips + st] = (uint16_t)(disp + 4 > 0xffff ? 0xffff : disp + 4);
                 } else {
                     int xbase = st * 240 - 8;
                     xmin = xbase < 0 ? 0 : xbase; xmax = xbase + 255 > W - 1 ? W - 1 : xbase + 255;
@@ -299,6 +308,8 @@ int mocap_set_undistort(mocap_ctx_t c, int slot, const double K[9], const double
                 }
         for (size_t i = 0; i < hull.size(); i++)
             hull[i].y |= (edge[i] & 2u) ? 0x80000000u : (edge[i] & 1u) ? 0x40000000u : 0u;
+        if (!c->dil) HIP_TRY(hipMalloc(&c->dil, sizeof(uint16_t) * dil.size() * c->n_slots));
+        HIP_TRY(hipMemcpy(c->dil + dil.size() * slot, dil.data(), sizeof(uint16_t) * dil.size(), hipMemcpyHostToDevice));
         if (!c->hull) HIP_TRY(hipMalloc(&c->hull, sizeof(uint2) * hull.size() * c->n_slots));
         HIP_TRY(hipMemcpy(c->hull + hull.size() * slot, hull.data(), sizeof(uint2) * hull.size(), hipMemcpyHostToDevice));
     }
@@ -450,7 +461,7 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
         const long long per_tap = 1024LL * (2LL * a.thr_mul - 127);
         int allow = -1;
         allow_cut1 = allow_cut2 = -1;
-        if (c->W < 8 || !c->tile_flags || !c->hull) ok = false;
+        if (c->W < 8 || !c->tile_rows || !c->hull || !c->dil) ok = false;
         if (ok && wmax > 0 && per_tap > 0) {
             allow = (int)((per_tap * t5full(c->W) * t5full(c->H) - 1) / (2LL * 192 * wmax)); // windows with all their taps
             const long long taps1 = t5(c->W) * t5full(c->H) < t5full(c->W) * t5(c->H) ? t5(c->W) * t5full(c->H) : t5full(c->W) * t5(c->H);
@@ -468,11 +479,12 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
     { const char* e = getenv("MOCAP_STRIP_ORDER"); if (e) a.strip_fastest = atoi(e) != 0; }
     a.spans = c->spans ? c->spans + (size_t)slot_base * tiling(c).n_strips * c->H : nullptr;
     const bool own_mask = mask == c->mask; // the context's mask keeps "zero unless filtered" from batch to batch
-    a.tile_flags = c->tile_flags; a.fill_dark = own_mask ? 0 : 1;
+    a.tile_rows = c->tile_rows; a.fill_dark = own_mask ? 0 : 1;
     EvPair p; bool on;
     if (a.skip_allow >= 0) { // one streaming pass over the frames marks the tiles that can hold set pixels
         BrightArgs b{a.src, a.image_stride, a.pitch, a.H, a.W, n_images, cam_mod, a.skip_allow / 4, allow_cut1 / 4, allow_cut2 / 4,
-                     c->hull + (size_t)slot_base * source_cells(c), c->tile_flags, tl.n_cgroups * 4, tl.n_strips,
+                     c->hull + (size_t)slot_base * source_cells(c), c->tile_rows, tl.n_cgroups * 4, tl.n_strips,
+                     c->dil + (size_t)slot_base * cells_per_image(c),
                      mask, own_mask ? 0 : (size_t)n_images * c->H * c->wpr, ((uintptr_t)mask & 15) == 0};
         prof_begin(c, 3, s, p, on);
         launch_bright_cells(b, s);
@@ -549,10 +561,13 @@ static int ensure_mask(mocap_ctx* c, int n_images)
     HIP_TRY(hipMalloc(&c->cells, cbytes));
     HIP_TRY(hipMemset(c->cells, 0, cbytes));
     c->cells_images = n_images;
-    if (c->tile_flags) { HIP_TRY(hipFree(c->tile_flags)); c->tile_flags = nullptr; }
-    size_t fbytes = (size_t)n_images * cells_per_image(c);
-    HIP_TRY(hipMalloc(&c->tile_flags, fbytes));
-    HIP_TRY(hipMemset(c->tile_flags, 0, fbytes));
+    if (c->tile_rows) { HIP_TRY(hipFree(c->tile_rows)); c->tile_rows = nullptr; }
+    {   // every tile starts with the empty range (0xffffffff, 0)
+        std::vector<uint32_t> init((size_t)n_images * cells_per_image(c) * 2);
+        for (size_t i = 0; i < init.size(); i += 2) { init[i] = 0xffffffffu; init[i + 1] = 0u; }
+        HIP_TRY(hipMalloc(&c->tile_rows, sizeof(uint32_t) * init.size()));
+        HIP_TRY(hipMemcpy(c->tile_rows, init.data(), sizeof(uint32_t) * init.size(), hipMemcpyHostToDevice));
+    }
     return 0;
 }
 
@@ -646,7 +661,7 @@ int mocap_image_filter_u8(mocap_ctx_t c, const void* src, void* dst, int spitch,
     a.remap_mode = slot >= 0 ? c->slot_mode[slot] : 0;
     a.strip_fastest = 0;
     a.skip_allow = -1; // single-image convenience path: no early-out
-    a.tile_flags = nullptr; a.fill_dark = 1;
+    a.tile_rows = nullptr; a.fill_dark = 1;
     a.spans = (slot >= 0 && c->spans) ? c->spans + (size_t)slot * tiling(c).n_strips * c->H : nullptr;
     a.thr_mul = ithresh + 1;
     Tiling tl = tiling(c);

@@ -274,8 +274,10 @@ __device__ __forceinline__ uint32_t bright_count(uint32_t v)
 // such pixels (4 * hot <= allow, so four dark cells can never exceed the 2x2-block bound above; `hot_edge` and
 // `hot_corner`, from the bounds of the 15- and 9-tap windows, for the cells that feed windows cut by the image
 // border in one axis or in both) marks every filter tile
-// whose source region contains it -- the hull table built at set-up says which -- by storing 1 into the tile's
-// flag byte.  Tiles left unmarked provably filter to zeros.
+// whose source region contains it -- the hull table built at set-up says which -- by widening the tile's range of
+// reachable mask rows (atomic min / max; `dil` = how far, in rows, a source row of the tile's region can act on the
+// mask: the largest vertical displacement of the undistort map over the tile + 4 rows of blur and median).  Tiles
+// left unmarked, and rows outside the range, provably filter to zeros.
 __global__ __launch_bounds__(256) void bright_cells_kernel(BrightArgs a)
 {
     const int ncx = (a.W + 7) >> 3, ncy = (a.H + 7) >> 3, n = ncx * ncy;
@@ -303,7 +305,8 @@ __global__ __launch_bounds__(256) void bright_cells_kernel(BrightArgs a)
     }
     const int slot = image % a.cam_mod;
     const uint2* __restrict__ hull = a.hull + (size_t)slot * n;
-    uint8_t* __restrict__ flags = a.flags + (size_t)image * a.n_chunks * a.n_strips;
+    uint32_t* __restrict__ rows = a.tile_rows + (size_t)image * a.n_chunks * a.n_strips * 2;
+    const uint16_t* __restrict__ dil = a.dil + (size_t)slot * a.n_chunks * a.n_strips;
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         uint32_t acc = 0;
@@ -317,9 +320,15 @@ __global__ __launch_bounds__(256) void bright_cells_kernel(BrightArgs a)
             // x = first | last << 16 chunk, y = first | last << 16 strip (first > last: none); bits 31 / 30 of y: the
             // cell feeds windows cut by the image border in both axes / in one axis (fewer taps, smaller bound)
             const uint2 h = hull[ci[u]];
-            if ((int)acc > ((h.y >> 31) ? a.hot_corner : ((h.y >> 30) & 1u) ? a.hot_edge : a.hot))
+            if ((int)acc > ((h.y >> 31) ? a.hot_corner : ((h.y >> 30) & 1u) ? a.hot_edge : a.hot)) {
+                const int s0 = 8 * cr[u], s1 = s0 + 7 < a.H - 1 ? s0 + 7 : a.H - 1; // source rows of the cell
                 for (int ch = (int)(h.x & 0xffffu); ch <= (int)(h.x >> 16); ch++)
-                    for (int st = (int)(h.y & 0xffffu); st <= (int)((h.y >> 16) & 0x3fffu); st++) flags[ch * a.n_strips + st] = 1;
+                    for (int st = (int)(h.y & 0xffffu); st <= (int)((h.y >> 16) & 0x3fffu); st++) {
+                        const int t = ch * a.n_strips + st, d = (int)dil[t];
+                        atomicMin(&rows[2 * t], (uint32_t)(s0 - d > 0 ? s0 - d : 0));
+                        atomicMax(&rows[2 * t + 1], (uint32_t)(s1 + d < a.H - 1 ? s1 + d : a.H - 1));
+                    }
+            }
         }
     }
     if (a.mask_words) {
@@ -387,43 +396,54 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
     const int image = tstep * a.cam_mod + slot;
     if (image >= a.n_images) return;
 
-    const int r0 = (cgroup * 4 + wv) * a.rows_per_chunk;
-    if (r0 >= a.H) return;
-    const int r1 = r0 + a.rows_per_chunk < a.H ? r0 + a.rows_per_chunk : a.H;
+    const int tile_r0 = (cgroup * 4 + wv) * a.rows_per_chunk; // the tile's mask rows [tile_r0, tile_r1)
+    if (tile_r0 >= a.H) return;
+    const int tile_r1 = tile_r0 + a.rows_per_chunk < a.H ? tile_r0 + a.rows_per_chunk : a.H;
+    int r0 = tile_r0, r1 = tile_r1;                            // the rows this wave filters
+    const int xbase = strip * 240 - 8;
+    const size_t cell_index = ((size_t)image * a.n_cgroups * 4 + (cgroup * 4 + wv)) * a.n_strips + strip;
+
+    if (a.skip_allow >= 0) {
+        // ---- dark-tile early-out (see the comment above bright_count): first thing a wave does ----
+        // bright_cells_kernel has left, per tile, the range of mask rows that hot cells of its source region can reach
+        // (empty = none: the tile is all zeros).  Only those rows are filtered.  The context's mask keeps the
+        // invariant "a tile's mask bytes are zero unless its occupancy word has bit 31 set" from batch to batch, so
+        // rows that are not filtered only have to be cleared if the tile was filtered last time.
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_rows[2 * cell_index]);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_rows[2 * cell_index + 1]);
+        if (lo <= hi) {
+            if (lane == 0) { a.tile_rows[2 * cell_index] = 0xffffffffu; a.tile_rows[2 * cell_index + 1] = 0u; } // ready for the next batch
+            if (!LDSR) { // (the LDS-staged variant's ring schedule is verified for whole tiles only)
+                r0 = (int)lo > r0 ? (int)lo : r0;
+                r1 = (int)hi + 1 < r1 ? (int)hi + 1 : r1;
+            }
+        }
+        const bool dark = lo > hi || r0 >= r1;
+        const uint32_t old = a.fill_dark ? 0x80000000u : a.cells[cell_index];
+        if (__builtin_amdgcn_readfirstlane((int)old) < 0) { // clear what will not be written below
+            uint8_t* mrow = (uint8_t*)(a.mask + (size_t)image * a.H * a.words_per_row);
+            const int rb = a.words_per_row * 4;
+            const int half = lane >> 5, pair = lane & 31, byte0 = strip * 30 + 2 * pair, nb = (a.W + 7) >> 3;
+            if (pair < 15 && byte0 < nb) {
+                for (int row = tile_r0 + half; row < tile_r1; row += 2) {
+                    if (!dark && row >= r0 && row < r1) continue;
+                    uint8_t* dst = mrow + (size_t)row * rb + byte0;
+                    if (byte0 + 1 < nb) *(uint16_t*)dst = 0; // byte0 is even: aligned
+                    else *dst = 0;
+                }
+            }
+        }
+        if (dark) {
+            if (lane == 0) a.cells[cell_index] = 0u;
+            return;
+        }
+    }
 
     const int Hm1 = a.H - 1;
     int kfirst = r0 - 2;
     kfirst = kfirst < 0 ? 0 : (kfirst > Hm1 ? Hm1 : kfirst);
     const int ks = r0 - 1 > 1 ? r0 - 1 : 1;                 // steady range: every iteration slides one source row
     const int ke = r1 + 1 < Hm1 ? r1 + 1 : Hm1;
-    const int xbase = strip * 240 - 8;
-    const size_t cell_index = ((size_t)image * a.n_cgroups * 4 + (cgroup * 4 + wv)) * a.n_strips + strip;
-
-    if (a.skip_allow >= 0) {
-        // ---- dark-tile early-out (see the comment above bright_count): first thing a wave does ----
-        // bright_cells_kernel has marked every tile whose source region holds a hot cell.  An unmarked tile is all
-        // zeros.  The context's mask keeps the invariant "a tile's mask bytes are zero unless its occupancy word has
-        // bit 31 set" from batch to batch, so a dark tile only has to be cleared if it was filtered last time.
-        const uint32_t flag = a.tile_flags[cell_index];
-        if (!__builtin_amdgcn_readfirstlane((int)flag)) {
-            const uint32_t old = a.fill_dark ? 0x80000000u : a.cells[cell_index];
-            if (__builtin_amdgcn_readfirstlane((int)old) < 0) {
-                uint8_t* mrow = (uint8_t*)(a.mask + (size_t)image * a.H * a.words_per_row);
-                const int rb = a.words_per_row * 4;
-                const int half = lane >> 5, pair = lane & 31, byte0 = strip * 30 + 2 * pair, nb = (a.W + 7) >> 3;
-                if (pair < 15 && byte0 < nb) {
-                    for (int i = half; i < r1 - r0; i += 2) {
-                        uint8_t* dst = mrow + (size_t)(r0 + i) * rb + byte0;
-                        if (byte0 + 1 < nb) *(uint16_t*)dst = 0; // byte0 is even: aligned
-                        else *dst = 0;
-                    }
-                }
-            }
-            if (lane == 0) a.cells[cell_index] = 0u;
-            return;
-        }
-        if (lane == 0) a.tile_flags[cell_index] = 0; // ready for the next batch
-    }
 
     // lut[w]: byte k = number of set bits among bits k..k+4 of the 8-bit window w.  Every wave that filters writes the
     // whole table (identical values), so no workgroup barrier is needed and dark waves are gone before this point.
@@ -630,7 +650,7 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
         uint32_t mm = ((Cv + 0x73737373u) >> 7) & 0x01010101u;
         uint32_t t1 = mm | (mm >> 7);
         uint32_t mn = (t1 | (t1 >> 14)) & colmask;
-        lacc |= (mn != 0u ? 1u : 0u) << (((on ? row : r0) - r0) >> 3); // rows not yet valid have mn from a partial window: harmless superset
+        lacc |= (mn != 0u ? 1u : 0u) << (((on ? row : r0) - tile_r0) >> 3); // rows not yet valid have mn from a partial window: harmless superset
         uint32_t odd = lane_from_next(mn);
         uint32_t byte = (mn & 0xfu) | ((odd & 0xfu) << 4);
         // direct byte store: all loads here are global-address-space loads, so the compiler keeps counted vmcnt
@@ -696,7 +716,7 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
     }
     {   // occupancy word of this (strip, chunk): OR of the output lanes' bits
         uint32_t cellmask = 0;
-        const int groups = (r1 - r0 + 7) >> 3;
+        const int groups = (tile_r1 - tile_r0 + 7) >> 3;
         for (int g = 0; g < groups; g++)
             if (__ballot(out_lane && ((lacc >> g) & 1u)) != 0ull) cellmask |= 1u << g;
         // bit 31 marks a tile that went through the full filter (the early-out writes 0); bits 0..16 are the groups

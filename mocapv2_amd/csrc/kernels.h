@@ -21,8 +21,9 @@ struct FilterArgs {
     int remap_mode;       // 0 plain / 2 per-pixel gather, 3 pipelined gather, 4 LDS-staged
     int skip_allow;       // dark-tile early-out: a tile whose source region has no 16x16 block (2x2 cells of 8x8 px)
                           //   with more than this many pixels >= 64 provably yields an all-zero mask; -1 = off
-    uint8_t* tile_flags;  // [n_images][n_cgroups*4][n_strips] (indexed like cells): 1 = bright_cells_kernel found a hot cell in
-                          //   the tile's source region; read and reset by the filter kernel; used if skip_allow >= 0
+    uint32_t* tile_rows;  // [n_images][n_cgroups*4][n_strips][2] (indexed like cells): first / last mask row that hot cells of the
+                          //   tile's source region can reach, (0xffffffff, 0) = none; written by bright_cells_kernel, read and
+                          //   reset by the filter kernel; used if skip_allow >= 0
     int fill_dark;        // 1 = dark tiles always write their zeros (caller-owned mask); 0 = only if the tile's previous
                           //   occupancy word says it was filtered (the context's own mask, see the kernel)
     int strip_fastest;    // block order: 1 = neighbouring strips share an XCD in time, 0 = time steps of a tile do
@@ -82,7 +83,8 @@ struct BrightArgs {
     int hot, hot_edge, hot_corner; // a cell with more than this many pixels >= 64 is hot (4 * hot <= skip_allow); _edge /
                                   //   _corner for cells feeding windows the image border cuts in one axis / in both
     const uint2* hull;            // [cam_mod][cells]: tiles whose source region contains the cell (see mocap_set_undistort)
-    uint8_t* flags; int n_chunks, n_strips; // tile flags, see FilterArgs
+    uint32_t* tile_rows; int n_chunks, n_strips; // reachable mask rows per tile, see FilterArgs
+    const uint16_t* dil;          // [cam_mod][tiles] reach in rows of a source row of the tile's region (see the kernel)
     uint32_t* mask; size_t mask_words; int mask_aligned16; // caller-owned bit masks to clear on the side (mask_words = 0: none)
 };
 void launch_bright_cells(const BrightArgs& a, hipStream_t s);
