@@ -47,11 +47,22 @@ def allgather_records(local, world, group=None):
     return out
 
 
+class _Lane:
+    """One set of per-batch buffers (context scratch, centroid records, outputs) and the HIP stream it works on."""
+
+    def __init__(self, ctx, records, stream):
+        self.ctx, self.records, self.stream, self.out = ctx, records, stream, None
+
+
 class BatchTracker:
-    """Frames -> 3-D marker positions for `steps_per_rank` time steps per call on this rank."""
+    """Frames -> 3-D marker positions for `steps_per_rank` time steps per call on this rank.
+
+    `depth` > 1 software-pipelines consecutive batches: batch k runs on HIP stream k % depth with its own scratch
+    buffers, so the latency-bound tail of one batch (border following, correspondence) overlaps the HBM-bound head of
+    the next (the streaming scan).  Results of a batch are complete once its stream (or the device) is synchronised."""
 
     def __init__(self, K, dist, R, t, F, width, height, steps_per_rank, world=1, rank=0, device=0, group=None,
-                 max_points=32, max_groups=4096):
+                 max_points=32, max_groups=4096, depth=1):
         self.n_cam = len(K)
         self.T = int(steps_per_rank)
         self.world, self.rank, self.group = world, rank, group
@@ -61,18 +72,40 @@ class BatchTracker:
         local_cams = sorted({c for c, _, _ in self.segs})
         self.slot_of = {c: i for i, c in enumerate(local_cams)}
         n_slots = self.n_cam if world == 1 else len(local_cams)
-        self.ctx = MocapContext(width, height, n_slots, device)
-        if world == 1:
-            for c in range(self.n_cam):
-                self.ctx.set_undistort(c, K[c], dist[c])
-        else:
-            for c in local_cams:
-                self.ctx.set_undistort(self.slot_of[c], K[c], dist[c])
-        self.ctx.set_cameras(K, dist, R, t)
-        self.ctx.set_fundamentals(F)
         self.per = self.n_cam * self.T
-        self.records = torch.zeros((self.per, REC_INTS), dtype=torch.int32, device=self.ctx.device)
-        self.out = None
+        self.lanes = []
+        for d in range(max(1, int(depth))):
+            ctx = MocapContext(width, height, n_slots, device)
+            if world == 1:
+                for c in range(self.n_cam):
+                    ctx.set_undistort(c, K[c], dist[c])
+            else:
+                for c in local_cams:
+                    ctx.set_undistort(self.slot_of[c], K[c], dist[c])
+            ctx.set_cameras(K, dist, R, t)
+            ctx.set_fundamentals(F)
+            records = torch.zeros((self.per, REC_INTS), dtype=torch.int32, device=ctx.device)
+            stream = torch.cuda.Stream(device=ctx.device) if depth > 1 else None
+            self.lanes.append(_Lane(ctx, records, stream))
+        self._k = 0
+        self._cur = self.lanes[0]
+
+    # the buffers of the batch most recently submitted
+    @property
+    def ctx(self):
+        return self._cur.ctx
+
+    @property
+    def records(self):
+        return self._cur.records
+
+    @property
+    def out(self):
+        return self._cur.out
+
+    @out.setter
+    def out(self, v):
+        self._cur.out = v
 
     def local_image_list(self):
         """(camera, global time step) of every local image, in the order `step` expects the frames."""
@@ -109,10 +142,40 @@ class BatchTracker:
 
     def step(self, frames):
         """One pass of the hot path over this rank's block: extract -> (all-gather) -> triangulate.  Returns the
-        correspondence outputs (dict of device tensors, see MocapContext.correspond) for this rank's time steps."""
+        correspondence outputs (dict of device tensors, see MocapContext.correspond) for this rank's time steps.
+        With depth > 1 the work is queued on the batch's own stream and the call returns at once."""
+        lane = self.lanes[self._k % len(self.lanes)]
+        self._k += 1
+        self._cur = lane
+        if lane.stream is None:
+            return self._run(frames)
+        lane.stream.wait_stream(torch.cuda.current_stream())  # the frames were produced on the caller's stream
+        with torch.cuda.stream(lane.stream):
+            return self._run(frames)
+
+    def _run(self, frames):
         records = self.extract(frames)
         gathered = allgather_records(records, self.world, self.group)  # [C * T_total, REC] camera-major when world > 1
         return self.triangulate(gathered)
+
+    def synchronize(self):
+        """Wait for every batch submitted so far."""
+        for lane in self.lanes:
+            if lane.stream is not None:
+                lane.stream.synchronize()
+
+    def profile(self, on=True):
+        """HIP-event timing of the kernels of every batch in flight (MocapContext.profile)."""
+        for lane in self.lanes:
+            lane.ctx.profile(on)
+
+    def profile_read(self):
+        """Sums of MocapContext.profile_read over the batches in flight."""
+        total = {}
+        for lane in self.lanes:
+            for k, v in lane.ctx.profile_read().items():
+                total[k] = total.get(k, 0) + v
+        return total
 
 
 def scene_arrays(scene):

@@ -4,12 +4,13 @@
 #include <stdint.h>
 #include <vector>
 
-template <int BYTES, int OFF, int LSTRIDE>
+template <int BYTES, int OFF, int LSTRIDE, int ACTIVE = 64>
 __global__ __launch_bounds__(256) void k(const uint8_t* __restrict__ base, uint32_t* out, int iters, int pitch)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint8_t* p = base + (size_t)(blockIdx.x & 63) * 65536 + wv * 16384 + lane * LSTRIDE + OFF;
     uint32_t acc = 0;
+    if (lane >= ACTIVE) { out[blockIdx.x * 256 + threadIdx.x] = 0; return; }
     for (int it = 0; it < iters; it++) {
         const uint8_t* q = p + (uint32_t)((it & 31) * pitch);
 #pragma unroll
@@ -24,14 +25,14 @@ __global__ __launch_bounds__(256) void k(const uint8_t* __restrict__ base, uint3
     out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
 
-template <int BYTES, int OFF, int LSTRIDE>
+template <int BYTES, int OFF, int LSTRIDE, int ACTIVE = 64>
 void run(const char* name, const uint8_t* buf, uint32_t* out)
 {
     const int blocks = 2048, iters = 512;
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    hipLaunchKernelGGL((k<BYTES, OFF, LSTRIDE>), dim3(blocks), dim3(256), 0, 0, buf, out, 8, 260);
+    hipLaunchKernelGGL((k<BYTES, OFF, LSTRIDE, ACTIVE>), dim3(blocks), dim3(256), 0, 0, buf, out, 8, 260);
     hipEventRecord(a);
-    hipLaunchKernelGGL((k<BYTES, OFF, LSTRIDE>), dim3(blocks), dim3(256), 0, 0, buf, out, iters, 260);
+    hipLaunchKernelGGL((k<BYTES, OFF, LSTRIDE, ACTIVE>), dim3(blocks), dim3(256), 0, 0, buf, out, iters, 260);
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
     double insts = (double)blocks * 4 * iters * 8; // wave-level load instructions
@@ -58,5 +59,9 @@ int main()
     run<16, 0, 16>("u128 stride16 off0", buf, out);
     run<16, 0, 4>("u128 stride4 off0", buf, out);
     run<16, 1, 4>("u128 stride4 off1", buf, out);
+    run<2, 1, 4, 32>("u16 off1, 32 lanes", buf, out);
+    run<2, 1, 4, 16>("u16 off1, 16 lanes", buf, out);
+    run<2, 1, 4, 8>("u16 off1, 8 lanes", buf, out);
+    run<16, 0, 4, 16>("u128 stride4 16 lanes", buf, out);
     return 0;
 }
