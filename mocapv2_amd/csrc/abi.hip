@@ -540,6 +540,17 @@ static int run_contours(mocap_ctx* c, const uint32_t* mask, const uint32_t* cell
             double tot = (double)(t[8 * i + 4] - t[8 * i]); mx = tot > mx ? tot : mx;
             lo = t[8 * i] < lo ? t[8 * i] : lo; hi = t[8 * i + 4] > hi ? t[8 * i + 4] : hi;
         }
+        {
+            int worst = 0; double wt = 0, sc = 0, ss = 0;
+            for (int i = 0; i < n_images; i++) {
+                double tot = (double)(t[8 * i + 4] - t[8 * i]);
+                if (tot > wt) { wt = tot; worst = i; }
+                sc += (double)t[8 * i + 5]; ss += (double)t[8 * i + 6];
+            }
+            fprintf(stderr, "[contours] slowest image %d: %.1f us, candidates %llu, longest border %llu steps, borders %llu | mean candidates %.1f, mean longest border %.1f steps\n",
+                    worst, wt / 100, (unsigned long long)t[8 * worst + 5], (unsigned long long)t[8 * worst + 6], (unsigned long long)t[8 * worst + 7],
+                    sc / n_images, ss / n_images);
+        }
         fprintf(stderr, "[contours] mean us per block: candidates %.1f follow %.1f link %.1f order %.1f | slowest block %.1f | first start to last end %.1f\n",
                 sum[0] / n_images / 100, sum[1] / n_images / 100, sum[2] / n_images / 100, sum[3] / n_images / 100, mx / 100, (double)(hi - lo) / 100);
     }

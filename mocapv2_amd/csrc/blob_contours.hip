@@ -105,8 +105,10 @@ __device__ __forceinline__ double run_length(int s, int k)
 // perimeter needs the CHAIN_APPROX_SIMPLE segments: axis-parallel runs add their integer length, a diagonal run of
 // k steps adds the float32 sqrt(2k^2) -- every term is a float32 >= 1 and the total stays far below 2^29, so the
 // double sum is exact in any order.
+// `win` (optional): 64 rows of the mask from row sy - 1 down, columns sx - 31 .. sx + 32, staged in LDS by the caller;
+// rows are taken from there while the walk stays inside that window's columns.
 __device__ __forceinline__ void follow(const Mask& M, int sx, int sy, int first, int abort_fg, int abort_ebg, int max_steps,
-                                       Trace& T, const double* diag_len)
+                                       Trace& T, const double* diag_len, const uint64_t* win = nullptr)
 {
     int64_t a00 = 0, a10 = 0, a01 = 0;
     int npts = 0, steps = 0;
@@ -117,7 +119,14 @@ __device__ __forceinline__ void follow(const Mask& M, int sx, int sy, int first,
 
     int x0 = sx - 31; // window columns x0 .. x0+63
     int x = sx, y = sy;
-    uint64_t rU = row64(M, y - 1, x0), rM = row64(M, y, x0), rD = row64(M, y + 1, x0);
+    const int wy0 = sy - 1;
+    bool staged = win != nullptr; // the LDS window still matches x0
+    auto fetch = [&](int yy) -> uint64_t {
+        const unsigned r = (unsigned)(yy - wy0);
+        if (staged && r < 64u) return win[r];
+        return row64(M, yy, x0);
+    };
+    uint64_t rU = fetch(y - 1), rM = fetch(y), rD = fetch(y + 1);
 
     // occupancy of the 8 neighbours of (x,y), bit s = direction code s (0=E 1=NE 2=N 3=NW 4=W 5=SW 6=S 7=SE)
     auto nbr8 = [&]() -> uint32_t {
@@ -145,11 +154,13 @@ __device__ __forceinline__ void follow(const Mask& M, int sx, int sy, int first,
     int first_len = 0;        // length of the run leaving the start when the start is not a vertex (merged at the end)
     int axis = 0;             // total length of the axis-parallel segments
     double diag = 0.0;        // total length of the diagonal segments
-    auto close_run = [&](int dir, int k) {
-        if (dir & 1) diag += k < 64 ? diag_len[k] : run_length(dir, k); // diag_len[0] = 0
-        else axis += k;
-    };
+    double pend = 0.0;        // table value fetched in the previous step, added one step later (hides the LDS latency)
+    const int abort_lt = abort_fg > abort_ebg ? abort_fg : abort_ebg; // exactly one of the two is armed (the other is -1)
+    const bool abort_on_fg = abort_fg >= 0;
     int status = 0;
+    // The loop body is written with selects: a lane-divergent branch costs two EXEC updates and their wait states,
+    // a select costs one instruction.  Branches remain only for leaving the loop, for re-centring the window and
+    // for the two row sources.
     for (;;) {
         s_end = s;
         // first occupied neighbour counter-clockwise from s_end+1
@@ -160,16 +171,20 @@ __device__ __forceinline__ void follow(const Mask& M, int sx, int sy, int first,
         const int re = east_bg ? r + 1 : 0x7fffffff;
         min_ebg = re < min_ebg ? re : min_ebg;
         min_fg = r < min_fg ? r : min_fg;
-        if (re < abort_ebg || r < abort_fg) { status = 1; break; }
-        if (s != prev_s) { // (x,y) is a CHAIN_APPROX_SIMPLE vertex
-            const bool open_start = npts == 0 && steps > 0; // the start was not a vertex: its run is closed at the end
-            first_len = open_start ? run : first_len;
-            close_run(prev_s, open_start ? 0 : run);
-            npts++;
-            prev_s = s;
-            run = 0;
-        }
-        run++;
+        // (x,y) is a CHAIN_APPROX_SIMPLE vertex when the direction changes: close the run that ends here
+        const bool vertex = s != prev_s;
+        const bool open_start = vertex && npts == 0 && steps > 0; // the start was not a vertex: its run is closed at the end
+        first_len = open_start ? run : first_len;
+        const int k = (vertex && !open_start) ? run : 0;
+        const bool odd = (prev_s & 1) != 0;
+        axis += odd ? 0 : k;
+        diag += pend;
+        const int kd = odd ? k : 0;                                  // diag_len[0] = 0
+        pend = diag_len[kd < 63 ? kd : 63];
+        if (kd > 63) pend = run_length(1, kd);                        // (a diagonal run longer than the table: rare)
+        npts += vertex ? 1 : 0;
+        prev_s = s;
+        run = vertex ? 1 : run + 1;
         const int dx = dir_dx(s), dy = dir_dy(s);
         const int nx = x + dx, ny = y + dy;
         const int cross = x * dy - dx * y; // x*ny - nx*y
@@ -177,22 +192,26 @@ __device__ __forceinline__ void follow(const Mask& M, int sx, int sy, int first,
         a10 += (int64_t)cross * (2 * x + dx);
         a01 += (int64_t)cross * (2 * y + dy);
         steps++;
-        if (nx == sx && ny == sy && x == i1x && y == i1y) break;
-        if (steps > max_steps) { status = 2; break; }
+        const bool aborted = (abort_on_fg ? r : re) < abort_lt;
+        const bool closed = nx == sx && ny == sy && x == i1x && y == i1y;
+        if (aborted || closed || steps > max_steps) {
+            status = aborted ? 1 : (closed ? 0 : 2);
+            break;
+        }
         bx0 = nx < bx0 ? nx : bx0; bx1 = nx > bx1 ? nx : bx1;
         by0 = ny < by0 ? ny : by0; by1 = ny > by1 ? ny : by1;
         // move, keeping the three cached rows around the current pixel
         const int lx = nx - x0;
         if (lx < 1 || lx > 62) { // left the window: re-centre it on the new pixel (rare)
             x0 = nx - 31;
+            staged = false;
             rU = row64(M, ny - 1, x0); rM = row64(M, ny, x0); rD = row64(M, ny + 1, x0);
-        } else if (dy != 0) {
-            const uint64_t nw = row64(M, ny + dy, x0);
-            const bool down = dy > 0;
+        } else {
+            const uint64_t nw = fetch(ny + dy); // (dy = 0: the middle row again, unused)
             const uint64_t oU = rU, oM = rM, oD = rD;
-            rU = down ? oM : nw;
-            rM = down ? oD : oU;
-            rD = down ? nw : oM;
+            rU = dy > 0 ? oM : (dy < 0 ? nw : oU);
+            rM = dy > 0 ? oD : (dy < 0 ? oU : oM);
+            rD = dy > 0 ? nw : (dy < 0 ? oM : oD);
         }
         x = nx; y = ny;
         s = (s + 4) & 7;
@@ -201,7 +220,12 @@ __device__ __forceinline__ void follow(const Mask& M, int sx, int sy, int first,
     T.status = status;
     if (status) return;
     // the run that arrives at the start, merged with the run that left it when the start is not a vertex
-    close_run(prev_s, run + first_len);
+    diag += pend;
+    {
+        const int k = run + first_len;
+        if (prev_s & 1) diag += k < 64 ? diag_len[k] : run_length(1, k);
+        else axis += k;
+    }
     T.a00 = a00; T.a10 = a10; T.a01 = a01;
     T.npts = npts; T.steps = steps;
     T.min_fg = min_fg; T.min_ebg = min_ebg;
@@ -236,6 +260,7 @@ __device__ void select_contour(ContourRec& r, double min_area, double min_circ)
 } // namespace
 
 constexpr int NTHREADS = 256, NWAVES = NTHREADS / 64;
+constexpr int NWIN = 16; // candidates per image whose mask window is staged in LDS
 
 // per-image workspace in global memory (L2-resident): the full border records and the ancestor paths of the kept ones
 struct ContourWork {
@@ -252,8 +277,9 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
     __shared__ int32_t rkey[MAXR];                 // per border: discovery key, start pixel, kind, links
     __shared__ int16_t rsx[MAXR], rsy[MAXR], rlink[MAXR], rparent[MAXR];
     __shared__ uint8_t rhole[MAXR], rkept[MAXR];
-    __shared__ int ncand, nrec, nkept, err, ncell;
+    __shared__ int ncand, nrec, nkept, err, ncell, dbg_steps;
     __shared__ double diag_len[64]; // float32 length of a diagonal run of k steps, as a double
+    __shared__ uint64_t win[NWIN][64]; // mask windows of the first NWIN candidates (see follow)
     uint16_t* const cell_list = (uint16_t*)scratch;
     int16_t (*const rbox)[4] = (int16_t (*)[4])scratch;          // bounding box of each border: x0, y0, x1, y1
     int16_t* const kept_idx = (int16_t*)(scratch + MAXR * 8);
@@ -265,7 +291,7 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
     Mask M{a.mask + (size_t)image * a.H * a.words_per_row, a.words_per_row, a.H, a.W, a.W + 1};
     ContourWork& work = ((ContourWork*)a.work)[image];
     int32_t* const out_count = a.out_count + (size_t)image * a.count_stride;
-    if (tid == 0) { ncand = 0; nrec = 0; nkept = 0; err = 0; ncell = 0; }
+    if (tid == 0) { ncand = 0; nrec = 0; nkept = 0; err = 0; ncell = 0; dbg_steps = 0; }
     if (tid < 64) diag_len[tid] = run_length(1, tid);
     // optional phase clock (MOCAP_CONTOUR_TIMING=1, a debugging aid): 100 MHz ticks at the phase boundaries
     uint64_t* const tick = a.timing ? a.timing + (size_t)image * 8 : nullptr;
@@ -374,24 +400,25 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
 
     // ---- phase B: one lane follows one candidate; the raster-first ones become records ---------------------------
     const int nc = ncand;
-    {   // The walks read the mask rows below each start one row at a time, each a cache line nobody on this XCD has
-        // touched yet.  Touch them all at once first: per candidate, the 64 rows from the start downwards (one per lane).
-        uint32_t warm = 0;
-        for (int c = wv; c < nc; c += NWAVES) {
-            const uint32_t v = cand[c];
-            const int x = v & 0x7fff, y = v >> 16, k0 = (x - 32) >> 5;
-            warm |= M.word(y + lane, k0) | M.word(y + lane, k0 + 2);
-        }
-        asm volatile("" ::"v"(warm)); // keeps the loads (their values are not needed)
+    // The walks read the mask rows below each start one at a time.  For the first NWIN candidates (all of them, in a
+    // typical frame) the 64 rows from the start downwards are staged in LDS first, one row per lane: one round of
+    // parallel loads instead of a dependent L2 round trip per vertical move.
+    for (int c = wv; c < nc && c < NWIN; c += NWAVES) {
+        const uint32_t v = cand[c];
+        const int sx = (int)(v & 0x7fff) - (int)((v >> 15) & 1u), sy = (int)(v >> 16);
+        win[c][lane] = row64(M, sy - 1 + lane, sx - 31);
     }
+    __syncthreads();
     for (int c = tid; c < nc; c += NTHREADS) {
         const uint32_t v = cand[c];
         const int is_hole = (v >> 15) & 1, x = v & 0x7fff, y = v >> 16;
         const int key = y * M.RS + x;
         Trace T;
-        if (!is_hole) follow(M, x, y, 4, key, -1, a.max_steps, T, diag_len);
-        else follow(M, x - 1, y, 0, -1, key, a.max_steps, T, diag_len);
+        const uint64_t* w = c < NWIN ? win[c] : nullptr;
+        if (!is_hole) follow(M, x, y, 4, key, -1, a.max_steps, T, diag_len, w);
+        else follow(M, x - 1, y, 0, -1, key, a.max_steps, T, diag_len, w);
         if (T.status == 2) atomicMax(&err, 1);
+        if (tick) atomicMax(&dbg_steps, T.status == 0 ? T.steps : 0);
         if (T.status != 0) continue;
         const int slot = atomicAdd(&nrec, 1);
         if (slot >= MAXR) continue;
@@ -413,6 +440,7 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
     }
     __syncthreads();
     stamp(2);
+    if (tick && tid == 0) { tick[5] = (uint64_t)ncand; tick[6] = (uint64_t)dbg_steps; tick[7] = (uint64_t)nrec; }
     if (nrec > MAXR || err) {
         if (tid == 0) { *out_count = err ? BLOB_ERR_STEPS : BLOB_ERR_CONTOURS; if (a.dbg_count) a.dbg_count[image] = 0; }
         return;
