@@ -511,6 +511,7 @@ static int run_contours(mocap_ctx* c, const uint32_t* mask, const uint32_t* cell
     a.max_steps = ms > (1 << 22) ? (1 << 22) : (int)ms;
     Tiling tl = tiling(c);
     a.cells = cells; a.rows_per_chunk = tl.rows; a.n_chunks = tl.n_cgroups * 4; a.n_strips = tl.n_strips;
+    if ((long long)a.n_chunks * a.n_strips * ((tl.rows + 7) / 8) > 65535) a.cells = nullptr; // cell ids are 16-bit in the kernel: scan every row instead
     if ((size_t)n_images > c->cwork_images) {
         std::lock_guard<std::mutex> lk(c->mu);
         if (c->cwork) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c->cwork)); c->cwork = nullptr; c->cwork_images = 0; }

@@ -219,3 +219,37 @@ def test_sharded_pipeline_equals_single_rank():
             assert np.array_equal(out["grp"][s, :k], ref_out["grp"][sl][s, :k])
             assert np.array_equal(out["xyz"][s, :k], ref_out["xyz"][sl][s, :k])  # same kernel, same inputs: bit-equal
             assert np.array_equal(out["order"][s, :k], ref_out["order"][sl][s, :k])
+
+
+def test_replay_tracker_matches_per_frame_drop_in(helpers):
+    """The batched headless tracker gives, per time step, what the reference's loops give for the same frames:
+    _find_dot per camera, find_point_correspondance_and_object_points(..., 4), the msgpack message (with the
+    previous point repeated when nothing was found)."""
+    import mocapv2_amd.lib.ImageOperations as IO
+    from mocapv2_amd.pipeline import scene_arrays
+    from mocapv2_amd.replay import ReplayTracker, tracker_message
+    H = helpers
+    C, T, W, Hh = 2, 5, 640, 360
+    sc = Scene(C, W, Hh, dist=MILD_DIST)
+    K, dist, R, t, F = scene_arrays(sc)
+    frames = sc.render_batch(seed=21, n_steps=T, n_markers=3, radius_range=(16, 20))
+    frames[2] = 10  # a time step without any marker: the previous message must be repeated
+    params = [{"intrinsic_matrix": sc.K.tolist(), "distortion_coef": sc.dist.tolist()} for _ in range(C)]
+    IO.camera_params = params
+    H.camera_params = np.array(params)
+    H.Fs = [f.tolist() for f in F]
+    poses = poses_from(R, t)
+    point = [0, 0, 0, 0, 0, 0, 0, 0]
+    got = list(ReplayTracker(K, dist, R, t, F, W, Hh, batch=4).run(frames))  # 5 steps in batches of 4: one padded batch
+    assert len(got) == T
+    seen = 0
+    for s in range(T):
+        lists = [IO._find_dot(frames[s, c])[1] for c in range(C)]
+        obj, img = H.find_point_correspondance_and_object_points(lists, poses, 4)
+        if len(obj) > 0:
+            point = [0, 0, 0, 0] + list(obj[0])
+            seen += 1
+        assert got[s]["object_points"].shape == obj.shape and np.array_equal(got[s]["object_points"], obj), s
+        assert got[s]["image_points"].shape == img.shape and np.array_equal(got[s]["image_points"], img), s
+        assert got[s]["message"] == tracker_message(point), s
+    assert seen >= 3 and len(got[2]["object_points"]) == 0 and got[2]["message"] == got[1]["message"]

@@ -77,3 +77,14 @@ def test_allgather_of_centroid_records_gloo(world, n_cams, T):
 def test_single_rank_gathers_nothing():
     x = torch.arange(12, dtype=torch.int32).reshape(3, 4)
     assert allgather_records(x, 1) is x
+
+
+def test_tracker_wire_format():
+    """msgpack bytes of one tracker update as the reference sends them (RealtimeTracking_FLIR.py:171,183-187)."""
+    import struct
+    from mocapv2_amd.replay import tracker_message, unpack_tracker_message
+    assert tracker_message([0] * 8) == b"\x81\xa8tracker1\x98" + b"\x00" * 8  # before the first detection: eight zeros
+    p = [0, 0, 0, 0, np.float64(0.25), np.float64(-1.5), np.float64(3.0000001)]
+    exp = b"\x81\xa8tracker1\x97" + b"\x00" * 4 + b"".join(b"\xcb" + struct.pack(">d", float(v)) for v in p[4:])
+    assert tracker_message(p) == exp
+    assert unpack_tracker_message(exp) == [0, 0, 0, 0, 0.25, -1.5, 3.0000001]
