@@ -83,6 +83,9 @@ def main():
                     help="time steps per batch and GPU (one step = one pass over time_steps x 6 resident images)")
     ap.add_argument("--depth", type=int, default=3,
                     help="batches in flight (software pipelining of consecutive batches on separate HIP streams; 1 = off)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 ranks share cuda:0 and exchange through gloo (checks the multi-rank code path on a one-GPU box; "
+                         "not a measurement)")
     ap.add_argument("--cpu-steps", type=int, default=256, help="time steps in the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-secondary", dest="secondary", action="store_false",
                     help="skip the second timed run with the other distortion variant")
@@ -100,10 +103,15 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with python -m torch.distributed.run --nproc-per-node N")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     def barrier():
         if world > 1:
@@ -138,7 +146,7 @@ def main():
         prof["timed_region"] = prof_timed
         prof["tiles"], prof["tiles_skipped"] = tracker.ctx.tile_stats()  # of the last step
         if world > 1:
-            tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else "cuda")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
         return out, elapsed, prof

@@ -40,7 +40,12 @@ def allgather_records(local, world, group=None):
         return local
     import torch.distributed as dist
     out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    if local.is_cuda:
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal of the multi-rank path on a box without RCCL peers: gloo has no GPU all-gather, stage through the host
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather(list(host.chunk(world, dim=0)), local.cpu().contiguous(), group=group)
+        out.copy_(host)
+    elif local.is_cuda:
         dist.all_gather_into_tensor(out, local.contiguous(), group=group)
     else:
         dist.all_gather(list(out.chunk(world, dim=0)), local.contiguous(), group=group)
