@@ -1,15 +1,20 @@
-// blob_filter.hip -- fused  undistort -> 5x5 in-bounds box sum -> threshold -> 5x5 majority  kernel.
+// blob_filter.hip -- the filter stage:  undistort -> 5x5 in-bounds box sum -> threshold -> 5x5 majority.
 //
 // Replaces, for one batch of camera images resident in HBM, the chain
 //   cv.undistort (reference lib/ImageOperations.py:38) -> fast_cuda_blur (lib/CudaOperations.py:5-41)
 //   -> cv.threshold (lib/ImageOperations.py:29) -> cv.medianBlur (lib/ImageOperations.py:30)
 // and writes the filtered binary image as a bit mask (1 bit / pixel).
 //
-// gfx950 design: one wave owns a strip of 256 source columns (4 px per lane, one dword load per lane
-// and row = a 256-byte coalesced row segment) and slides down the rows of its chunk.  Everything lives
-// in registers; horizontal neighbours come from DPP wave shifts, byte sums from v_dot4_u32_u8, the
-// vertical 5-row windows are running sums whose history sits in a per-wave LDS ring.  HBM traffic is
-// the 1 B/px read (+6 % halo) and the 1/8 B/px mask write.
+// Two kernels per batch:
+//   bright_cells_kernel  streams every frame byte once (the algorithmic HBM traffic of the stage) and records, per
+//                        filter tile, which mask rows can possibly hold a set pixel -- an exact bound, see
+//                        "dark-tile early-out" below;
+//   filter_mask_kernel   runs the fused filter over those rows only.  One wave owns a strip of 256 source columns
+//                        (4 px per lane, one dword load per lane and row = a 256-byte coalesced row segment) and
+//                        slides down its rows.  Everything lives in registers; horizontal neighbours come from DPP
+//                        wave shifts, byte sums from v_dot4_u32_u8, the vertical 5-row windows are running sums
+//                        whose history sits in a per-wave LDS ring.
+// Also here: the set-up kernels of the undistort tables and the single-image convenience kernels.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "kernels.h"
