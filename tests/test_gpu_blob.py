@@ -288,3 +288,29 @@ def test_mixed_identity_and_remapped_cameras_in_one_batch(torch_cuda):
     assert total > 0
     tiles, skipped = ctx.tile_stats()
     assert 0 < skipped < tiles
+
+
+@pytest.mark.parametrize("W,H", [(251, 131), (333, 77), (64, 48), (500, 300)])
+@pytest.mark.parametrize("scale", [0.0, 2.0])
+def test_centroids_odd_sizes_two_batches(torch_cuda, W, H, scale):
+    """_find_dot through the context-owned mask (early-out, row ranges, on-demand clearing) at sizes that are not
+    multiples of the 8x8 cells / 240x68 tiles, two different batches in a row."""
+    torch = torch_cuda
+    from mocapv2_amd.engine import MocapContext
+    sc = Scene(1, width=W, height=H, dist=np.array(MILD_DIST) * scale)
+    ctx = MocapContext(W, H, n_slots=1)
+    ctx.set_undistort(0, sc.K, sc.dist)
+    ctx.set_blob_params(min_area=60.0)
+    prm = oracle.default_params(undistort=True)
+    prm.min_area = 60.0
+    rng = np.random.default_rng(W * 1000 + H)
+    seen = 0
+    for b in range(2):
+        frames = dark_frames(rng, 3, H, W, n_discs=3, salt=0.002)
+        xy, cnt = ctx.record_views(ctx.blob_centroids(torch.from_numpy(frames).cuda()))
+        xy, cnt = xy.cpu().numpy(), cnt.cpu().numpy()
+        for i in range(3):
+            exp = oracle.find_dot(frames[i], sc.K, sc.dist, params=prm)
+            assert cnt[i] == len(exp) and xy[i, :cnt[i]].tolist() == exp, (b, i, cnt[i], exp)
+            seen += len(exp)
+    assert seen > 0
