@@ -171,7 +171,7 @@ def main():
     if rank == 0:
         frames_per_step = T_STEPS * world
         value = frames_per_step * args.steps / elapsed
-        KERNELS = (("scan", "bright_cells_kernel"), ("filter", "filter_mask_kernel"))
+        KERNELS = (("scan", "bright_cells_kernel"), ("patch", "undistort_patches_kernel"), ("filter", "filter_mask_kernel"))
 
         def roofline_of(prof, n_images, n_launch_groups, dist_name):
             """Roofline entries of the two HBM-bound kernels of the filter stage; the one with the longer launches leads.
@@ -217,7 +217,8 @@ def main():
 
         def kernel_ms(prof):
             n = prof["steps"]
-            return {"scan": round(prof["scan_ms"] / n, 4), "filter": round(prof["filter_ms"] / n, 4),
+            return {"scan": round(prof["scan_ms"] / n, 4), "patches": round(prof["patch_ms"] / n, 4),
+                    "filter": round(prof["filter_ms"] / n, 4),
                     "contours": round(prof["contour_ms"] / n, 4), "correspond": round(prof["corr_ms"] / n, 4)}
 
         roof = roofline_of(prof, len(images), 1 if world == 1 else len(tracker.segs), args.dist)

@@ -153,9 +153,10 @@ MOCAP_API int mocap_reproject_batch(mocap_ctx_t ctx, const double* pts_dev, cons
 MOCAP_API int mocap_tile_stats(mocap_ctx_t ctx, uint64_t* tiles, uint64_t* skipped);
 /* HIP-event timing of the kernels launched by mocap_blob_centroids / mocap_filter_mask / mocap_correspond, recorded
  * on their stream.  mocap_profile_read synchronises, returns accumulated milliseconds and launch counts and resets:
- * index 0 = filter_mask_kernel, 1 = contours_kernel, 2 = correspond_kernel, 3 = bright_cells_kernel. */
+ * index 0 = filter_mask_kernel, 1 = contours_kernel, 2 = correspond_kernel, 3 = bright_cells_kernel,
+ * 4 = undistort_patches_kernel. */
 MOCAP_API int mocap_profile_enable(mocap_ctx_t ctx, int on);
-MOCAP_API int mocap_profile_read(mocap_ctx_t ctx, double ms[4], int launches[4]);
+MOCAP_API int mocap_profile_read(mocap_ctx_t ctx, double ms[5], int launches[5]);
 
 #ifdef __cplusplus
 }

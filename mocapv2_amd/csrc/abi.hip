@@ -47,18 +47,19 @@ struct mocap_ctx {
     std::vector<uint32_t> slot_wmax; // largest total blend weight of a source pixel (1024 = identity); 0 = early-out not provable
     std::vector<int> slot_mode;  // remap kernel variant the slot's table admits: 2 per-pixel, 3 pipelined gather, 4 LDS-staged
     uint2* spans;             // [n_slots][n_strips][H] source row / column spans per strip row
-    uint2* hull;              // [n_slots][ceil(H/8)][ceil(W/8)] per 8x8 source cell: the tiles whose source region holds it
+    uint2* reach;             // [n_slots][ceil(H/8)][ceil(W/8)] per 8x8 source cell: box of the output pixels that read it
+    uint8_t* cflags;          // [n_slots][cells] border-cut window flags per source cell (see BrightArgs)
     uint32_t* mask; size_t mask_images;
     uint32_t* cells; size_t cells_images; // occupancy cells written by the filter kernel for c->mask
     int last_images;                       // images of the most recent batch that wrote c->cells
     uint32_t* tile_rows;                   // [mask_images][tiles][2] reachable mask rows per tile, beside cells (see FilterArgs)
-    uint16_t* dil;                         // [n_slots][tiles] vertical reach of a source row per tile (see BrightArgs)
+    uint8_t* patch; size_t patch_images;   // undistorted boxes of the marked tiles (see FilterArgs)
     uint32_t* cells_ext; size_t cells_ext_images; // occupancy words of caller-owned masks (mocap_filter_mask)
     void* cwork; size_t cwork_images;      // contour kernel workspace, contour_work_bytes() per image
     CameraTable* cams; int n_cam, n_F;
     double* scratch; size_t scratch_elems;
     bool profiling;
-    std::vector<EvPair> ev[4];
+    std::vector<EvPair> ev[5];
     std::mutex mu;
 };
 
@@ -139,7 +140,7 @@ int mocap_ctx_create(int device_id, int width, int height, int n_slots, mocap_ct
     mocap_ctx* c = new mocap_ctx();
     c->device = device_id; c->W = width; c->H = height; c->n_slots = n_slots; c->wpr = (width + 31) / 32;
     c->prm = mocap_blob_params{5, 5, 255 * 0.85, 500.0, 0.5};
-    c->maps = nullptr; c->spans = nullptr; c->hull = nullptr; c->cells_ext = nullptr; c->cells_ext_images = 0; c->map_flags = nullptr; c->mask = nullptr; c->mask_images = 0; c->cells = nullptr; c->cells_images = 0; c->last_images = 0; c->tile_rows = nullptr; c->dil = nullptr; c->cwork = nullptr; c->cwork_images = 0;
+    c->maps = nullptr; c->spans = nullptr; c->reach = nullptr; c->cflags = nullptr; c->cells_ext = nullptr; c->cells_ext_images = 0; c->map_flags = nullptr; c->mask = nullptr; c->mask_images = 0; c->cells = nullptr; c->cells_images = 0; c->last_images = 0; c->tile_rows = nullptr; c->patch = nullptr; c->patch_images = 0; c->cwork = nullptr; c->cwork_images = 0;
     c->cams = nullptr; c->n_cam = 0; c->n_F = 0; c->scratch = nullptr; c->scratch_elems = 0; c->profiling = false;
     c->slot_state.assign(n_slots, 0);
     c->slot_mode.assign(n_slots, 2);
@@ -163,13 +164,14 @@ int mocap_ctx_destroy(mocap_ctx_t c)
     for (auto& v : c->ev) for (auto& p : v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (c->maps) (void)hipFree(c->maps);
     if (c->spans) (void)hipFree(c->spans);
-    if (c->hull) (void)hipFree(c->hull);
+    if (c->reach) (void)hipFree(c->reach);
+    if (c->cflags) (void)hipFree(c->cflags);
     if (c->cells_ext) (void)hipFree(c->cells_ext);
     if (c->map_flags) (void)hipFree(c->map_flags);
     if (c->mask) (void)hipFree(c->mask);
     if (c->cells) (void)hipFree(c->cells);
     if (c->tile_rows) (void)hipFree(c->tile_rows);
-    if (c->dil) (void)hipFree(c->dil);
+    if (c->patch) (void)hipFree(c->patch);
     if (c->cwork) (void)hipFree(c->cwork);
     if (c->cams) (void)hipFree(c->cams);
     if (c->scratch) (void)hipFree(c->scratch);
@@ -219,9 +221,10 @@ int mocap_set_undistort(mocap_ctx_t c, int slot, const double K[9], const double
     c->slot_mode[slot] = 2;
     c->slot_wmax[slot] = c->slot_state[slot] == 1 ? 1024u : 0u; // identity: every source pixel feeds exactly one output pixel
     Tiling tl = tiling(c);
-    std::vector<uint2> sp_host; // remap slots: the span table on the host
     const int ncx_ = (c->W + 7) / 8, ncy_ = (c->H + 7) / 8;
     std::vector<uint32_t> edge((size_t)ncx_ * ncy_, 0); // source cells read by windows that the image border cuts: bit 0 one axis, bit 1 both
+    std::vector<int> reach32((size_t)ncx_ * ncy_ * 4);  // per source cell: x0, x1, y0, y1 of the output pixels that read it
+    for (size_t i = 0; i < reach32.size(); i += 2) { reach32[i] = 0x7fffffff; reach32[i + 1] = -0x7fffffff - 1; }
     if (c->slot_state[slot] == 2) {
         size_t nsp = (size_t)tl.n_strips * c->H;
         if (!c->spans) HIP_TRY(hipMalloc(&c->spans, sizeof(uint2) * nsp * c->n_slots));
@@ -230,87 +233,53 @@ int mocap_set_undistort(mocap_ctx_t c, int slot, const double K[9], const double
         HIP_TRY(hipGetLastError());
         std::vector<uint2> sp(nsp);
         HIP_TRY(hipMemcpy(sp.data(), sa.spans, sizeof(uint2) * nsp, hipMemcpyDeviceToHost));
-        sp_host = sp;
         if (lds_remap_ok(c, sp)) c->slot_mode[slot] = 4;
         else if (c->W >= 4 && (c->W & 3) == 0 && c->H >= 2) c->slot_mode[slot] = 3;
         // statistics for the dark-tile early-out (see blob_filter.hip): total weight per source pixel, tap extents
         uint32_t* tmp = nullptr;
         const size_t edge_words = edge.size();
-        HIP_TRY(hipMalloc(&tmp, sizeof(uint32_t) * (per + 4 + edge_words)));
+        HIP_TRY(hipMalloc(&tmp, sizeof(uint32_t) * (per + 4 + edge_words + reach32.size())));
         hipError_t e2 = hipMemset(tmp, 0, sizeof(uint32_t) * (per + 4 + edge_words));
+        int* reach_dev = (int*)(tmp + per + 4 + edge_words);
+        if (e2 == hipSuccess) e2 = hipMemcpy(reach_dev, reach32.data(), sizeof(int) * reach32.size(), hipMemcpyHostToDevice);
         uint32_t st3[3] = {0, 0, 0};
         if (e2 == hipSuccess) {
-            StatArgs sg{m.map, m.mapw, tmp, tmp + per, c->H, c->W, tmp + per + 4};
+            StatArgs sg{m.map, m.mapw, tmp, tmp + per, c->H, c->W, tmp + per + 4, reach_dev};
             launch_remap_stats(sg, 0);
             e2 = hipGetLastError();
             if (e2 == hipSuccess) e2 = hipMemcpy(st3, tmp + per, sizeof(st3), hipMemcpyDeviceToHost);
             if (e2 == hipSuccess) e2 = hipMemcpy(edge.data(), tmp + per + 4, sizeof(uint32_t) * edge.size(), hipMemcpyDeviceToHost);
+            if (e2 == hipSuccess) e2 = hipMemcpy(reach32.data(), reach_dev, sizeof(int) * reach32.size(), hipMemcpyDeviceToHost);
         }
         (void)hipFree(tmp);
         if (e2 != hipSuccess) return fail(MOCAP_E_HIP, "undistort statistics: %s", hipGetErrorString(e2));
         if (st3[1] <= 9 && st3[2] <= 9 && c->W >= 8) c->slot_wmax[slot] = st3[0];
     }
-    {   // Dark-tile early-out tables.  Source region of every (chunk, strip) filter tile = what the tile's rows read
-        // (remap: the union of their spans; identity: the tile's own input rectangle), then per 8x8 source cell the
-        // hull (chunk range x strip range) of the tiles whose region holds the cell -- what bright_cells_kernel marks
-        // when the cell is hot.  A hull may name tiles that do not hold the cell (it is a rectangle): harmless, a
-        // marked tile is simply filtered.
-        const int H = c->H, W = c->W, Hm1 = H - 1, nch = tl.n_cgroups * 4, ncx = (W + 7) / 8, ncy = (H + 7) / 8;
-        std::vector<uint2> hull((size_t)ncx * ncy, make_uint2(0xffffu, 0xffffu)); // first = 0xffff > last = 0: no tile
-        std::vector<uint16_t> dil((size_t)nch * tl.n_strips, 4); // rows a source row can reach: map displacement + blur 2 + median 2
-        for (int ch = 0; ch < nch && ch * tl.rows < H; ch++)
-            for (int st = 0; st < tl.n_strips; st++) {
-                int r0 = ch * tl.rows, r1 = r0 + tl.rows < H ? r0 + tl.rows : H;
-                int kfirst = r0 - 2 < 0 ? 0 : (r0 - 2 > Hm1 ? Hm1 : r0 - 2), ke = r1 + 1 < Hm1 ? r1 + 1 : Hm1;
-                int y0 = kfirst - 2, last = (ke > kfirst ? ke : kfirst) + 2;
-                int ra = y0 < 0 ? 0 : y0, rb = last > Hm1 ? Hm1 : last;
-                int xmin = 0x7fff, xmax = -1, smin = 0x7fff, smax = -1;
-                if (c->slot_state[slot] == 2) {
-                    int disp = 0; // largest |source row - output row| over the rows the tile consumes
-                    for (int y = ra; y <= rb; y++) {
-                        uint2 v = sp_host[(size_t)st * H + y];
-                        int lo = (int)(v.y & 0xffffu), hi = (int)(v.y >> 16), s0 = (int)(v.x & 0xffffu), s1 = (int)(v.x >> 16);
-                        xmin = lo < xmin ? lo : xmin; xmax = hi > xmax ? hi : xmax;
-                        smin = s0 < smin ? s0 : smin; smax = s1 > smax ? s1 : smax;
-                        if (s1 >= s0) {
-                            disp = y - s0 > disp ? y - s0 : disp;
-                            disp = s1 - y > disp ? s1 - y : disp;
-                        }
-                    }
-                    dil[(size_t)ch * tl.n_strips + st] = (uint16_t)(disp + 4 > 0xffff ? 0xffff : disp + 4);
-                } else {
-                    int xbase = st * 240 - 8;
-                    xmin = xbase < 0 ? 0 : xbase; xmax = xbase + 255 > W - 1 ? W - 1 : xbase + 255;
-                    smin = ra; smax = rb;
-                }
-                if (xmax < xmin || smax < smin) continue;
-                xmin = xmin < 0 ? 0 : xmin; smin = smin < 0 ? 0 : smin;
-                xmax = xmax > W - 1 ? W - 1 : xmax; smax = smax > Hm1 ? Hm1 : smax;
-                for (int cr = smin >> 3; cr <= smax >> 3; cr++)
-                    for (int cx = xmin >> 3; cx <= xmax >> 3; cx++) {
-                        uint2& h = hull[(size_t)cr * ncx + cx];
-                        uint32_t c_lo = h.x & 0xffffu, c_hi = h.x >> 16, s_lo = h.y & 0xffffu, s_hi = h.y >> 16;
-                        if (c_lo > c_hi) { c_lo = c_hi = (uint32_t)ch; s_lo = s_hi = (uint32_t)st; }
-                        else {
-                            c_lo = (uint32_t)ch < c_lo ? (uint32_t)ch : c_lo; c_hi = (uint32_t)ch > c_hi ? (uint32_t)ch : c_hi;
-                            s_lo = (uint32_t)st < s_lo ? (uint32_t)st : s_lo; s_hi = (uint32_t)st > s_hi ? (uint32_t)st : s_hi;
-                        }
-                        h = make_uint2(c_lo | (c_hi << 16), s_lo | (s_hi << 16));
-                    }
-            }
-        if (c->slot_state[slot] == 1) // identity: the cut windows lie within 4 pixels of the border
-            for (int cr = 0; cr < ncy; cr++)
-                for (int cx = 0; cx < ncx; cx++)
-                {
+    {   // Dark-tile early-out tables per 8x8 source cell: the reach (which output pixels read the cell: from the map itself
+        // for a remapped camera, the cell's own pixels for the identity) and the border-cut window flags.
+        const int H = c->H, W = c->W, ncx = ncx_, ncy = ncy_;
+        std::vector<uint2> reach((size_t)ncx * ncy);
+        std::vector<uint8_t> cflags((size_t)ncx * ncy);
+        for (int cr = 0; cr < ncy; cr++)
+            for (int cx = 0; cx < ncx; cx++) {
+                const size_t i = (size_t)cr * ncx + cx;
+                int x0, x1, y0, y1;
+                if (c->slot_state[slot] == 1) {
+                    x0 = 8 * cx; x1 = 8 * cx + 7 < W - 1 ? 8 * cx + 7 : W - 1; y0 = 8 * cr; y1 = 8 * cr + 7 < H - 1 ? 8 * cr + 7 : H - 1;
+                    // identity: the cut windows lie within 4 pixels of the border
                     const bool xc = 8 * cx < 4 || 8 * cx + 7 >= W - 4, yc = 8 * cr < 4 || 8 * cr + 7 >= H - 4;
-                    edge[(size_t)cr * ncx + cx] = (xc && yc) ? 2u : (xc || yc) ? 1u : 0u;
+                    edge[i] = (xc && yc) ? 2u : (xc || yc) ? 1u : 0u;
+                } else {
+                    x0 = reach32[4 * i]; x1 = reach32[4 * i + 1]; y0 = reach32[4 * i + 2]; y1 = reach32[4 * i + 3];
                 }
-        for (size_t i = 0; i < hull.size(); i++)
-            hull[i].y |= (edge[i] & 2u) ? 0x80000000u : (edge[i] & 1u) ? 0x40000000u : 0u;
-        if (!c->dil) HIP_TRY(hipMalloc(&c->dil, sizeof(uint16_t) * dil.size() * c->n_slots));
-        HIP_TRY(hipMemcpy(c->dil + dil.size() * slot, dil.data(), sizeof(uint16_t) * dil.size(), hipMemcpyHostToDevice));
-        if (!c->hull) HIP_TRY(hipMalloc(&c->hull, sizeof(uint2) * hull.size() * c->n_slots));
-        HIP_TRY(hipMemcpy(c->hull + hull.size() * slot, hull.data(), sizeof(uint2) * hull.size(), hipMemcpyHostToDevice));
+                if (x0 > x1 || y0 > y1) reach[i] = make_uint2(1u, 0u); // read by nothing: x0 = 1 > x1 = 0
+                else reach[i] = make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16));
+                cflags[i] = (edge[i] & 2u) ? 2 : (edge[i] & 1u) ? 1 : 0;
+            }
+        if (!c->reach) HIP_TRY(hipMalloc(&c->reach, sizeof(uint2) * reach.size() * c->n_slots));
+        HIP_TRY(hipMemcpy(c->reach + reach.size() * slot, reach.data(), sizeof(uint2) * reach.size(), hipMemcpyHostToDevice));
+        if (!c->cflags) HIP_TRY(hipMalloc(&c->cflags, cflags.size() * c->n_slots));
+        HIP_TRY(hipMemcpy(c->cflags + cflags.size() * slot, cflags.data(), cflags.size(), hipMemcpyHostToDevice));
     }
     if (identity_out) *identity_out = c->slot_state[slot] == 1;
     return MOCAP_OK;
@@ -363,13 +332,13 @@ int mocap_profile_enable(mocap_ctx_t c, int on)
     return MOCAP_OK;
 }
 
-int mocap_profile_read(mocap_ctx_t c, double ms[4], int cnt[4])
+int mocap_profile_read(mocap_ctx_t c, double ms[5], int cnt[5])
 {
     if (!c || !ms || !cnt) return fail(MOCAP_E_INVALID, "null argument");
     if (set_device(c)) return MOCAP_E_HIP;
-    for (int w = 0; w < 4; w++) { ms[w] = 0; cnt[w] = 0; }
+    for (int w = 0; w < 5; w++) { ms[w] = 0; cnt[w] = 0; }
     std::lock_guard<std::mutex> lk(c->mu);
-    for (int w = 0; w < 4; w++) {
+    for (int w = 0; w < 5; w++) {
         for (auto& p : c->ev[w]) {
             HIP_TRY(hipEventSynchronize(p.b));
             float f = 0;
@@ -460,7 +429,7 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
         const long long per_tap = 1024LL * (2LL * a.thr_mul - 127);
         int allow = -1;
         allow_cut1 = allow_cut2 = -1;
-        if (c->W < 8 || !c->tile_rows || !c->hull || !c->dil) ok = false;
+        if (c->W < 8 || !c->tile_rows || !c->reach || !c->cflags) ok = false;
         if (ok && wmax > 0 && per_tap > 0) {
             allow = (int)((per_tap * t5full(c->W) * t5full(c->H) - 1) / (2LL * 192 * wmax)); // windows with all their taps
             const long long taps1 = t5(c->W) * t5full(c->H) < t5full(c->W) * t5(c->H) ? t5(c->W) * t5full(c->H) : t5full(c->W) * t5(c->H);
@@ -471,23 +440,41 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
         a.skip_allow = allow;
     }
     if (cells == c->cells) c->last_images = n_images;
-    // Block order: time-fastest, so that concurrently resident blocks work on the same tile of the same camera at
-    // different times and share its map words in L2 (8 B of tables per pixel against 1 B of image).  Strip-fastest
-    // (neighbouring tiles of one image together; MOCAP_STRIP_ORDER=1) fetches fewer bytes when every tile is filtered.
-    a.strip_fastest = 0;
-    { const char* e = getenv("MOCAP_STRIP_ORDER"); if (e) a.strip_fastest = atoi(e) != 0; }
     a.spans = c->spans ? c->spans + (size_t)slot_base * tiling(c).n_strips * c->H : nullptr;
     const bool own_mask = mask == c->mask; // the context's mask keeps "zero unless filtered" from batch to batch
-    a.tile_rows = c->tile_rows; a.fill_dark = own_mask ? 0 : 1;
+    a.tile_rows = c->tile_rows; a.ext_mask = own_mask ? 0 : 1;
+    // Remapped cameras with the early-out: undistort only the boxes hot cells can reach into per-tile patches and run
+    // the plain pipeline on them (MOCAP_PATCH=0: gather in the filter kernel for every filtered row instead).
+    a.patch = nullptr;
+    {
+        bool all_remap = true;
+        for (int sl = slot_base; sl < slot_base + cam_mod; sl++) all_remap &= c->slot_state[sl] == 2 && c->slot_mode[sl] >= 3;
+        const char* e = getenv("MOCAP_PATCH");
+        if (a.skip_allow >= 0 && all_remap && !(e && atoi(e) == 0)) {
+            if ((size_t)n_images > c->patch_images) {
+                std::lock_guard<std::mutex> lk(c->mu);
+                if (c->patch) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c->patch)); c->patch = nullptr; c->patch_images = 0; }
+                HIP_TRY(hipMalloc(&c->patch, (size_t)n_images * cells_per_image(c) * (tl.rows + 8) * 256));
+                c->patch_images = n_images;
+            }
+            a.patch = c->patch;
+        }
+    }
     EvPair p; bool on;
     if (a.skip_allow >= 0) { // one streaming pass over the frames marks the tiles that can hold set pixels
         BrightArgs b{a.src, a.image_stride, a.pitch, a.H, a.W, n_images, cam_mod, a.skip_allow / 4, allow_cut1 / 4, allow_cut2 / 4,
-                     c->hull + (size_t)slot_base * source_cells(c), c->tile_rows, tl.n_cgroups * 4, tl.n_strips,
-                     c->dil + (size_t)slot_base * cells_per_image(c),
+                     c->reach + (size_t)slot_base * source_cells(c), c->cflags + (size_t)slot_base * source_cells(c),
+                     c->tile_rows, tl.n_cgroups * 4, tl.n_strips, tl.rows,
                      mask, own_mask ? 0 : (size_t)n_images * c->H * c->wpr, ((uintptr_t)mask & 15) == 0};
         prof_begin(c, 3, s, p, on);
         launch_bright_cells(b, s);
         prof_end(c, 3, s, p, on);
+        HIP_TRY(hipGetLastError());
+    }
+    if (a.patch) {
+        prof_begin(c, 4, s, p, on);
+        launch_undistort_patches(a, s);
+        prof_end(c, 4, s, p, on);
         HIP_TRY(hipGetLastError());
     }
     prof_begin(c, 0, s, p, on);
@@ -574,7 +561,7 @@ static int ensure_mask(mocap_ctx* c, int n_images)
     c->cells_images = n_images;
     if (c->tile_rows) { HIP_TRY(hipFree(c->tile_rows)); c->tile_rows = nullptr; }
     {   // every tile starts with the empty range (0xffffffff, 0)
-        std::vector<uint32_t> init((size_t)n_images * cells_per_image(c) * 2);
+        std::vector<uint32_t> init((size_t)n_images * cells_per_image(c) * 4);
         for (size_t i = 0; i < init.size(); i += 2) { init[i] = 0xffffffffu; init[i + 1] = 0u; }
         HIP_TRY(hipMalloc(&c->tile_rows, sizeof(uint32_t) * init.size()));
         HIP_TRY(hipMemcpy(c->tile_rows, init.data(), sizeof(uint32_t) * init.size(), hipMemcpyHostToDevice));
@@ -670,9 +657,8 @@ int mocap_image_filter_u8(mocap_ctx_t c, const void* src, void* dst, int spitch,
     a.map = slot >= 0 ? c->maps + (size_t)slot * c->H * c->W : nullptr;
     a.mapw = slot >= 0 ? c->maps + (size_t)(c->n_slots + slot) * c->H * c->W : nullptr;
     a.remap_mode = slot >= 0 ? c->slot_mode[slot] : 0;
-    a.strip_fastest = 0;
     a.skip_allow = -1; // single-image convenience path: no early-out
-    a.tile_rows = nullptr; a.fill_dark = 1;
+    a.tile_rows = nullptr; a.ext_mask = 1; a.patch = nullptr;
     a.spans = (slot >= 0 && c->spans) ? c->spans + (size_t)slot * tiling(c).n_strips * c->H : nullptr;
     a.thr_mul = ithresh + 1;
     Tiling tl = tiling(c);

@@ -278,11 +278,9 @@ __device__ __forceinline__ uint32_t bright_count(uint32_t v)
 // a cell row, so a wave's loads cover 512 contiguous bytes of each of 8 image rows).  A cell with more than `hot`
 // such pixels (4 * hot <= allow, so four dark cells can never exceed the 2x2-block bound above; `hot_edge` and
 // `hot_corner`, from the bounds of the 15- and 9-tap windows, for the cells that feed windows cut by the image
-// border in one axis or in both) marks every filter tile
-// whose source region contains it -- the hull table built at set-up says which -- by widening the tile's range of
-// reachable mask rows (atomic min / max; `dil` = how far, in rows, a source row of the tile's region can act on the
-// mask: the largest vertical displacement of the undistort map over the tile + 4 rows of blur and median).  Tiles
-// left unmarked, and rows outside the range, provably filter to zeros.
+// border in one axis or in both) marks every filter tile its reach touches (reach = the box of output pixels that read
+// the cell, tabulated at set-up, + 4 pixels of blur and median) by widening the tile's range of reachable mask rows
+// and columns (atomic min / max).  Tiles left unmarked, and rows outside the range, provably filter to zeros.
 __global__ __launch_bounds__(256) void bright_cells_kernel(BrightArgs a)
 {
     const int ncx = (a.W + 7) >> 3, ncy = (a.H + 7) >> 3, n = ncx * ncy;
@@ -309,9 +307,9 @@ __global__ __launch_bounds__(256) void bright_cells_kernel(BrightArgs a)
         }
     }
     const int slot = image % a.cam_mod;
-    const uint2* __restrict__ hull = a.hull + (size_t)slot * n;
-    uint32_t* __restrict__ rows = a.tile_rows + (size_t)image * a.n_chunks * a.n_strips * 2;
-    const uint16_t* __restrict__ dil = a.dil + (size_t)slot * a.n_chunks * a.n_strips;
+    const uint2* __restrict__ reach = a.reach + (size_t)slot * n;
+    const uint8_t* __restrict__ cflags = a.cflags + (size_t)slot * n;
+    uint32_t* __restrict__ rows = a.tile_rows + (size_t)image * a.n_chunks * a.n_strips * 4;
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         uint32_t acc = 0;
@@ -322,16 +320,23 @@ __global__ __launch_bounds__(256) void bright_cells_kernel(BrightArgs a)
             if (8 * cr[u] + j < a.H) acc += cnt;
         }
         if ((int)acc > a.hot_corner) { // rare: a few cells per marker
-            // x = first | last << 16 chunk, y = first | last << 16 strip (first > last: none); bits 31 / 30 of y: the
-            // cell feeds windows cut by the image border in both axes / in one axis (fewer taps, smaller bound)
-            const uint2 h = hull[ci[u]];
-            if ((int)acc > ((h.y >> 31) ? a.hot_corner : ((h.y >> 30) & 1u) ? a.hot_edge : a.hot)) {
-                const int s0 = 8 * cr[u], s1 = s0 + 7 < a.H - 1 ? s0 + 7 : a.H - 1; // source rows of the cell
-                for (int ch = (int)(h.x & 0xffffu); ch <= (int)(h.x >> 16); ch++)
-                    for (int st = (int)(h.y & 0xffffu); st <= (int)((h.y >> 16) & 0x3fffu); st++) {
-                        const int t = ch * a.n_strips + st, d = (int)dil[t];
-                        atomicMin(&rows[2 * t], (uint32_t)(s0 - d > 0 ? s0 - d : 0));
-                        atomicMax(&rows[2 * t + 1], (uint32_t)(s1 + d < a.H - 1 ? s1 + d : a.H - 1));
+            // reach = bounding box of the output pixels that read this cell (x0 | x1 << 16, y0 | y1 << 16; x0 > x1: none);
+            // flag bits: the cell feeds windows cut by the image border in one axis (1) / in both (2): fewer taps, smaller bound
+            const uint2 rc = reach[ci[u]];
+            const uint32_t fl = cflags[ci[u]];
+            const int x0 = (int)(rc.x & 0xffffu), x1 = (int)(rc.x >> 16), y0 = (int)(rc.y & 0xffffu), y1 = (int)(rc.y >> 16);
+            if (x0 <= x1 && (int)acc > ((fl & 2u) ? a.hot_corner : (fl & 1u) ? a.hot_edge : a.hot)) {
+                // a window with a set threshold bit is centred within 2 pixels of a pixel that reads a hot cell and spans 2
+                // more; the median adds 2 again: exact pixels are needed, and mask bits can be set, within 4 of the reach
+                const int xa = x0 - 4 > 0 ? x0 - 4 : 0, xb = x1 + 4 < a.W - 1 ? x1 + 4 : a.W - 1;
+                const int ya = y0 - 4 > 0 ? y0 - 4 : 0, yb = y1 + 4 < a.H - 1 ? y1 + 4 : a.H - 1;
+                for (int ch = ya / a.rows_per_chunk; ch <= yb / a.rows_per_chunk; ch++)
+                    for (int st = xa / 240; st <= xb / 240; st++) {
+                        const int t = ch * a.n_strips + st;
+                        atomicMin(&rows[4 * t], (uint32_t)ya);
+                        atomicMax(&rows[4 * t + 1], (uint32_t)yb);
+                        atomicMin(&rows[4 * t + 2], (uint32_t)xa);
+                        atomicMax(&rows[4 * t + 3], (uint32_t)xb);
                     }
             }
         }
@@ -361,7 +366,175 @@ __device__ __forceinline__ int taps5(int v, int n)
 template <int J> struct IC { static constexpr int value = J; };
 
 
-template <bool REMAP, bool TINY, bool PIPE, bool LDSR>
+// workgroup -> (camera slot, chunk group, time step); wave wv of the workgroup owns chunk cgroup * 4 + wv and walks over
+// that chunk's strips (tiles).  (Single-wave workgroups were measured too: no better.)  Blocks b and b+8 share an XCD (round-robin dispatch; placement only affects speed):
+// all time steps of one (slot, chunk group) go to the same XCD back to back, so the undistort tables of those rows are
+// fetched into that XCD's L2 once per batch instead of once per frame.
+struct TileId { int slot, cgroup, image; bool valid; };
+__device__ __forceinline__ TileId decode_tile(const FilterArgs& a, int b)
+{
+    TileId t;
+    const int xcd = b & 7, q_ = b >> 3;
+    const int groups = a.cam_mod * a.n_cgroups;
+    const int grp = (q_ / a.n_steps) * 8 + xcd;
+    const int tstep = q_ % a.n_steps;
+    t.slot = grp % a.cam_mod;
+    t.cgroup = grp / a.cam_mod;
+    t.image = tstep * a.cam_mod + t.slot;
+    t.valid = grp < groups && t.image < a.n_images;
+    return t;
+}
+
+// The strips of this wave's chunk that need work, 64 at a time (lane = strip): with the early-out, those whose row range
+// is not empty, plus -- filter kernel only -- those that were filtered in the previous batch and must be cleared;
+// occupancy words of the others are settled right here.  Without the early-out, all of them.
+template <bool FILTER>
+__device__ __forceinline__ uint64_t strips_to_do(const FilterArgs& a, size_t cell_row, int sbase, int lane)
+{
+    const int nrem = a.n_strips - sbase;
+    if (a.skip_allow < 0) return nrem >= 64 ? ~0ull : ((1ull << nrem) - 1ull);
+    bool work = false;
+    if (lane < nrem) {
+        const size_t ci = cell_row + sbase + lane;
+        const uint32_t lo = a.tile_rows[4 * ci], hi = a.tile_rows[4 * ci + 1];
+        work = lo <= hi;
+        if (FILTER) {
+            const uint32_t old = a.ext_mask ? 0u : a.cells[ci];
+            work = work || (old >> 31);
+            if (!work && (a.ext_mask || old != 0u)) a.cells[ci] = 0u; // dark and clean: an empty occupancy word
+        }
+    }
+    return __ballot(work);
+}
+
+// Patch of one filter tile: the undistorted pixels the tile's row pipeline will read (mask rows [r0, r1) + 4 rows
+// above and 3 below, the strip's 256 columns), row-major with a pitch of 256 bytes, first row = tile_r0 - 4.
+constexpr int PATCH_PITCH = 256;
+__device__ __forceinline__ size_t patch_offset(const FilterArgs& a, size_t cell_index)
+{
+    return cell_index * (size_t)(a.rows_per_chunk + 8) * PATCH_PITCH;
+}
+
+// The box of a marked tile inside its patch: rows [by0, by1] x column quads [qa, qb] (quad q = columns xbase + 4q .. +3),
+// from the ranges bright_cells_kernel left (ylo, yhi, xlo, xhi), clipped to the rows [in0, in1] the pipeline reads and
+// to the quads inside the image.  Empty if qa > qb or by0 > by1.
+struct PatchBox { int by0, by1, qa, qb; };
+__device__ __forceinline__ PatchBox patch_box(int ylo, int yhi, int xlo, int xhi, int in0, int in1, int xbase, int W)
+{
+    PatchBox b;
+    b.by0 = ylo > in0 ? ylo : in0; b.by1 = yhi < in1 ? yhi : in1;
+    b.qa = (xlo - xbase) >> 2; b.qb = (xhi - xbase) >> 2;
+    const int qmin = xbase < 0 ? 2 : 0, qmax = (W - 4 - xbase) >> 2 < 63 ? (W - 4 - xbase) >> 2 : 63;
+    b.qa = b.qa < qmin ? qmin : b.qa; b.qb = b.qb > qmax ? qmax : b.qb;
+    return b;
+}
+
+// the four patch pixels of a lane (columns xbase + 4*lane ..) in image row y: loaded from the nearest box row (so the
+// load is unconditional and always hits written memory); patch_valid says whether the value counts or is a zero
+__device__ __forceinline__ uint32_t fetch_patch4(const uint8_t* __restrict__ patch, int y, int prow0, int lane, const PatchBox& b)
+{
+    const int yc = y < b.by0 ? b.by0 : (y > b.by1 ? b.by1 : y);
+    const int lc = lane < b.qa ? b.qa : (lane > b.qb ? b.qb : lane);
+    return *(const uint32_t*)(patch + (uint32_t)(yc - prow0) * PATCH_PITCH + 4u * (uint32_t)lc);
+}
+__device__ __forceinline__ bool patch_valid(int y, int lane, const PatchBox& b)
+{
+    return y >= b.by0 && y <= b.by1 && lane >= b.qa && lane <= b.qb;
+}
+
+// undistort_patches_kernel -- cv::remap only where it can matter.  For every tile that bright_cells_kernel marked, the
+// box of pixels that hot cells can reach (rows and columns, including the 4 pixels of blur + median) is undistorted
+// exactly; every other pixel the tile's pipeline reads counts as 0 (filter_mask_kernel's patch path).  That is exact
+// for the mask: a 5x5 window with a set threshold bit lies inside the box (its centre is within 2 pixels of a pixel
+// that touches a hot cell), and zeros elsewhere can only lower box sums that are provably below the threshold.
+// The box is usually much narrower than the strip, so its pixels are dealt to the lanes compactly (several box rows
+// per wave instruction); the filter kernel then runs its plain (no gather) path on the patch.
+__global__ __launch_bounds__(256) void undistort_patches_kernel(FilterArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const TileId t = decode_tile(a, blockIdx.x);
+    if (!t.valid) return;
+    const int tile_r0 = (t.cgroup * 4 + wv) * a.rows_per_chunk;
+    if (tile_r0 >= a.H) return;
+    const int tile_r1 = tile_r0 + a.rows_per_chunk < a.H ? tile_r0 + a.rows_per_chunk : a.H;
+    const size_t cell_row = ((size_t)t.image * a.n_cgroups * 4 + (t.cgroup * 4 + wv)) * a.n_strips;
+    for (int sbase = 0; sbase < a.n_strips; sbase += 64)
+        for (uint64_t todo = strips_to_do<false>(a, cell_row, sbase, lane); todo; todo &= todo - 1) {
+    const int strip = sbase + __ffsll((long long)todo) - 1;
+    const size_t cell_index = cell_row + strip;
+    const uint32_t ylo = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_rows[4 * cell_index]);
+    const uint32_t yhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_rows[4 * cell_index + 1]);
+    if (ylo > yhi) continue; // dark tile
+    const int r0 = (int)ylo > tile_r0 ? (int)ylo : tile_r0, r1 = (int)yhi + 1 < tile_r1 ? (int)yhi + 1 : tile_r1;
+    if (r0 >= r1) continue;
+    const int xlo = __builtin_amdgcn_readfirstlane((int)a.tile_rows[4 * cell_index + 2]);
+    const int xhi = __builtin_amdgcn_readfirstlane((int)a.tile_rows[4 * cell_index + 3]);
+    const int Hm1 = a.H - 1;
+    const int in0 = r0 - 4 > 0 ? r0 - 4 : 0, in1 = r1 + 3 < Hm1 ? r1 + 3 : Hm1;     // rows the pipeline reads
+    const int xbase = strip * 240 - 8;
+    // The ranges left by bright_cells_kernel already include the 4 pixels of blur + median: a window with a set
+    // threshold bit is centred within 2 pixels of a pixel that reads a hot cell and extends 2 pixels further.
+    const PatchBox box = patch_box((int)ylo, (int)yhi, xlo, xhi, in0, in1, xbase, a.W);
+    const int by0 = box.by0, by1 = box.by1, qa = box.qa, qb = box.qb;
+    uint8_t* __restrict__ patch = a.patch + patch_offset(a, cell_index);
+    const int prow0 = tile_r0 - 4;
+    if (qa > qb || by0 > by1) continue;
+    // the box only (the filter kernel substitutes the zeros around it itself): nq quads per row, rpw rows per wave instruction
+    const uint8_t* __restrict__ img = a.src + (size_t)t.image * a.image_stride;
+    const uint32_t* __restrict__ map = a.map + (size_t)t.slot * a.H * a.W;
+    const uint32_t* __restrict__ mapw = a.mapw + (size_t)t.slot * a.H * a.W;
+    const int nq = qb - qa + 1, rpw = 64 / nq;
+    const int rsub = lane / nq, q = qa + (lane - rsub * nq);
+    const bool lane_on = rsub < rpw;
+    const int x = xbase + 4 * q; // inside the image and a multiple of 4 by construction
+    // U row groups per trip: all table loads first, then all tap loads, then the blends -- two memory round trips per
+    // trip instead of per row group.  Rows past the box are clamped to its last row (computed again, stored again with
+    // the same value): no branch around the loads.
+    constexpr int U = 4;
+    if (!lane_on) continue;
+    for (int rb = by0; rb <= by1; rb += U * rpw) {
+        int rows[U];
+        uint4 m4[U], w4[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            int row = rb + u * rpw + rsub;
+            rows[u] = row > by1 ? by1 : row;
+            __builtin_memcpy(&m4[u], map + ((uint32_t)rows[u] * (uint32_t)a.W + (uint32_t)x), 16);
+            __builtin_memcpy(&w4[u], mapw + ((uint32_t)rows[u] * (uint32_t)a.W + (uint32_t)x), 16);
+        }
+        uint32_t t0[U][4], t1[U][4];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t mm[4] = {m4[u].x, m4[u].y, m4[u].z, m4[u].w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t m = mm[k];
+                const int sx = x + k + (int)(int16_t)(m & 0xffffu), sy = rows[u] + ((int)m >> 16); // inside the image by construction
+                const uint32_t off0 = __umul24((uint32_t)sy, (uint32_t)a.pitch) + (uint32_t)sx;
+                t0[u][k] = load_u16(img + off0);
+                t1[u][k] = load_u16(img + off0 + (uint32_t)a.pitch);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t ww[4] = {w4[u].x, w4[u].y, w4[u].z, w4[u].w};
+            uint32_t out = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t w = ww[k];
+                const uint32_t top = dot4(t0[u][k], w, 0u), bot = dot4(t1[u][k], w, 0u); // tap bytes 2,3 are zero
+                uint32_t r = __umul24(top, w >> 24) + 512u;
+                r += __umul24(bot, (w >> 16) & 0xffu);
+                out |= (r >> 10) << (8 * k);
+            }
+            *(uint32_t*)(patch + (size_t)(rows[u] - prow0) * PATCH_PITCH + 4 * q) = out;
+        }
+    }
+        } // strips
+}
+
+template <bool REMAP, bool TINY, bool PIPE, bool LDSR, bool PATCH = false>
 __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
 {
     __shared__ uint32_t lut[256];
@@ -372,59 +545,44 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform: keeps the row loop scalar
 
-    // block -> (camera slot, strip, chunk group, time step).  Blocks b and b+8 share an XCD (round-robin dispatch;
-    // placement only affects speed).  Two orders:
-    //  * time-fastest: all time steps of one (slot, strip, chunk group) tile go to the same XCD back to back, so the
-    //    tile's undistort tables are fetched into that XCD's L2 once per batch instead of once per frame;
-    //  * strip-fastest: the strips of one (image, chunk group) go to the same XCD back to back, so the 128-byte
-    //    lines that two neighbouring strips share (strips overlap by 16 columns and are not line-aligned) are
-    //    fetched from HBM once.
-    const int b = blockIdx.x, xcd = b & 7, q_ = b >> 3;
-    int slot, strip, cgroup, tstep;
-    if (!a.strip_fastest) {
-        const int tiles = a.cam_mod * a.n_strips * a.n_cgroups;
-        const int tile = (q_ / a.n_steps) * 8 + xcd;
-        tstep = q_ % a.n_steps;
-        if (tile >= tiles) return;
-        slot = tile % a.cam_mod;
-        strip = (tile / a.cam_mod) % a.n_strips;
-        cgroup = tile / (a.cam_mod * a.n_strips);
-    } else {
-        const int groups = a.cam_mod * a.n_cgroups * a.n_steps;
-        const int grp = (q_ / a.n_strips) * 8 + xcd;
-        strip = q_ % a.n_strips;
-        if (grp >= groups) return;
-        slot = grp % a.cam_mod;
-        cgroup = (grp / a.cam_mod) % a.n_cgroups;
-        tstep = grp / (a.cam_mod * a.n_cgroups);
-    }
-    const int image = tstep * a.cam_mod + slot;
-    if (image >= a.n_images) return;
+    const TileId tid_ = decode_tile(a, blockIdx.x);
+    if (!tid_.valid) return;
+    const int slot = tid_.slot, cgroup = tid_.cgroup, image = tid_.image;
 
-    const int tile_r0 = (cgroup * 4 + wv) * a.rows_per_chunk; // the tile's mask rows [tile_r0, tile_r1)
+    const int tile_r0 = (cgroup * 4 + wv) * a.rows_per_chunk; // the tiles' mask rows [tile_r0, tile_r1)
     if (tile_r0 >= a.H) return;
     const int tile_r1 = tile_r0 + a.rows_per_chunk < a.H ? tile_r0 + a.rows_per_chunk : a.H;
+    const size_t cell_row = ((size_t)image * a.n_cgroups * 4 + (cgroup * 4 + wv)) * a.n_strips;
+    for (int sbase = 0; sbase < a.n_strips; sbase += 64)
+        for (uint64_t todo = strips_to_do<true>(a, cell_row, sbase, lane); todo; todo &= todo - 1) {
+    const int strip = sbase + __ffsll((long long)todo) - 1;
     int r0 = tile_r0, r1 = tile_r1;                            // the rows this wave filters
+    int box_ylo = 0, box_yhi = a.H - 1, box_xlo = 0, box_xhi = a.W - 1; // patch path: the exact pixels' box
     const int xbase = strip * 240 - 8;
-    const size_t cell_index = ((size_t)image * a.n_cgroups * 4 + (cgroup * 4 + wv)) * a.n_strips + strip;
+    const size_t cell_index = cell_row + strip;
 
     if (a.skip_allow >= 0) {
-        // ---- dark-tile early-out (see the comment above bright_count): first thing a wave does ----
+        // ---- dark-tile early-out (see the comment above bright_count) ----
         // bright_cells_kernel has left, per tile, the range of mask rows that hot cells of its source region can reach
         // (empty = none: the tile is all zeros).  Only those rows are filtered.  The context's mask keeps the
         // invariant "a tile's mask bytes are zero unless its occupancy word has bit 31 set" from batch to batch, so
         // rows that are not filtered only have to be cleared if the tile was filtered last time.
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_rows[2 * cell_index]);
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_rows[2 * cell_index + 1]);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_rows[4 * cell_index]);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_rows[4 * cell_index + 1]);
+        if (PATCH) {
+            box_ylo = (int)lo; box_yhi = (int)hi;
+            box_xlo = __builtin_amdgcn_readfirstlane((int)a.tile_rows[4 * cell_index + 2]);
+            box_xhi = __builtin_amdgcn_readfirstlane((int)a.tile_rows[4 * cell_index + 3]);
+        }
         if (lo <= hi) {
-            if (lane == 0) { a.tile_rows[2 * cell_index] = 0xffffffffu; a.tile_rows[2 * cell_index + 1] = 0u; } // ready for the next batch
+            if (lane < 4) a.tile_rows[4 * cell_index + lane] = (lane & 1) ? 0u : 0xffffffffu; // ready for the next batch
             if (!LDSR) { // (the LDS-staged variant's ring schedule is verified for whole tiles only)
                 r0 = (int)lo > r0 ? (int)lo : r0;
                 r1 = (int)hi + 1 < r1 ? (int)hi + 1 : r1;
             }
         }
         const bool dark = lo > hi || r0 >= r1;
-        const uint32_t old = a.fill_dark ? 0x80000000u : a.cells[cell_index];
+        const uint32_t old = a.ext_mask ? 0u : a.cells[cell_index]; // (a caller-owned mask was cleared by bright_cells_kernel)
         if (__builtin_amdgcn_readfirstlane((int)old) < 0) { // clear what will not be written below
             uint8_t* mrow = (uint8_t*)(a.mask + (size_t)image * a.H * a.words_per_row);
             const int rb = a.words_per_row * 4;
@@ -440,7 +598,7 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
         }
         if (dark) {
             if (lane == 0) a.cells[cell_index] = 0u;
-            return;
+            continue;
         }
     }
 
@@ -466,6 +624,10 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
     }
 
     const uint8_t* __restrict__ img = a.src + (size_t)image * a.image_stride;
+    const uint8_t* __restrict__ patch = PATCH ? a.patch + patch_offset(a, cell_index) : nullptr;
+    const int prow0 = tile_r0 - 4;
+    const PatchBox pbox = patch_box(box_ylo, box_yhi, box_xlo, box_xhi, r0 - 4 > 0 ? r0 - 4 : 0, r1 + 3 < a.H - 1 ? r1 + 3 : a.H - 1,
+                                    xbase, a.W);
     const uint32_t* __restrict__ map = REMAP ? a.map + (size_t)slot * a.H * a.W : nullptr;
     const uint32_t* __restrict__ mapw = REMAP ? a.mapw + (size_t)slot * a.H * a.W : nullptr;
     uint8_t* __restrict__ mrow_base = (uint8_t*)(a.mask + (size_t)image * a.H * a.words_per_row);
@@ -575,7 +737,7 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             int row = y0 + ((j + 5) & 7);
-            q[j] = fetch_src4<REMAP, TINY>(a, img, map, row, xl, lc);
+            q[j] = PATCH ? fetch_patch4(patch, row, prow0, lane, pbox) : fetch_src4<REMAP, TINY>(a, img, map, row, xl, lc);
         }
     }
     // next source row (row index `row`, queue slot J): its four pixels, and the refill of the pipeline behind it
@@ -600,10 +762,11 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
             remap_issue_map(mq[S], map, row + 8, a.H, a.W, lc);
             return B;
         } else {
-            uint32_t B = finish_src4<REMAP, TINY>(q[J], (unsigned)row < (unsigned)a.H, lc);
+            uint32_t B = PATCH ? (patch_valid(row, lane, pbox) ? q[J] : 0u)
+                               : finish_src4<REMAP, TINY>(q[J], (unsigned)row < (unsigned)a.H, lc);
             // refill 8 rows ahead, unconditionally (rows past the chunk are clamped into the image and simply
             // unused: a branch here would make the compiler drain the whole queue at the join)
-            q[J] = fetch_src4<REMAP, TINY>(a, img, map, row + 8, xl, lc);
+            q[J] = PATCH ? fetch_patch4(patch, row + 8, prow0, lane, pbox) : fetch_src4<REMAP, TINY>(a, img, map, row + 8, xl, lc);
             return B;
         }
     };
@@ -727,6 +890,7 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
         // bit 31 marks a tile that went through the full filter (the early-out writes 0); bits 0..16 are the groups
         if (lane == 0) a.cells[cell_index] = cellmask | 0x80000000u;
     }
+        } // strips
 }
 
 // ---- map construction: cv::initUndistortRectifyMap as called by cv::undistort (stripe by stripe) -------------
@@ -899,6 +1063,7 @@ __global__ void remap_spans_kernel(SpanArgs a)
         xmin = sx < xmin ? sx : xmin; xmax = sx + 1 > xmax ? sx + 1 : xmax;
     }
     a.spans[(size_t)strip * a.H + y] = make_uint2((uint32_t)smin | ((uint32_t)smax << 16), (uint32_t)xmin | ((uint32_t)xmax << 16));
+
 }
 
 // total blend weight every source pixel carries over all output pixels (scatter), for the dark-tile bound
@@ -914,6 +1079,16 @@ __global__ void remap_weight_scatter_kernel(StatArgs a)
     if (wx1 * wy0) atomicAdd(p + 1, wx1 * wy0);
     if (wx0 * wy1) atomicAdd(p + a.W, wx0 * wy1);
     if (wx1 * wy1) atomicAdd(p + a.W + 1, wx1 * wy1);
+    // reach of every 8x8 source cell: the bounding box of the output pixels that read it with a nonzero weight
+    const int ncx = (a.W + 7) >> 3;
+    auto touch = [&](int tx, int ty) {
+        int* r = a.reach + 4 * ((ty >> 3) * ncx + (tx >> 3));
+        atomicMin(r, x); atomicMax(r + 1, x); atomicMin(r + 2, y); atomicMax(r + 3, y);
+    };
+    if (wx0 * wy0) touch(sx, sy);
+    if (wx1 * wy0) touch(sx + 1, sy);
+    if (wx0 * wy1) touch(sx, sy + 1);
+    if (wx1 * wy1) touch(sx + 1, sy + 1);
 }
 __global__ void remap_stats_kernel(StatArgs a)
 {
@@ -954,17 +1129,23 @@ void launch_remap_spans(const SpanArgs& a, hipStream_t s)
     hipLaunchKernelGGL(remap_spans_kernel, dim3((a.H + 63) / 64, a.n_strips), dim3(64), 0, s, a);
 }
 
+static int filter_blocks(const FilterArgs& a)
+{
+    const int groups = a.cam_mod * a.n_cgroups;
+    return ((groups + 7) / 8) * 8 * a.n_steps;
+}
+
+void launch_undistort_patches(const FilterArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(undistort_patches_kernel, dim3(filter_blocks(a)), dim3(256), 0, s, a);
+}
+
 void launch_filter_mask(const FilterArgs& a, bool remap, hipStream_t s)
 {
-    int blocks;
-    if (!a.strip_fastest) {
-        int tiles = a.cam_mod * a.n_strips * a.n_cgroups;
-        blocks = ((tiles + 7) / 8) * 8 * a.n_steps;
-    } else {
-        int groups = a.cam_mod * a.n_cgroups * a.n_steps;
-        blocks = ((groups + 7) / 8) * 8 * a.n_strips;
-    }
-    if (remap && a.remap_mode == 4)
+    const int blocks = filter_blocks(a);
+    if (a.patch) // remapped cameras with the early-out: the plain pipeline on the undistorted patches
+        hipLaunchKernelGGL((filter_mask_kernel<false, false, false, false, true>), dim3(blocks), dim3(256), 0, s, a);
+    else if (remap && a.remap_mode == 4)
         hipLaunchKernelGGL((filter_mask_kernel<true, false, false, true>), dim3(blocks), dim3(256), 0, s, a);
     else if (remap && a.remap_mode == 3)
         hipLaunchKernelGGL((filter_mask_kernel<true, false, true, false>), dim3(blocks), dim3(256), 0, s, a);

@@ -21,12 +21,13 @@ struct FilterArgs {
     int remap_mode;       // 0 plain / 2 per-pixel gather, 3 pipelined gather, 4 LDS-staged
     int skip_allow;       // dark-tile early-out: a tile whose source region has no 16x16 block (2x2 cells of 8x8 px)
                           //   with more than this many pixels >= 64 provably yields an all-zero mask; -1 = off
-    uint32_t* tile_rows;  // [n_images][n_cgroups*4][n_strips][2] (indexed like cells): first / last mask row that hot cells of the
-                          //   tile's source region can reach, (0xffffffff, 0) = none; written by bright_cells_kernel, read and
-                          //   reset by the filter kernel; used if skip_allow >= 0
-    int fill_dark;        // 1 = dark tiles always write their zeros (caller-owned mask); 0 = only if the tile's previous
-                          //   occupancy word says it was filtered (the context's own mask, see the kernel)
-    int strip_fastest;    // block order: 1 = neighbouring strips share an XCD in time, 0 = time steps of a tile do
+    uint32_t* tile_rows;  // [n_images][n_cgroups*4][n_strips][4] (indexed like cells): first / last mask row and first / last
+                          //   column that hot cells of the tile's source region can reach, (0xffffffff, 0) = none; written by
+                          //   bright_cells_kernel, read and reset by the filter kernel; used if skip_allow >= 0
+    uint8_t* patch;       // optional [n_images][tiles][rows_per_chunk + 8][256]: undistorted boxes (undistort_patches_kernel);
+                          //   non-null selects the patch path (all cameras of the batch remapped, early-out on, W % 4 == 0)
+    int ext_mask;         // 1 = caller-owned mask (with the early-out: cleared by bright_cells_kernel, occupancy words of dark
+                          //   tiles always written); 0 = the context's own mask (cleared on demand, see the filter kernel)
     int cam_mod;          // undistort slot of image n = n % cam_mod (map already points at the first slot)
     int n_images, n_steps; // n_steps = ceil(n_images / cam_mod)
     int thr_mul;          // floor(thresh)+1: blurred > thresh  <=>  S >= thr_mul * taps
@@ -77,14 +78,15 @@ struct ContourArgs {
 enum { BLOB_ERR_CANDIDATES = -2, BLOB_ERR_CONTOURS = -3, BLOB_ERR_STEPS = -4, BLOB_ERR_DEPTH = -5 };
 
 void launch_filter_mask(const FilterArgs& a, bool remap, hipStream_t s);
+void launch_undistort_patches(const FilterArgs& a, hipStream_t s); // needs a.patch; before launch_filter_mask
 struct BrightArgs {
     const uint8_t* src; size_t image_stride; int pitch, H, W, n_images; // W >= 8
     int cam_mod;                  // undistort slot of image n = n % cam_mod (hull already points at the first slot)
     int hot, hot_edge, hot_corner; // a cell with more than this many pixels >= 64 is hot (4 * hot <= skip_allow); _edge /
                                   //   _corner for cells feeding windows the image border cuts in one axis / in both
-    const uint2* hull;            // [cam_mod][cells]: tiles whose source region contains the cell (see mocap_set_undistort)
-    uint32_t* tile_rows; int n_chunks, n_strips; // reachable mask rows per tile, see FilterArgs
-    const uint16_t* dil;          // [cam_mod][tiles] reach in rows of a source row of the tile's region (see the kernel)
+    const uint2* reach;           // [cam_mod][cells]: box of the output pixels that read the 8x8 source cell, x0 | x1 << 16, y0 | y1 << 16
+    const uint8_t* cflags;        // [cam_mod][cells]: 1 / 2 = the cell feeds windows the image border cuts in one axis / in both
+    uint32_t* tile_rows; int n_chunks, n_strips, rows_per_chunk; // reachable mask rows / columns per tile, see FilterArgs
     uint32_t* mask; size_t mask_words; int mask_aligned16; // caller-owned bit masks to clear on the side (mask_words = 0: none)
 };
 void launch_bright_cells(const BrightArgs& a, hipStream_t s);
@@ -93,8 +95,9 @@ struct SpanArgs { const uint32_t* map; uint2* spans; int H, W, n_strips; };
 // pixel carries over all output pixels (1024 = one full pixel), stats[1] / stats[2] = largest x / y extent (in source
 // pixels) of the taps feeding one 5x5 output window.  acc: H*W zero-initialised scratch words.  edge: zero-initialised
 // [ceil(H/8)][ceil(W/8)] words, bit 0 / bit 1 set for the 8x8 source cells read by windows that the image border cuts
-// in exactly one axis / in both.
-struct StatArgs { const uint32_t* map; const uint32_t* mapw; uint32_t* acc; uint32_t* stats; int H, W; uint32_t* edge; };
+// in exactly one axis / in both.  reach: [cells][4] = x0, x1, y0, y1 initialised to (INT_MAX, INT_MIN, INT_MAX, INT_MIN):
+// bounding box of the output pixels that read the cell with a nonzero weight.
+struct StatArgs { const uint32_t* map; const uint32_t* mapw; uint32_t* acc; uint32_t* stats; int H, W; uint32_t* edge; int* reach; };
 void launch_remap_stats(const StatArgs& a, hipStream_t s);
 void launch_remap_spans(const SpanArgs& a, hipStream_t s);
 constexpr int RING_H = 32, RING_W = 288, RING_LOOKAHEAD = 5; // LDS source-row ring of the staged remap (per wave)

@@ -262,11 +262,12 @@ class MocapContext:
 
     def profile_read(self):
         """Accumulated HIP-event milliseconds / launch counts per kernel since the last read (mocap_hip.h)."""
-        ms = (C.c_double * 4)()
-        n = (C.c_int * 4)()
+        ms = (C.c_double * 5)()
+        n = (C.c_int * 5)()
         _abi.check(self.lib.mocap_profile_read(self._h, ms, n))
         return {"filter_ms": ms[0], "filter_launches": n[0], "contour_ms": ms[1], "contour_launches": n[1],
-                "corr_ms": ms[2], "corr_launches": n[2], "scan_ms": ms[3], "scan_launches": n[3]}
+                "corr_ms": ms[2], "corr_launches": n[2], "scan_ms": ms[3], "scan_launches": n[3],
+                "patch_ms": ms[4], "patch_launches": n[4]}
 
 
 _contexts = {}

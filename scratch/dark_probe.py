@@ -23,5 +23,5 @@ for name, dist in (("mild", MILD_DIST), ("zero", ZERO_DIST)):
         torch.cuda.synchronize()
         tr.ctx.profile(False)
         p = tr.ctx.profile_read()
-        print(name, kind, {k: round(p[k + "_ms"] / max(1, p[k + "_launches"]), 4) for k in ("scan", "filter", "contour")}, tr.ctx.tile_stats(), flush=True)
+        print(name, kind, {k: round(p[k + "_ms"] / max(1, p[k + "_launches"]), 4) for k in ("scan", "patch", "filter", "contour")}, tr.ctx.tile_stats(), flush=True)
     del tr
