@@ -454,8 +454,9 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
             if ((size_t)n_images > c->patch_images) {
                 std::lock_guard<std::mutex> lk(c->mu);
                 if (c->patch) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c->patch)); c->patch = nullptr; c->patch_images = 0; }
-                HIP_TRY(hipMalloc(&c->patch, (size_t)n_images * cells_per_image(c) * (tl.rows + 8) * 256));
-                c->patch_images = n_images;
+                if (hipMalloc(&c->patch, (size_t)n_images * cells_per_image(c) * (tl.rows + 8) * 256) == hipSuccess)
+                    c->patch_images = n_images;
+                else { (void)hipGetLastError(); c->patch = nullptr; } // no room for patches: gather in the filter kernel instead
             }
             a.patch = c->patch;
         }
