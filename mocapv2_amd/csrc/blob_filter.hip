@@ -366,10 +366,11 @@ __device__ __forceinline__ int taps5(int v, int n)
 template <int J> struct IC { static constexpr int value = J; };
 
 
-// workgroup -> (camera slot, chunk group, time step); wave wv of the workgroup owns chunk cgroup * 4 + wv and walks over
-// that chunk's strips (tiles).  (Single-wave workgroups were measured too: no better.)  Blocks b and b+8 share an XCD (round-robin dispatch; placement only affects speed):
-// all time steps of one (slot, chunk group) go to the same XCD back to back, so the undistort tables of those rows are
-// fetched into that XCD's L2 once per batch instead of once per frame.
+// workgroup -> (camera slot, chunk group, time step): its four waves share the tiles (4 chunks x all strips) of that
+// chunk group through a work list (below).  Blocks b and b+8 share an XCD (round-robin dispatch; placement only affects
+// speed): all time steps of one (slot, chunk group) go to the same XCD back to back, so the undistort tables of those
+// rows are fetched into that XCD's L2 once per batch instead of once per frame.  (Single-wave workgroups were measured
+// too: no better.)
 struct TileId { int slot, cgroup, image; bool valid; };
 __device__ __forceinline__ TileId decode_tile(const FilterArgs& a, int b)
 {
@@ -385,26 +386,49 @@ __device__ __forceinline__ TileId decode_tile(const FilterArgs& a, int b)
     return t;
 }
 
-// The strips of this wave's chunk that need work, 64 at a time (lane = strip): with the early-out, those whose row range
-// is not empty, plus -- filter kernel only -- those that were filtered in the previous batch and must be cleared;
-// occupancy words of the others are settled right here.  Without the early-out, all of them.
+// Work list of a workgroup: the tiles (chunk of the group, strip) of its four chunks that need work -- with the
+// early-out, those whose box is not empty, plus (filter kernel only) those that were filtered in the previous batch and
+// must be cleared; occupancy words of the others are settled right here; without the early-out, all of them.  Each wave
+// tests the strips of one chunk with one lane-parallel load (lane = strip); afterwards the four waves take tiles from the
+// list one by one, so a chunk with several marked strips does not hold up one wave while the others idle.
+constexpr int MAX_STRIPS = 144; // 32767 / 240 + 1 rounded up
+struct WorkList { uint16_t tile[4 * MAX_STRIPS]; int n, head; };
 template <bool FILTER>
-__device__ __forceinline__ uint64_t strips_to_do(const FilterArgs& a, size_t cell_row, int sbase, int lane)
+__device__ __forceinline__ void list_work(const FilterArgs& a, WorkList& wl, int image, int cgroup, int wv, int lane)
 {
-    const int nrem = a.n_strips - sbase;
-    if (a.skip_allow < 0) return nrem >= 64 ? ~0ull : ((1ull << nrem) - 1ull);
-    bool work = false;
-    if (lane < nrem) {
-        const size_t ci = cell_row + sbase + lane;
-        const uint32_t lo = a.tile_rows[4 * ci], hi = a.tile_rows[4 * ci + 1];
-        work = lo <= hi;
-        if (FILTER) {
-            const uint32_t old = a.ext_mask ? 0u : a.cells[ci];
-            work = work || (old >> 31);
-            if (!work && (a.ext_mask || old != 0u)) a.cells[ci] = 0u; // dark and clean: an empty occupancy word
+    if (threadIdx.x == 0) { wl.n = 0; wl.head = 0; }
+    __syncthreads();
+    const int chunk = cgroup * 4 + wv;
+    if (chunk * a.rows_per_chunk < a.H) {
+        const size_t cell_row = ((size_t)image * a.n_cgroups * 4 + chunk) * a.n_strips;
+        for (int sbase = 0; sbase < a.n_strips; sbase += 64) {
+            const int strip = sbase + lane;
+            bool work = false;
+            if (strip < a.n_strips) {
+                work = true;
+                if (a.skip_allow >= 0) {
+                    const size_t ci = cell_row + strip;
+                    const uint32_t lo = a.tile_rows[4 * ci], hi = a.tile_rows[4 * ci + 1];
+                    work = lo <= hi;
+                    if (FILTER) {
+                        const uint32_t old = a.ext_mask ? 0u : a.cells[ci];
+                        work = work || (old >> 31);
+                        if (!work && (a.ext_mask || old != 0u)) a.cells[ci] = 0u; // dark and clean: an empty occupancy word
+                    }
+                }
+            }
+            if (work) wl.tile[atomicAdd(&wl.n, 1)] = (uint16_t)((wv << 8) | strip);
         }
     }
-    return __ballot(work);
+    __syncthreads();
+}
+// next tile of the list for this wave: (chunk of the group << 8 | strip), or -1 when the list is exhausted
+__device__ __forceinline__ int next_work(WorkList& wl, int lane)
+{
+    int i = 0;
+    if (lane == 0) i = atomicAdd(&wl.head, 1);
+    i = __builtin_amdgcn_readfirstlane(i);
+    return i < wl.n ? (int)wl.tile[i] : -1;
 }
 
 // Patch of one filter tile: the undistorted pixels the tile's row pipeline will read (mask rows [r0, r1) + 4 rows
@@ -453,16 +477,15 @@ __global__ __launch_bounds__(256) void undistort_patches_kernel(FilterArgs a)
 {
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __shared__ WorkList wl;
     const TileId t = decode_tile(a, blockIdx.x);
     if (!t.valid) return;
-    const int tile_r0 = (t.cgroup * 4 + wv) * a.rows_per_chunk;
-    if (tile_r0 >= a.H) return;
+    list_work<false>(a, wl, t.image, t.cgroup, wv, lane);
+        for (int e = next_work(wl, lane); e >= 0; e = next_work(wl, lane)) {
+    const int chunk = t.cgroup * 4 + (e >> 8), strip = e & 0xff;
+    const int tile_r0 = chunk * a.rows_per_chunk;
     const int tile_r1 = tile_r0 + a.rows_per_chunk < a.H ? tile_r0 + a.rows_per_chunk : a.H;
-    const size_t cell_row = ((size_t)t.image * a.n_cgroups * 4 + (t.cgroup * 4 + wv)) * a.n_strips;
-    for (int sbase = 0; sbase < a.n_strips; sbase += 64)
-        for (uint64_t todo = strips_to_do<false>(a, cell_row, sbase, lane); todo; todo &= todo - 1) {
-    const int strip = sbase + __ffsll((long long)todo) - 1;
-    const size_t cell_index = cell_row + strip;
+    const size_t cell_index = ((size_t)t.image * a.n_cgroups * 4 + chunk) * a.n_strips + strip;
     const uint32_t ylo = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_rows[4 * cell_index]);
     const uint32_t yhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_rows[4 * cell_index + 1]);
     if (ylo > yhi) continue; // dark tile
@@ -549,13 +572,13 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
     if (!tid_.valid) return;
     const int slot = tid_.slot, cgroup = tid_.cgroup, image = tid_.image;
 
-    const int tile_r0 = (cgroup * 4 + wv) * a.rows_per_chunk; // the tiles' mask rows [tile_r0, tile_r1)
-    if (tile_r0 >= a.H) return;
+    __shared__ WorkList wl;
+    list_work<true>(a, wl, image, cgroup, wv, lane);
+        for (int e = next_work(wl, lane); e >= 0; e = next_work(wl, lane)) {
+    const int chunk = cgroup * 4 + (e >> 8), strip = e & 0xff;
+    const int tile_r0 = chunk * a.rows_per_chunk;              // the tile's mask rows [tile_r0, tile_r1)
     const int tile_r1 = tile_r0 + a.rows_per_chunk < a.H ? tile_r0 + a.rows_per_chunk : a.H;
-    const size_t cell_row = ((size_t)image * a.n_cgroups * 4 + (cgroup * 4 + wv)) * a.n_strips;
-    for (int sbase = 0; sbase < a.n_strips; sbase += 64)
-        for (uint64_t todo = strips_to_do<true>(a, cell_row, sbase, lane); todo; todo &= todo - 1) {
-    const int strip = sbase + __ffsll((long long)todo) - 1;
+    const size_t cell_row = ((size_t)image * a.n_cgroups * 4 + chunk) * a.n_strips;
     int r0 = tile_r0, r1 = tile_r1;                            // the rows this wave filters
     int box_ylo = 0, box_yhi = a.H - 1, box_xlo = 0, box_xhi = a.W - 1; // patch path: the exact pixels' box
     const int xbase = strip * 240 - 8;
