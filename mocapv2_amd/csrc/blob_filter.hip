@@ -366,19 +366,17 @@ __device__ __forceinline__ int taps5(int v, int n)
 template <int J> struct IC { static constexpr int value = J; };
 
 
-// workgroup -> (camera slot, chunk group, time step): its four waves share the tiles (4 chunks x all strips) of that
-// chunk group through a work list (below).  Blocks b and b+8 share an XCD (round-robin dispatch; placement only affects
-// speed): all time steps of one (slot, chunk group) go to the same XCD back to back, so the undistort tables of those
-// rows are fetched into that XCD's L2 once per batch instead of once per frame.  (Single-wave workgroups were measured
-// too: no better.)
-struct TileId { int slot, cgroup, image; bool valid; };
+// workgroup -> (camera slot, group of CPB chunks, time step): its four waves share the tiles (CPB chunks x all strips; a
+// half of a 1080p image; 4 and 16 measured slightly slower) of that group through a work list (below).  Only the marked tiles' boxes touch the undistort
+// tables, far too little per camera to keep anything resident in an XCD's L2, so there is no XCD-aware placement here.
+constexpr int CPB = 8; // chunks per workgroup (4 per wave for the dark test; the marked tiles are shared by all waves)
+struct TileId { int slot, cgroup, image; bool valid; }; // cgroup: group of CPB chunks
+__device__ __forceinline__ int block_groups(const FilterArgs& a) { return (a.n_cgroups * 4 + CPB - 1) / CPB; }
 __device__ __forceinline__ TileId decode_tile(const FilterArgs& a, int b)
 {
     TileId t;
-    const int xcd = b & 7, q_ = b >> 3;
-    const int groups = a.cam_mod * a.n_cgroups;
-    const int grp = (q_ / a.n_steps) * 8 + xcd;
-    const int tstep = q_ % a.n_steps;
+    const int groups = a.cam_mod * block_groups(a);
+    const int grp = b / a.n_steps, tstep = b - grp * a.n_steps;
     t.slot = grp % a.cam_mod;
     t.cgroup = grp / a.cam_mod;
     t.image = tstep * a.cam_mod + t.slot;
@@ -392,14 +390,15 @@ __device__ __forceinline__ TileId decode_tile(const FilterArgs& a, int b)
 // tests the strips of one chunk with one lane-parallel load (lane = strip); afterwards the four waves take tiles from the
 // list one by one, so a chunk with several marked strips does not hold up one wave while the others idle.
 constexpr int MAX_STRIPS = 144; // 32767 / 240 + 1 rounded up
-struct WorkList { uint16_t tile[4 * MAX_STRIPS]; int n, head; };
+struct WorkList { uint16_t tile[CPB * MAX_STRIPS]; int n, head; };
 template <bool FILTER>
 __device__ __forceinline__ void list_work(const FilterArgs& a, WorkList& wl, int image, int cgroup, int wv, int lane)
 {
     if (threadIdx.x == 0) { wl.n = 0; wl.head = 0; }
     __syncthreads();
-    const int chunk = cgroup * 4 + wv;
-    if (chunk * a.rows_per_chunk < a.H) {
+    for (int j = wv; j < CPB; j += 4) {
+        const int chunk = cgroup * CPB + j;
+        if (chunk * a.rows_per_chunk >= a.H) break;
         const size_t cell_row = ((size_t)image * a.n_cgroups * 4 + chunk) * a.n_strips;
         for (int sbase = 0; sbase < a.n_strips; sbase += 64) {
             const int strip = sbase + lane;
@@ -417,7 +416,7 @@ __device__ __forceinline__ void list_work(const FilterArgs& a, WorkList& wl, int
                     }
                 }
             }
-            if (work) wl.tile[atomicAdd(&wl.n, 1)] = (uint16_t)((wv << 8) | strip);
+            if (work) wl.tile[atomicAdd(&wl.n, 1)] = (uint16_t)((j << 8) | strip);
         }
     }
     __syncthreads();
@@ -482,7 +481,7 @@ __global__ __launch_bounds__(256) void undistort_patches_kernel(FilterArgs a)
     if (!t.valid) return;
     list_work<false>(a, wl, t.image, t.cgroup, wv, lane);
         for (int e = next_work(wl, lane); e >= 0; e = next_work(wl, lane)) {
-    const int chunk = t.cgroup * 4 + (e >> 8), strip = e & 0xff;
+    const int chunk = t.cgroup * CPB + (e >> 8), strip = e & 0xff;
     const int tile_r0 = chunk * a.rows_per_chunk;
     const int tile_r1 = tile_r0 + a.rows_per_chunk < a.H ? tile_r0 + a.rows_per_chunk : a.H;
     const size_t cell_index = ((size_t)t.image * a.n_cgroups * 4 + chunk) * a.n_strips + strip;
@@ -575,7 +574,7 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
     __shared__ WorkList wl;
     list_work<true>(a, wl, image, cgroup, wv, lane);
         for (int e = next_work(wl, lane); e >= 0; e = next_work(wl, lane)) {
-    const int chunk = cgroup * 4 + (e >> 8), strip = e & 0xff;
+    const int chunk = cgroup * CPB + (e >> 8), strip = e & 0xff;
     const int tile_r0 = chunk * a.rows_per_chunk;              // the tile's mask rows [tile_r0, tile_r1)
     const int tile_r1 = tile_r0 + a.rows_per_chunk < a.H ? tile_r0 + a.rows_per_chunk : a.H;
     const size_t cell_row = ((size_t)image * a.n_cgroups * 4 + chunk) * a.n_strips;
@@ -1154,8 +1153,8 @@ void launch_remap_spans(const SpanArgs& a, hipStream_t s)
 
 static int filter_blocks(const FilterArgs& a)
 {
-    const int groups = a.cam_mod * a.n_cgroups;
-    return ((groups + 7) / 8) * 8 * a.n_steps;
+    const int groups = a.cam_mod * ((a.n_cgroups * 4 + CPB - 1) / CPB);
+    return groups * a.n_steps;
 }
 
 void launch_undistort_patches(const FilterArgs& a, hipStream_t s)
