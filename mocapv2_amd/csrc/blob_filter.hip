@@ -480,7 +480,9 @@ __global__ __launch_bounds__(256) void undistort_patches_kernel(FilterArgs a)
     const TileId t = decode_tile(a, blockIdx.x);
     if (!t.valid) return;
     list_work<false>(a, wl, t.image, t.cgroup, wv, lane);
-        for (int e = next_work(wl, lane); e >= 0; e = next_work(wl, lane)) {
+    // every marked tile is worked on by all four waves together: wave w takes trips w, w + 4, ... of its box
+        for (int i = 0; i < wl.n; ++i) {
+    const int e = (int)wl.tile[i];
     const int chunk = t.cgroup * CPB + (e >> 8), strip = e & 0xff;
     const int tile_r0 = chunk * a.rows_per_chunk;
     const int tile_r1 = tile_r0 + a.rows_per_chunk < a.H ? tile_r0 + a.rows_per_chunk : a.H;
@@ -515,7 +517,7 @@ __global__ __launch_bounds__(256) void undistort_patches_kernel(FilterArgs a)
     // the same value): no branch around the loads.
     constexpr int U = 4;
     if (!lane_on) continue;
-    for (int rb = by0; rb <= by1; rb += U * rpw) {
+    for (int rb = by0 + wv * U * rpw; rb <= by1; rb += 4 * U * rpw) {
         int rows[U];
         uint4 m4[U], w4[U];
 #pragma unroll
