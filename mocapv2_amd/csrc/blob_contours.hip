@@ -342,10 +342,16 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
             if (y >= yend || 8 * g + j >= R) continue;
             const int xa = 240 * st, xb = xa + 240 < a.W ? xa + 240 : a.W; // columns [xa, xb)
             const int ka = xa >> 5, kb = (xb - 1) >> 5;
+            // words are requested three iterations before they are needed (a dependent L2 round trip per word otherwise)
             uint32_t prev_w = ka > 0 ? M.word(y, ka - 1) : 0u, prev_n = ka > 0 ? M.word(y - 1, ka - 1) : 0u;
             uint32_t cur_w = M.word(y, ka), cur_n = M.word(y - 1, ka);
+            uint32_t w1 = M.word(y, ka + 1), n1 = M.word(y - 1, ka + 1);
+            uint32_t w2 = M.word(y, ka + 2), n2 = M.word(y - 1, ka + 2);
+            uint32_t w3 = M.word(y, ka + 3), n3 = M.word(y - 1, ka + 3);
             for (int k = ka; k <= kb; k++) {
-                uint32_t next_w = M.word(y, k + 1), next_n = M.word(y - 1, k + 1);
+                const uint32_t next_w = w1, next_n = n1;
+                w1 = w2; n1 = n2; w2 = w3; n2 = n3;
+                w3 = k + 4 <= kb + 1 ? M.word(y, k + 4) : 0u; n3 = k + 4 <= kb + 1 ? M.word(y - 1, k + 4) : 0u;
                 uint32_t w = cur_w, n = cur_n;
                 uint32_t Wn = (w << 1) | (prev_w >> 31);
                 // Necessary conditions, evaluated on the 64 columns starting at this word (this word + the next):
