@@ -481,81 +481,81 @@ __global__ __launch_bounds__(256) void undistort_patches_kernel(FilterArgs a)
     if (!t.valid) return;
     list_work<false>(a, wl, t.image, t.cgroup, wv, lane);
     // every marked tile is worked on by all four waves together: wave w takes trips w, w + 4, ... of its box
-        for (int i = 0; i < wl.n; ++i) {
-    const int e = (int)wl.tile[i];
-    const int chunk = t.cgroup * CPB + (e >> 8), strip = e & 0xff;
-    const int tile_r0 = chunk * a.rows_per_chunk;
-    const int tile_r1 = tile_r0 + a.rows_per_chunk < a.H ? tile_r0 + a.rows_per_chunk : a.H;
-    const size_t cell_index = ((size_t)t.image * a.n_cgroups * 4 + chunk) * a.n_strips + strip;
-    const uint32_t ylo = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_rows[4 * cell_index]);
-    const uint32_t yhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_rows[4 * cell_index + 1]);
-    if (ylo > yhi) continue; // dark tile
-    const int r0 = (int)ylo > tile_r0 ? (int)ylo : tile_r0, r1 = (int)yhi + 1 < tile_r1 ? (int)yhi + 1 : tile_r1;
-    if (r0 >= r1) continue;
-    const int xlo = __builtin_amdgcn_readfirstlane((int)a.tile_rows[4 * cell_index + 2]);
-    const int xhi = __builtin_amdgcn_readfirstlane((int)a.tile_rows[4 * cell_index + 3]);
-    const int Hm1 = a.H - 1;
-    const int in0 = r0 - 4 > 0 ? r0 - 4 : 0, in1 = r1 + 3 < Hm1 ? r1 + 3 : Hm1;     // rows the pipeline reads
-    const int xbase = strip * 240 - 8;
-    // The ranges left by bright_cells_kernel already include the 4 pixels of blur + median: a window with a set
-    // threshold bit is centred within 2 pixels of a pixel that reads a hot cell and extends 2 pixels further.
-    const PatchBox box = patch_box((int)ylo, (int)yhi, xlo, xhi, in0, in1, xbase, a.W);
-    const int by0 = box.by0, by1 = box.by1, qa = box.qa, qb = box.qb;
-    uint8_t* __restrict__ patch = a.patch + patch_offset(a, cell_index);
-    const int prow0 = tile_r0 - 4;
-    if (qa > qb || by0 > by1) continue;
-    // the box only (the filter kernel substitutes the zeros around it itself): nq quads per row, rpw rows per wave instruction
-    const uint8_t* __restrict__ img = a.src + (size_t)t.image * a.image_stride;
-    const uint32_t* __restrict__ map = a.map + (size_t)t.slot * a.H * a.W;
-    const uint32_t* __restrict__ mapw = a.mapw + (size_t)t.slot * a.H * a.W;
-    const int nq = qb - qa + 1, rpw = 64 / nq;
-    const int rsub = lane / nq, q = qa + (lane - rsub * nq);
-    const bool lane_on = rsub < rpw;
-    const int x = xbase + 4 * q; // inside the image and a multiple of 4 by construction
-    // U row groups per trip: all table loads first, then all tap loads, then the blends -- two memory round trips per
-    // trip instead of per row group.  Rows past the box are clamped to its last row (computed again, stored again with
-    // the same value): no branch around the loads.
-    constexpr int U = 4;
-    if (!lane_on) continue;
-    for (int rb = by0 + wv * U * rpw; rb <= by1; rb += 4 * U * rpw) {
-        int rows[U];
-        uint4 m4[U], w4[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            int row = rb + u * rpw + rsub;
-            rows[u] = row > by1 ? by1 : row;
-            __builtin_memcpy(&m4[u], map + ((uint32_t)rows[u] * (uint32_t)a.W + (uint32_t)x), 16);
-            __builtin_memcpy(&w4[u], mapw + ((uint32_t)rows[u] * (uint32_t)a.W + (uint32_t)x), 16);
-        }
-        uint32_t t0[U][4], t1[U][4];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const uint32_t mm[4] = {m4[u].x, m4[u].y, m4[u].z, m4[u].w};
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t m = mm[k];
-                const int sx = x + k + (int)(int16_t)(m & 0xffffu), sy = rows[u] + ((int)m >> 16); // inside the image by construction
-                const uint32_t off0 = __umul24((uint32_t)sy, (uint32_t)a.pitch) + (uint32_t)sx;
-                t0[u][k] = load_u16(img + off0);
-                t1[u][k] = load_u16(img + off0 + (uint32_t)a.pitch);
+    for (int i = 0; i < wl.n; ++i) {
+        const int e = (int)wl.tile[i];
+        const int chunk = t.cgroup * CPB + (e >> 8), strip = e & 0xff;
+        const int tile_r0 = chunk * a.rows_per_chunk;
+        const int tile_r1 = tile_r0 + a.rows_per_chunk < a.H ? tile_r0 + a.rows_per_chunk : a.H;
+        const size_t cell_index = ((size_t)t.image * a.n_cgroups * 4 + chunk) * a.n_strips + strip;
+        const uint32_t ylo = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_rows[4 * cell_index]);
+        const uint32_t yhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_rows[4 * cell_index + 1]);
+        if (ylo > yhi) continue; // dark tile
+        const int r0 = (int)ylo > tile_r0 ? (int)ylo : tile_r0, r1 = (int)yhi + 1 < tile_r1 ? (int)yhi + 1 : tile_r1;
+        if (r0 >= r1) continue;
+        const int xlo = __builtin_amdgcn_readfirstlane((int)a.tile_rows[4 * cell_index + 2]);
+        const int xhi = __builtin_amdgcn_readfirstlane((int)a.tile_rows[4 * cell_index + 3]);
+        const int Hm1 = a.H - 1;
+        const int in0 = r0 - 4 > 0 ? r0 - 4 : 0, in1 = r1 + 3 < Hm1 ? r1 + 3 : Hm1;     // rows the pipeline reads
+        const int xbase = strip * 240 - 8;
+        // The ranges left by bright_cells_kernel already include the 4 pixels of blur + median: a window with a set
+        // threshold bit is centred within 2 pixels of a pixel that reads a hot cell and extends 2 pixels further.
+        const PatchBox box = patch_box((int)ylo, (int)yhi, xlo, xhi, in0, in1, xbase, a.W);
+        const int by0 = box.by0, by1 = box.by1, qa = box.qa, qb = box.qb;
+        uint8_t* __restrict__ patch = a.patch + patch_offset(a, cell_index);
+        const int prow0 = tile_r0 - 4;
+        if (qa > qb || by0 > by1) continue;
+        // the box only (the filter kernel substitutes the zeros around it itself): nq quads per row, rpw rows per wave instruction
+        const uint8_t* __restrict__ img = a.src + (size_t)t.image * a.image_stride;
+        const uint32_t* __restrict__ map = a.map + (size_t)t.slot * a.H * a.W;
+        const uint32_t* __restrict__ mapw = a.mapw + (size_t)t.slot * a.H * a.W;
+        const int nq = qb - qa + 1, rpw = 64 / nq;
+        const int rsub = lane / nq, q = qa + (lane - rsub * nq);
+        const bool lane_on = rsub < rpw;
+        const int x = xbase + 4 * q; // inside the image and a multiple of 4 by construction
+        // U row groups per trip: all table loads first, then all tap loads, then the blends -- two memory round trips per
+        // trip instead of per row group.  Rows past the box are clamped to its last row (computed again, stored again with
+        // the same value): no branch around the loads.
+        constexpr int U = 4;
+        if (!lane_on) continue;
+        for (int rb = by0 + wv * U * rpw; rb <= by1; rb += 4 * U * rpw) {
+            int rows[U];
+            uint4 m4[U], w4[U];
+    #pragma unroll
+            for (int u = 0; u < U; u++) {
+                int row = rb + u * rpw + rsub;
+                rows[u] = row > by1 ? by1 : row;
+                __builtin_memcpy(&m4[u], map + ((uint32_t)rows[u] * (uint32_t)a.W + (uint32_t)x), 16);
+                __builtin_memcpy(&w4[u], mapw + ((uint32_t)rows[u] * (uint32_t)a.W + (uint32_t)x), 16);
+            }
+            uint32_t t0[U][4], t1[U][4];
+    #pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t mm[4] = {m4[u].x, m4[u].y, m4[u].z, m4[u].w};
+    #pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t m = mm[k];
+                    const int sx = x + k + (int)(int16_t)(m & 0xffffu), sy = rows[u] + ((int)m >> 16); // inside the image by construction
+                    const uint32_t off0 = __umul24((uint32_t)sy, (uint32_t)a.pitch) + (uint32_t)sx;
+                    t0[u][k] = load_u16(img + off0);
+                    t1[u][k] = load_u16(img + off0 + (uint32_t)a.pitch);
+                }
+            }
+    #pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t ww[4] = {w4[u].x, w4[u].y, w4[u].z, w4[u].w};
+                uint32_t out = 0;
+    #pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t w = ww[k];
+                    const uint32_t top = dot4(t0[u][k], w, 0u), bot = dot4(t1[u][k], w, 0u); // tap bytes 2,3 are zero
+                    uint32_t r = __umul24(top, w >> 24) + 512u;
+                    r += __umul24(bot, (w >> 16) & 0xffu);
+                    out |= (r >> 10) << (8 * k);
+                }
+                *(uint32_t*)(patch + (size_t)(rows[u] - prow0) * PATCH_PITCH + 4 * q) = out;
             }
         }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const uint32_t ww[4] = {w4[u].x, w4[u].y, w4[u].z, w4[u].w};
-            uint32_t out = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t w = ww[k];
-                const uint32_t top = dot4(t0[u][k], w, 0u), bot = dot4(t1[u][k], w, 0u); // tap bytes 2,3 are zero
-                uint32_t r = __umul24(top, w >> 24) + 512u;
-                r += __umul24(bot, (w >> 16) & 0xffu);
-                out |= (r >> 10) << (8 * k);
-            }
-            *(uint32_t*)(patch + (size_t)(rows[u] - prow0) * PATCH_PITCH + 4 * q) = out;
-        }
-    }
-        } // strips
+    } // marked tiles
 }
 
 template <bool REMAP, bool TINY, bool PIPE, bool LDSR, bool PATCH = false>
@@ -575,346 +575,346 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
 
     __shared__ WorkList wl;
     list_work<true>(a, wl, image, cgroup, wv, lane);
-        for (int e = next_work(wl, lane); e >= 0; e = next_work(wl, lane)) {
-    const int chunk = cgroup * CPB + (e >> 8), strip = e & 0xff;
-    const int tile_r0 = chunk * a.rows_per_chunk;              // the tile's mask rows [tile_r0, tile_r1)
-    const int tile_r1 = tile_r0 + a.rows_per_chunk < a.H ? tile_r0 + a.rows_per_chunk : a.H;
-    const size_t cell_row = ((size_t)image * a.n_cgroups * 4 + chunk) * a.n_strips;
-    int r0 = tile_r0, r1 = tile_r1;                            // the rows this wave filters
-    int box_ylo = 0, box_yhi = a.H - 1, box_xlo = 0, box_xhi = a.W - 1; // patch path: the exact pixels' box
-    const int xbase = strip * 240 - 8;
-    const size_t cell_index = cell_row + strip;
+    for (int e = next_work(wl, lane); e >= 0; e = next_work(wl, lane)) {
+        const int chunk = cgroup * CPB + (e >> 8), strip = e & 0xff;
+        const int tile_r0 = chunk * a.rows_per_chunk;              // the tile's mask rows [tile_r0, tile_r1)
+        const int tile_r1 = tile_r0 + a.rows_per_chunk < a.H ? tile_r0 + a.rows_per_chunk : a.H;
+        const size_t cell_row = ((size_t)image * a.n_cgroups * 4 + chunk) * a.n_strips;
+        int r0 = tile_r0, r1 = tile_r1;                            // the rows this wave filters
+        int box_ylo = 0, box_yhi = a.H - 1, box_xlo = 0, box_xhi = a.W - 1; // patch path: the exact pixels' box
+        const int xbase = strip * 240 - 8;
+        const size_t cell_index = cell_row + strip;
 
-    if (a.skip_allow >= 0) {
-        // ---- dark-tile early-out (see the comment above bright_count) ----
-        // bright_cells_kernel has left, per tile, the range of mask rows that hot cells of its source region can reach
-        // (empty = none: the tile is all zeros).  Only those rows are filtered.  The context's mask keeps the
-        // invariant "a tile's mask bytes are zero unless its occupancy word has bit 31 set" from batch to batch, so
-        // rows that are not filtered only have to be cleared if the tile was filtered last time.
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_rows[4 * cell_index]);
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_rows[4 * cell_index + 1]);
-        if (PATCH) {
-            box_ylo = (int)lo; box_yhi = (int)hi;
-            box_xlo = __builtin_amdgcn_readfirstlane((int)a.tile_rows[4 * cell_index + 2]);
-            box_xhi = __builtin_amdgcn_readfirstlane((int)a.tile_rows[4 * cell_index + 3]);
-        }
-        if (lo <= hi) {
-            if (lane < 4) a.tile_rows[4 * cell_index + lane] = (lane & 1) ? 0u : 0xffffffffu; // ready for the next batch
-            if (!LDSR) { // (the LDS-staged variant's ring schedule is verified for whole tiles only)
-                r0 = (int)lo > r0 ? (int)lo : r0;
-                r1 = (int)hi + 1 < r1 ? (int)hi + 1 : r1;
+        if (a.skip_allow >= 0) {
+            // ---- dark-tile early-out (see the comment above bright_count) ----
+            // bright_cells_kernel has left, per tile, the range of mask rows that hot cells of its source region can reach
+            // (empty = none: the tile is all zeros).  Only those rows are filtered.  The context's mask keeps the
+            // invariant "a tile's mask bytes are zero unless its occupancy word has bit 31 set" from batch to batch, so
+            // rows that are not filtered only have to be cleared if the tile was filtered last time.
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_rows[4 * cell_index]);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_rows[4 * cell_index + 1]);
+            if (PATCH) {
+                box_ylo = (int)lo; box_yhi = (int)hi;
+                box_xlo = __builtin_amdgcn_readfirstlane((int)a.tile_rows[4 * cell_index + 2]);
+                box_xhi = __builtin_amdgcn_readfirstlane((int)a.tile_rows[4 * cell_index + 3]);
             }
-        }
-        const bool dark = lo > hi || r0 >= r1;
-        const uint32_t old = a.ext_mask ? 0u : a.cells[cell_index]; // (a caller-owned mask was cleared by bright_cells_kernel)
-        if (__builtin_amdgcn_readfirstlane((int)old) < 0) { // clear what will not be written below
-            uint8_t* mrow = (uint8_t*)(a.mask + (size_t)image * a.H * a.words_per_row);
-            const int rb = a.words_per_row * 4;
-            const int half = lane >> 5, pair = lane & 31, byte0 = strip * 30 + 2 * pair, nb = (a.W + 7) >> 3;
-            if (pair < 15 && byte0 < nb) {
-                for (int row = tile_r0 + half; row < tile_r1; row += 2) {
-                    if (!dark && row >= r0 && row < r1) continue;
-                    uint8_t* dst = mrow + (size_t)row * rb + byte0;
-                    if (byte0 + 1 < nb) *(uint16_t*)dst = 0; // byte0 is even: aligned
-                    else *dst = 0;
+            if (lo <= hi) {
+                if (lane < 4) a.tile_rows[4 * cell_index + lane] = (lane & 1) ? 0u : 0xffffffffu; // ready for the next batch
+                if (!LDSR) { // (the LDS-staged variant's ring schedule is verified for whole tiles only)
+                    r0 = (int)lo > r0 ? (int)lo : r0;
+                    r1 = (int)hi + 1 < r1 ? (int)hi + 1 : r1;
                 }
             }
+            const bool dark = lo > hi || r0 >= r1;
+            const uint32_t old = a.ext_mask ? 0u : a.cells[cell_index]; // (a caller-owned mask was cleared by bright_cells_kernel)
+            if (__builtin_amdgcn_readfirstlane((int)old) < 0) { // clear what will not be written below
+                uint8_t* mrow = (uint8_t*)(a.mask + (size_t)image * a.H * a.words_per_row);
+                const int rb = a.words_per_row * 4;
+                const int half = lane >> 5, pair = lane & 31, byte0 = strip * 30 + 2 * pair, nb = (a.W + 7) >> 3;
+                if (pair < 15 && byte0 < nb) {
+                    for (int row = tile_r0 + half; row < tile_r1; row += 2) {
+                        if (!dark && row >= r0 && row < r1) continue;
+                        uint8_t* dst = mrow + (size_t)row * rb + byte0;
+                        if (byte0 + 1 < nb) *(uint16_t*)dst = 0; // byte0 is even: aligned
+                        else *dst = 0;
+                    }
+                }
+            }
+            if (dark) {
+                if (lane == 0) a.cells[cell_index] = 0u;
+                continue;
+            }
         }
-        if (dark) {
-            if (lane == 0) a.cells[cell_index] = 0u;
-            continue;
+
+        const int Hm1 = a.H - 1;
+        int kfirst = r0 - 2;
+        kfirst = kfirst < 0 ? 0 : (kfirst > Hm1 ? Hm1 : kfirst);
+        const int ks = r0 - 1 > 1 ? r0 - 1 : 1;                 // steady range: every iteration slides one source row
+        const int ke = r1 + 1 < Hm1 ? r1 + 1 : Hm1;
+
+        // lut[w]: byte k = number of set bits among bits k..k+4 of the 8-bit window w.  Every wave that filters writes the
+        // whole table (identical values), so no workgroup barrier is needed and dark waves are gone before this point.
+    #pragma unroll
+        for (int e = 0; e < 4; e++) {
+            uint32_t i = (uint32_t)(lane + 64 * e), v = 0;
+    #pragma unroll
+            for (int k = 0; k < 4; k++) v |= (uint32_t)__popc((i >> k) & 0x1fu) << (8 * k);
+            lut[i] = v;
         }
-    }
-
-    const int Hm1 = a.H - 1;
-    int kfirst = r0 - 2;
-    kfirst = kfirst < 0 ? 0 : (kfirst > Hm1 ? Hm1 : kfirst);
-    const int ks = r0 - 1 > 1 ? r0 - 1 : 1;                 // steady range: every iteration slides one source row
-    const int ke = r1 + 1 < Hm1 ? r1 + 1 : Hm1;
-
-    // lut[w]: byte k = number of set bits among bits k..k+4 of the 8-bit window w.  Every wave that filters writes the
-    // whole table (identical values), so no workgroup barrier is needed and dark waves are gone before this point.
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-        uint32_t i = (uint32_t)(lane + 64 * e), v = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) v |= (uint32_t)__popc((i >> k) & 0x1fu) << (8 * k);
-        lut[i] = v;
-    }
-#pragma unroll
-    for (int s = 0; s < 8; s++) {
-        hring[wv][s][lane] = make_uint2(0u, 0u);
-        cring[wv][s][lane] = 0u;
-    }
-
-    const uint8_t* __restrict__ img = a.src + (size_t)image * a.image_stride;
-    const uint8_t* __restrict__ patch = PATCH ? a.patch + patch_offset(a, cell_index) : nullptr;
-    const int prow0 = tile_r0 - 4;
-    const PatchBox pbox = patch_box(box_ylo, box_yhi, box_xlo, box_xhi, r0 - 4 > 0 ? r0 - 4 : 0, r1 + 3 < a.H - 1 ? r1 + 3 : a.H - 1,
-                                    xbase, a.W);
-    const uint32_t* __restrict__ map = REMAP ? a.map + (size_t)slot * a.H * a.W : nullptr;
-    const uint32_t* __restrict__ mapw = REMAP ? a.mapw + (size_t)slot * a.H * a.W : nullptr;
-    uint8_t* __restrict__ mrow_base = (uint8_t*)(a.mask + (size_t)image * a.H * a.words_per_row);
-    const int row_bytes = a.words_per_row * 4;
-
-    const int xl = xbase + 4 * lane;
-
-    // per-lane column constants
-    uint32_t cx01, cx23, colmask = 0;
-    {
-        int c0 = taps5(xl, a.W), c1 = taps5(xl + 1, a.W), c2 = taps5(xl + 2, a.W), c3 = taps5(xl + 3, a.W);
-        cx01 = (uint32_t)(c0 & 0xffff) | ((uint32_t)c1 << 16);
-        cx23 = (uint32_t)(c2 & 0xffff) | ((uint32_t)c3 << 16);
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            if ((unsigned)(xl + k) < (unsigned)a.W) colmask |= 1u << k;
-    }
-    const LaneCols lc = lane_cols(xl, a.W);
-    const bool left_edge = xbase < 0;
-    const bool right_edge = xbase + 255 >= a.W;
-    const int lane_r = (a.W - 1 - xbase) >> 2, bit_r = (a.W - 1 - xbase) & 3; // lane / bit of column W-1
-    // byte of the output row written by this (even) lane
-    const int out_byte = strip * 30 + ((lane - 2) >> 1);
-    const bool stores = ((lane & 1) == 0) && lane >= 2 && lane <= 60 && out_byte < ((a.W + 7) >> 3) &&
-                        out_byte < row_bytes;
-
-    uint32_t V01 = 0, V23 = 0, Cv = 0;
-    uint32_t lacc = 0; // per lane: bit g = this lane's columns have set pixels in output rows r0+8g .. r0+8g+7
-    const bool out_lane = lane >= 2 && lane <= 61;
-    // source-row queue, 8 deep.  q[3] holds the first row so that the five set-up slides consume q[3..7] and the
-    // steady loop starts at q[0] / ring slot 0 with all indices static.
-    uint32_t q[8];
-    MapSlot mq[4];
-    TapSlot tq[4];
-    int xq[4];
-#pragma unroll
-    // columns the lane's four table words belong to (lanes outside the image read the nearest in-image group:
-    // their taps stay inside the image, their result is masked out)
-    for (int k = 0; k < 4; k++) xq[k] = lc.addr_x + k;
-    const int y0 = kfirst - 2;
-    TabSlot tabs[4];
-    RowReq rq[4];
-    LTaps tb[2];
-    LdsRemap st;
-    if (LDSR) {
-        const uint2* spans = a.spans + ((size_t)slot * a.n_strips + strip) * a.H;
-        auto span_row = [&](int r) { return r < 0 ? 0 : (r > Hm1 ? Hm1 : r); };
-        // source columns this strip needs over the rows the chunk consumes: y0 .. ke+2 (clamped into the image)
-        int xmin = 0x7fff, xmax = 0;
-        const int ra = span_row(y0), rb = span_row((ke > kfirst ? ke : kfirst) + 2);
-        for (int r = ra + lane; r <= rb; r += 64) {
-            uint32_t xs = spans[r].y;
-            int lo = (int)(xs & 0xffffu), hi = (int)(xs >> 16);
-            xmin = lo < xmin ? lo : xmin; xmax = hi > xmax ? hi : xmax;
+    #pragma unroll
+        for (int s = 0; s < 8; s++) {
+            hring[wv][s][lane] = make_uint2(0u, 0u);
+            cring[wv][s][lane] = 0u;
         }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            int o1 = __shfl_xor(xmin, d), o2 = __shfl_xor(xmax, d);
-            xmin = o1 < xmin ? o1 : xmin; xmax = o2 > xmax ? o2 : xmax;
-        }
-        st.ring = &sring[wv][0];
-        st.xs0 = __builtin_amdgcn_readfirstlane(xmin) & ~7;
-        st.nl = (__builtin_amdgcn_readfirstlane(xmax) - st.xs0 + 8) >> 3;
+
+        const uint8_t* __restrict__ img = a.src + (size_t)image * a.image_stride;
+        const uint8_t* __restrict__ patch = PATCH ? a.patch + patch_offset(a, cell_index) : nullptr;
+        const int prow0 = tile_r0 - 4;
+        const PatchBox pbox = patch_box(box_ylo, box_yhi, box_xlo, box_xhi, r0 - 4 > 0 ? r0 - 4 : 0, r1 + 3 < a.H - 1 ? r1 + 3 : a.H - 1,
+                                        xbase, a.W);
+        const uint32_t* __restrict__ map = REMAP ? a.map + (size_t)slot * a.H * a.W : nullptr;
+        const uint32_t* __restrict__ mapw = REMAP ? a.mapw + (size_t)slot * a.H * a.W : nullptr;
+        uint8_t* __restrict__ mrow_base = (uint8_t*)(a.mask + (size_t)image * a.H * a.words_per_row);
+        const int row_bytes = a.words_per_row * 4;
+
+        const int xl = xbase + 4 * lane;
+
+        // per-lane column constants
+        uint32_t cx01, cx23, colmask = 0;
         {
-            int c = st.xs0 + 8 * lane, cc = c < a.W - 8 ? c : a.W - 8;
-            st.col = (uint32_t)cc;
-            int sh = 8 * (c - cc);
-            st.colsh = (uint32_t)(sh > 63 ? 63 : sh);
+            int c0 = taps5(xl, a.W), c1 = taps5(xl + 1, a.W), c2 = taps5(xl + 2, a.W), c3 = taps5(xl + 3, a.W);
+            cx01 = (uint32_t)(c0 & 0xffff) | ((uint32_t)c1 << 16);
+            cx23 = (uint32_t)(c2 & 0xffff) | ((uint32_t)c3 << 16);
+    #pragma unroll
+            for (int k = 0; k < 4; k++)
+                if ((unsigned)(xl + k) < (unsigned)a.W) colmask |= 1u << k;
         }
-        // first tables, then the ring rows the first five rows of the pipeline need, synchronously
-        ldsr_issue_tables(tabs[3], map, mapw, y0, a.H, a.W, lc);
-        const int first = (int)(spans[span_row(y0)].x & 0xffffu);
-        const int upto = (int)(spans[span_row(y0 + RING_LOOKAHEAD - 1)].x >> 16);
-        for (int qrow = first; qrow <= upto; ++qrow) {
-            uint2 v;
-            __builtin_memcpy(&v, img + ((uint32_t)qrow * (uint32_t)a.pitch + st.col), 8);
-            uint64_t vv = (((uint64_t)v.y << 32) | v.x) >> st.colsh;
-            if (lane < st.nl) *(uint2*)(st.ring + (qrow & (RING_H - 1)) * RING_W + 8 * lane) = make_uint2((uint32_t)vv, (uint32_t)(vv >> 32));
-        }
-        st.loaded_hi = upto;
-        // the four request slots start as harmless re-fetches of the newest row
-        ldsr_request(rq[3], st, upto, img, a.pitch);
-        ldsr_request(rq[0], st, upto, img, a.pitch);
-        ldsr_request(rq[1], st, upto, img, a.pitch);
-        ldsr_request(rq[2], st, upto, img, a.pitch);
-        // taps of the first row; tables of the next four (row rho lives in slot (rho - y0 + 3) & 3)
-        ldsr_read_taps(tb[1], tabs[3], st, y0, a.H, xq);
-        ldsr_issue_tables(tabs[0], map, mapw, y0 + 1, a.H, a.W, lc);
-        ldsr_issue_tables(tabs[1], map, mapw, y0 + 2, a.H, a.W, lc);
-        ldsr_issue_tables(tabs[2], map, mapw, y0 + 3, a.H, a.W, lc);
-        ldsr_issue_tables(tabs[3], map, mapw, y0 + 4, a.H, a.W, lc);
-    } else if (PIPE) {
-        // slot of source row rho = (rho - (y0 + 5)) & 3, so that the steady loop starts at slot 0
-        remap_issue_map(mq[3], map, y0, a.H, a.W, lc);
-        remap_issue_map(mq[0], map, y0 + 1, a.H, a.W, lc);
-        remap_issue_map(mq[1], map, y0 + 2, a.H, a.W, lc);
-        remap_issue_map(mq[2], map, y0 + 3, a.H, a.W, lc);
-        remap_issue_taps(tq[3], mq[3], img, mapw, a.pitch, a.H, a.W, y0, xq, lc);
-        remap_issue_map(mq[3], map, y0 + 4, a.H, a.W, lc);
-        remap_issue_taps(tq[0], mq[0], img, mapw, a.pitch, a.H, a.W, y0 + 1, xq, lc);
-        remap_issue_map(mq[0], map, y0 + 5, a.H, a.W, lc);
-        remap_issue_taps(tq[1], mq[1], img, mapw, a.pitch, a.H, a.W, y0 + 2, xq, lc);
-        remap_issue_map(mq[1], map, y0 + 6, a.H, a.W, lc);
-        remap_issue_taps(tq[2], mq[2], img, mapw, a.pitch, a.H, a.W, y0 + 3, xq, lc);
-        remap_issue_map(mq[2], map, y0 + 7, a.H, a.W, lc);
-    } else {
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            int row = y0 + ((j + 5) & 7);
-            q[j] = PATCH ? fetch_patch4(patch, row, prow0, lane, pbox) : fetch_src4<REMAP, TINY>(a, img, map, row, xl, lc);
-        }
-    }
-    // next source row (row index `row`, queue slot J): its four pixels, and the refill of the pipeline behind it
-    auto next_row = [&](auto Jc, int row) -> uint32_t {
-        constexpr int J = decltype(Jc)::value;
+        const LaneCols lc = lane_cols(xl, a.W);
+        const bool left_edge = xbase < 0;
+        const bool right_edge = xbase + 255 >= a.W;
+        const int lane_r = (a.W - 1 - xbase) >> 2, bit_r = (a.W - 1 - xbase) & 3; // lane / bit of column W-1
+        // byte of the output row written by this (even) lane
+        const int out_byte = strip * 30 + ((lane - 2) >> 1);
+        const bool stores = ((lane & 1) == 0) && lane >= 2 && lane <= 60 && out_byte < ((a.W + 7) >> 3) &&
+                            out_byte < row_bytes;
+
+        uint32_t V01 = 0, V23 = 0, Cv = 0;
+        uint32_t lacc = 0; // per lane: bit g = this lane's columns have set pixels in output rows r0+8g .. r0+8g+7
+        const bool out_lane = lane >= 2 && lane <= 61;
+        // source-row queue, 8 deep.  q[3] holds the first row so that the five set-up slides consume q[3..7] and the
+        // steady loop starts at q[0] / ring slot 0 with all indices static.
+        uint32_t q[8];
+        MapSlot mq[4];
+        TapSlot tq[4];
+        int xq[4];
+    #pragma unroll
+        // columns the lane's four table words belong to (lanes outside the image read the nearest in-image group:
+        // their taps stay inside the image, their result is masked out)
+        for (int k = 0; k < 4; k++) xq[k] = lc.addr_x + k;
+        const int y0 = kfirst - 2;
+        TabSlot tabs[4];
+        RowReq rq[4];
+        LTaps tb[2];
+        LdsRemap st;
         if (LDSR) {
             const uint2* spans = a.spans + ((size_t)slot * a.n_strips + strip) * a.H;
-            ldsr_write(rq[J & 3], st, lane);                                         // 1
-            ldsr_read_taps(tb[(J + 1) & 1], tabs[(J + 1) & 3], st, row + 1, a.H, xq); // 2
-            ldsr_issue_tables(tabs[(J + 1) & 3], map, mapw, row + 5, a.H, a.W, lc);   // 3
-            int nr = row + RING_LOOKAHEAD;
-            nr = nr < 0 ? 0 : (nr > Hm1 ? Hm1 : nr);
-            ldsr_request(rq[J & 3], st, (int)(spans[nr].x >> 16), img, a.pitch);      // 4
-            uint32_t B = ldsr_combine(tb[J & 1], lc);                                 // 5
-            if ((unsigned)row >= (unsigned)a.H) B = 0u;
-            return B;
+            auto span_row = [&](int r) { return r < 0 ? 0 : (r > Hm1 ? Hm1 : r); };
+            // source columns this strip needs over the rows the chunk consumes: y0 .. ke+2 (clamped into the image)
+            int xmin = 0x7fff, xmax = 0;
+            const int ra = span_row(y0), rb = span_row((ke > kfirst ? ke : kfirst) + 2);
+            for (int r = ra + lane; r <= rb; r += 64) {
+                uint32_t xs = spans[r].y;
+                int lo = (int)(xs & 0xffffu), hi = (int)(xs >> 16);
+                xmin = lo < xmin ? lo : xmin; xmax = hi > xmax ? hi : xmax;
+            }
+    #pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                int o1 = __shfl_xor(xmin, d), o2 = __shfl_xor(xmax, d);
+                xmin = o1 < xmin ? o1 : xmin; xmax = o2 > xmax ? o2 : xmax;
+            }
+            st.ring = &sring[wv][0];
+            st.xs0 = __builtin_amdgcn_readfirstlane(xmin) & ~7;
+            st.nl = (__builtin_amdgcn_readfirstlane(xmax) - st.xs0 + 8) >> 3;
+            {
+                int c = st.xs0 + 8 * lane, cc = c < a.W - 8 ? c : a.W - 8;
+                st.col = (uint32_t)cc;
+                int sh = 8 * (c - cc);
+                st.colsh = (uint32_t)(sh > 63 ? 63 : sh);
+            }
+            // first tables, then the ring rows the first five rows of the pipeline need, synchronously
+            ldsr_issue_tables(tabs[3], map, mapw, y0, a.H, a.W, lc);
+            const int first = (int)(spans[span_row(y0)].x & 0xffffu);
+            const int upto = (int)(spans[span_row(y0 + RING_LOOKAHEAD - 1)].x >> 16);
+            for (int qrow = first; qrow <= upto; ++qrow) {
+                uint2 v;
+                __builtin_memcpy(&v, img + ((uint32_t)qrow * (uint32_t)a.pitch + st.col), 8);
+                uint64_t vv = (((uint64_t)v.y << 32) | v.x) >> st.colsh;
+                if (lane < st.nl) *(uint2*)(st.ring + (qrow & (RING_H - 1)) * RING_W + 8 * lane) = make_uint2((uint32_t)vv, (uint32_t)(vv >> 32));
+            }
+            st.loaded_hi = upto;
+            // the four request slots start as harmless re-fetches of the newest row
+            ldsr_request(rq[3], st, upto, img, a.pitch);
+            ldsr_request(rq[0], st, upto, img, a.pitch);
+            ldsr_request(rq[1], st, upto, img, a.pitch);
+            ldsr_request(rq[2], st, upto, img, a.pitch);
+            // taps of the first row; tables of the next four (row rho lives in slot (rho - y0 + 3) & 3)
+            ldsr_read_taps(tb[1], tabs[3], st, y0, a.H, xq);
+            ldsr_issue_tables(tabs[0], map, mapw, y0 + 1, a.H, a.W, lc);
+            ldsr_issue_tables(tabs[1], map, mapw, y0 + 2, a.H, a.W, lc);
+            ldsr_issue_tables(tabs[2], map, mapw, y0 + 3, a.H, a.W, lc);
+            ldsr_issue_tables(tabs[3], map, mapw, y0 + 4, a.H, a.W, lc);
         } else if (PIPE) {
-            constexpr int S = J & 3;
-            uint32_t B = remap_combine(tq[S], lc);
-            if ((unsigned)row >= (unsigned)a.H) B = 0u; // wave-uniform select: rows outside the image are zero
-            remap_issue_taps(tq[S], mq[S], img, mapw, a.pitch, a.H, a.W, row + 4, xq, lc);
-            remap_issue_map(mq[S], map, row + 8, a.H, a.W, lc);
-            return B;
+            // slot of source row rho = (rho - (y0 + 5)) & 3, so that the steady loop starts at slot 0
+            remap_issue_map(mq[3], map, y0, a.H, a.W, lc);
+            remap_issue_map(mq[0], map, y0 + 1, a.H, a.W, lc);
+            remap_issue_map(mq[1], map, y0 + 2, a.H, a.W, lc);
+            remap_issue_map(mq[2], map, y0 + 3, a.H, a.W, lc);
+            remap_issue_taps(tq[3], mq[3], img, mapw, a.pitch, a.H, a.W, y0, xq, lc);
+            remap_issue_map(mq[3], map, y0 + 4, a.H, a.W, lc);
+            remap_issue_taps(tq[0], mq[0], img, mapw, a.pitch, a.H, a.W, y0 + 1, xq, lc);
+            remap_issue_map(mq[0], map, y0 + 5, a.H, a.W, lc);
+            remap_issue_taps(tq[1], mq[1], img, mapw, a.pitch, a.H, a.W, y0 + 2, xq, lc);
+            remap_issue_map(mq[1], map, y0 + 6, a.H, a.W, lc);
+            remap_issue_taps(tq[2], mq[2], img, mapw, a.pitch, a.H, a.W, y0 + 3, xq, lc);
+            remap_issue_map(mq[2], map, y0 + 7, a.H, a.W, lc);
         } else {
-            uint32_t B = PATCH ? (patch_valid(row, lane, pbox) ? q[J] : 0u)
-                               : finish_src4<REMAP, TINY>(q[J], (unsigned)row < (unsigned)a.H, lc);
-            // refill 8 rows ahead, unconditionally (rows past the chunk are clamped into the image and simply
-            // unused: a branch here would make the compiler drain the whole queue at the join)
-            q[J] = PATCH ? fetch_patch4(patch, row + 8, prow0, lane, pbox) : fetch_src4<REMAP, TINY>(a, img, map, row + 8, xl, lc);
-            return B;
+    #pragma unroll
+            for (int j = 0; j < 8; j++) {
+                int row = y0 + ((j + 5) & 7);
+                q[j] = PATCH ? fetch_patch4(patch, row, prow0, lane, pbox) : fetch_src4<REMAP, TINY>(a, img, map, row, xl, lc);
+            }
         }
-    };
+        // next source row (row index `row`, queue slot J): its four pixels, and the refill of the pipeline behind it
+        auto next_row = [&](auto Jc, int row) -> uint32_t {
+            constexpr int J = decltype(Jc)::value;
+            if (LDSR) {
+                const uint2* spans = a.spans + ((size_t)slot * a.n_strips + strip) * a.H;
+                ldsr_write(rq[J & 3], st, lane);                                         // 1
+                ldsr_read_taps(tb[(J + 1) & 1], tabs[(J + 1) & 3], st, row + 1, a.H, xq); // 2
+                ldsr_issue_tables(tabs[(J + 1) & 3], map, mapw, row + 5, a.H, a.W, lc);   // 3
+                int nr = row + RING_LOOKAHEAD;
+                nr = nr < 0 ? 0 : (nr > Hm1 ? Hm1 : nr);
+                ldsr_request(rq[J & 3], st, (int)(spans[nr].x >> 16), img, a.pitch);      // 4
+                uint32_t B = ldsr_combine(tb[J & 1], lc);                                 // 5
+                if ((unsigned)row >= (unsigned)a.H) B = 0u;
+                return B;
+            } else if (PIPE) {
+                constexpr int S = J & 3;
+                uint32_t B = remap_combine(tq[S], lc);
+                if ((unsigned)row >= (unsigned)a.H) B = 0u; // wave-uniform select: rows outside the image are zero
+                remap_issue_taps(tq[S], mq[S], img, mapw, a.pitch, a.H, a.W, row + 4, xq, lc);
+                remap_issue_map(mq[S], map, row + 8, a.H, a.W, lc);
+                return B;
+            } else {
+                uint32_t B = PATCH ? (patch_valid(row, lane, pbox) ? q[J] : 0u)
+                                   : finish_src4<REMAP, TINY>(q[J], (unsigned)row < (unsigned)a.H, lc);
+                // refill 8 rows ahead, unconditionally (rows past the chunk are clamped into the image and simply
+                // unused: a branch here would make the compiler drain the whole queue at the join)
+                q[J] = PATCH ? fetch_patch4(patch, row + 8, prow0, lane, pbox) : fetch_src4<REMAP, TINY>(a, img, map, row + 8, xl, lc);
+                return B;
+            }
+        };
 
-    // horizontal 5-sums of one source row -> vertical running sums (history in the LDS ring)
-    auto hsum_update = [&](uint32_t B, int s_new, int s_old) {
-        uint32_t A = lane_from_prev(B), C = lane_from_next(B);
-        uint32_t sB = dot4(B, 0x01010101u, 0u);
-        uint32_t h0 = dot4(A, 0x01010000u, dot4(B, 0x00010101u, 0u));
-        uint32_t h1 = dot4(A, 0x01000000u, sB);
-        uint32_t h2 = dot4(C, 0x00000001u, sB);
-        uint32_t h3 = dot4(C, 0x00000101u, dot4(B, 0x01010100u, 0u));
-        uint32_t H01 = h0 | (h1 << 16), H23 = h2 | (h3 << 16);
-        uint2 old = hring[wv][s_old][lane];
-        hring[wv][s_new][lane] = make_uint2(H01, H23);
-        V01 += H01 - old.x; // 16-bit fields never borrow: the window sum always contains the row removed
-        V23 += H23 - old.y;
-    };
-    // threshold row kc from the running sums -> packed horizontal 5-window counts of the thresholded row
-    auto thresh_counts = [&](int kc) -> uint32_t {
-        uint32_t m = (uint32_t)(a.thr_mul * taps5(kc, a.H));
-        uint32_t T01 = __umul24(cx01, m), T23 = __umul24(cx23, m);
-        uint32_t d01 = (V01 | 0x80008000u) - T01, d23 = (V23 | 0x80008000u) - T23;
-        uint32_t t = (d01 >> 15) & 0x10001u, u = (d23 >> 15) & 0x10001u;
-        uint32_t w = t | (u << 2);
-        uint32_t nib = (w | (w >> 15)) & 0xfu;
-        // medianBlur replicates the border: columns outside the image take the edge column's bit
-        if (left_edge) {
-            uint32_t e = __builtin_amdgcn_readlane(nib, 2) & 1u;
-            if (xl < 0) nib = e ? 0xfu : 0u;
-        }
-        if (right_edge) {
-            uint32_t e = (__builtin_amdgcn_readlane(nib, lane_r) >> bit_r) & 1u;
-            uint32_t keep = (2u << bit_r) - 1u;
-            if (lane > lane_r) nib = e ? 0xfu : 0u;
-            else if (lane == lane_r) nib = (nib & keep) | (e ? (0xfu & ~keep) : 0u);
-        }
-        uint32_t nl = lane_from_prev(nib), nr = lane_from_next(nib);
-        uint32_t win = (nl >> 2) | (nib << 2) | ((nr & 3u) << 6);
-        return lut[win];
-    };
-    auto push_counts = [&](uint32_t c, int s_new, int s_old) {
-        uint32_t cold = cring[wv][s_old][lane];
-        cring[wv][s_new][lane] = c;
-        Cv += c - cold;
-    };
-    // majority (>= 13 of 25) of output row `row`, two lanes -> one byte of the bit mask
-    auto emit = [&](int row, bool on) {
-        uint32_t mm = ((Cv + 0x73737373u) >> 7) & 0x01010101u;
-        uint32_t t1 = mm | (mm >> 7);
-        uint32_t mn = (t1 | (t1 >> 14)) & colmask;
-        lacc |= (mn != 0u ? 1u : 0u) << (((on ? row : r0) - tile_r0) >> 3); // rows not yet valid have mn from a partial window: harmless superset
-        uint32_t odd = lane_from_next(mn);
-        uint32_t byte = (mn & 0xfu) | ((odd & 0xfu) << 4);
-        // direct byte store: all loads here are global-address-space loads, so the compiler keeps counted vmcnt
-        // waits around this exec-masked store and the load pipeline stays full
-        if (stores && on) mrow_base[(size_t)row * row_bytes + out_byte] = (uint8_t)byte;
-    };
+        // horizontal 5-sums of one source row -> vertical running sums (history in the LDS ring)
+        auto hsum_update = [&](uint32_t B, int s_new, int s_old) {
+            uint32_t A = lane_from_prev(B), C = lane_from_next(B);
+            uint32_t sB = dot4(B, 0x01010101u, 0u);
+            uint32_t h0 = dot4(A, 0x01010000u, dot4(B, 0x00010101u, 0u));
+            uint32_t h1 = dot4(A, 0x01000000u, sB);
+            uint32_t h2 = dot4(C, 0x00000001u, sB);
+            uint32_t h3 = dot4(C, 0x00000101u, dot4(B, 0x01010100u, 0u));
+            uint32_t H01 = h0 | (h1 << 16), H23 = h2 | (h3 << 16);
+            uint2 old = hring[wv][s_old][lane];
+            hring[wv][s_new][lane] = make_uint2(H01, H23);
+            V01 += H01 - old.x; // 16-bit fields never borrow: the window sum always contains the row removed
+            V23 += H23 - old.y;
+        };
+        // threshold row kc from the running sums -> packed horizontal 5-window counts of the thresholded row
+        auto thresh_counts = [&](int kc) -> uint32_t {
+            uint32_t m = (uint32_t)(a.thr_mul * taps5(kc, a.H));
+            uint32_t T01 = __umul24(cx01, m), T23 = __umul24(cx23, m);
+            uint32_t d01 = (V01 | 0x80008000u) - T01, d23 = (V23 | 0x80008000u) - T23;
+            uint32_t t = (d01 >> 15) & 0x10001u, u = (d23 >> 15) & 0x10001u;
+            uint32_t w = t | (u << 2);
+            uint32_t nib = (w | (w >> 15)) & 0xfu;
+            // medianBlur replicates the border: columns outside the image take the edge column's bit
+            if (left_edge) {
+                uint32_t e = __builtin_amdgcn_readlane(nib, 2) & 1u;
+                if (xl < 0) nib = e ? 0xfu : 0u;
+            }
+            if (right_edge) {
+                uint32_t e = (__builtin_amdgcn_readlane(nib, lane_r) >> bit_r) & 1u;
+                uint32_t keep = (2u << bit_r) - 1u;
+                if (lane > lane_r) nib = e ? 0xfu : 0u;
+                else if (lane == lane_r) nib = (nib & keep) | (e ? (0xfu & ~keep) : 0u);
+            }
+            uint32_t nl = lane_from_prev(nib), nr = lane_from_next(nib);
+            uint32_t win = (nl >> 2) | (nib << 2) | ((nr & 3u) << 6);
+            return lut[win];
+        };
+        auto push_counts = [&](uint32_t c, int s_new, int s_old) {
+            uint32_t cold = cring[wv][s_old][lane];
+            cring[wv][s_new][lane] = c;
+            Cv += c - cold;
+        };
+        // majority (>= 13 of 25) of output row `row`, two lanes -> one byte of the bit mask
+        auto emit = [&](int row, bool on) {
+            uint32_t mm = ((Cv + 0x73737373u) >> 7) & 0x01010101u;
+            uint32_t t1 = mm | (mm >> 7);
+            uint32_t mn = (t1 | (t1 >> 14)) & colmask;
+            lacc |= (mn != 0u ? 1u : 0u) << (((on ? row : r0) - tile_r0) >> 3); // rows not yet valid have mn from a partial window: harmless superset
+            uint32_t odd = lane_from_next(mn);
+            uint32_t byte = (mn & 0xfu) | ((odd & 0xfu) << 4);
+            // direct byte store: all loads here are global-address-space loads, so the compiler keeps counted vmcnt
+            // waits around this exec-masked store and the load pipeline stays full
+            if (stores && on) mrow_base[(size_t)row * row_bytes + out_byte] = (uint8_t)byte;
+        };
 
-    // ---- set-up: source rows kfirst-2 .. kfirst+2 (ring slots 3..7), first threshold row, replicated top rows ----
-    hsum_update(next_row(IC<3>{}, y0), 3, 6);
-    hsum_update(next_row(IC<4>{}, y0 + 1), 4, 7);
-    hsum_update(next_row(IC<5>{}, y0 + 2), 5, 0);
-    hsum_update(next_row(IC<6>{}, y0 + 3), 6, 1);
-    hsum_update(next_row(IC<7>{}, y0 + 4), 7, 2);
-    uint32_t c_cur = thresh_counts(kfirst);
-    // count-ring phase chosen so that the steady loop starts at slot 0: pushes so far = 1 (+2 at the image top)
-    int cj = (r0 == 0) ? 5 : 7;
-    push_counts(c_cur, cj & 7, (cj + 3) & 7);
-    cj++;
-    for (int kk = r0 - 1; kk < ks; ++kk) { // rows above the image replicate row 0 (only the top chunk gets here)
+        // ---- set-up: source rows kfirst-2 .. kfirst+2 (ring slots 3..7), first threshold row, replicated top rows ----
+        hsum_update(next_row(IC<3>{}, y0), 3, 6);
+        hsum_update(next_row(IC<4>{}, y0 + 1), 4, 7);
+        hsum_update(next_row(IC<5>{}, y0 + 2), 5, 0);
+        hsum_update(next_row(IC<6>{}, y0 + 3), 6, 1);
+        hsum_update(next_row(IC<7>{}, y0 + 4), 7, 2);
+        uint32_t c_cur = thresh_counts(kfirst);
+        // count-ring phase chosen so that the steady loop starts at slot 0: pushes so far = 1 (+2 at the image top)
+        int cj = (r0 == 0) ? 5 : 7;
         push_counts(c_cur, cj & 7, (cj + 3) & 7);
         cj++;
-        if (kk >= r0 + 2) emit(kk - 2, true);
-    }
-
-    // ---- steady state: one source row in, one threshold row, one output row per step; unrolled by 8 so that the
-    // queue registers and both ring slots are compile-time constants ----
-    auto step = [&](auto Jc, int k) {
-        constexpr int J = decltype(Jc)::value;
-        uint32_t B = next_row(Jc, k + 2);
-        hsum_update(B, J, (J + 3) & 7);
-        c_cur = thresh_counts(k);
-        push_counts(c_cur, J, (J + 3) & 7);
-        emit(k - 2, k >= r0 + 2);
-    };
-    int k = ks;
-    for (; k + 7 <= ke; k += 8) { // hot loop: no guards, every index static
-        step(IC<0>{}, k);
-        step(IC<1>{}, k + 1);
-        step(IC<2>{}, k + 2);
-        step(IC<3>{}, k + 3);
-        step(IC<4>{}, k + 4);
-        step(IC<5>{}, k + 5);
-        step(IC<6>{}, k + 6);
-        step(IC<7>{}, k + 7);
-    }
-    if (k <= ke) step(IC<0>{}, k);
-    if (k + 1 <= ke) step(IC<1>{}, k + 1);
-    if (k + 2 <= ke) step(IC<2>{}, k + 2);
-    if (k + 3 <= ke) step(IC<3>{}, k + 3);
-    if (k + 4 <= ke) step(IC<4>{}, k + 4);
-    if (k + 5 <= ke) step(IC<5>{}, k + 5);
-    if (k + 6 <= ke) step(IC<6>{}, k + 6);
-    // ---- rows below the image replicate the last row (only the bottom chunk gets here) ----
-    {
-        int n_steady = ke >= ks ? ke - ks + 1 : 0;
-        cj = n_steady; // slot of the next push (the steady loop started at slot 0)
-        int kb = ke + 1 > ks ? ke + 1 : ks;
-        for (int kk = kb; kk <= r1 + 1; ++kk) {
+        for (int kk = r0 - 1; kk < ks; ++kk) { // rows above the image replicate row 0 (only the top chunk gets here)
             push_counts(c_cur, cj & 7, (cj + 3) & 7);
             cj++;
             if (kk >= r0 + 2) emit(kk - 2, true);
         }
-    }
-    {   // occupancy word of this (strip, chunk): OR of the output lanes' bits
-        uint32_t cellmask = 0;
-        const int groups = (tile_r1 - tile_r0 + 7) >> 3;
-        for (int g = 0; g < groups; g++)
-            if (__ballot(out_lane && ((lacc >> g) & 1u)) != 0ull) cellmask |= 1u << g;
-        // bit 31 marks a tile that went through the full filter (the early-out writes 0); bits 0..16 are the groups
-        if (lane == 0) a.cells[cell_index] = cellmask | 0x80000000u;
-    }
-        } // strips
+
+        // ---- steady state: one source row in, one threshold row, one output row per step; unrolled by 8 so that the
+        // queue registers and both ring slots are compile-time constants ----
+        auto step = [&](auto Jc, int k) {
+            constexpr int J = decltype(Jc)::value;
+            uint32_t B = next_row(Jc, k + 2);
+            hsum_update(B, J, (J + 3) & 7);
+            c_cur = thresh_counts(k);
+            push_counts(c_cur, J, (J + 3) & 7);
+            emit(k - 2, k >= r0 + 2);
+        };
+        int k = ks;
+        for (; k + 7 <= ke; k += 8) { // hot loop: no guards, every index static
+            step(IC<0>{}, k);
+            step(IC<1>{}, k + 1);
+            step(IC<2>{}, k + 2);
+            step(IC<3>{}, k + 3);
+            step(IC<4>{}, k + 4);
+            step(IC<5>{}, k + 5);
+            step(IC<6>{}, k + 6);
+            step(IC<7>{}, k + 7);
+        }
+        if (k <= ke) step(IC<0>{}, k);
+        if (k + 1 <= ke) step(IC<1>{}, k + 1);
+        if (k + 2 <= ke) step(IC<2>{}, k + 2);
+        if (k + 3 <= ke) step(IC<3>{}, k + 3);
+        if (k + 4 <= ke) step(IC<4>{}, k + 4);
+        if (k + 5 <= ke) step(IC<5>{}, k + 5);
+        if (k + 6 <= ke) step(IC<6>{}, k + 6);
+        // ---- rows below the image replicate the last row (only the bottom chunk gets here) ----
+        {
+            int n_steady = ke >= ks ? ke - ks + 1 : 0;
+            cj = n_steady; // slot of the next push (the steady loop started at slot 0)
+            int kb = ke + 1 > ks ? ke + 1 : ks;
+            for (int kk = kb; kk <= r1 + 1; ++kk) {
+                push_counts(c_cur, cj & 7, (cj + 3) & 7);
+                cj++;
+                if (kk >= r0 + 2) emit(kk - 2, true);
+            }
+        }
+        {   // occupancy word of this (strip, chunk): OR of the output lanes' bits
+            uint32_t cellmask = 0;
+            const int groups = (tile_r1 - tile_r0 + 7) >> 3;
+            for (int g = 0; g < groups; g++)
+                if (__ballot(out_lane && ((lacc >> g) & 1u)) != 0ull) cellmask |= 1u << g;
+            // bit 31 marks a tile that went through the full filter (the early-out writes 0); bits 0..16 are the groups
+            if (lane == 0) a.cells[cell_index] = cellmask | 0x80000000u;
+        }
+    } // marked tiles
 }
 
 // ---- map construction: cv::initUndistortRectifyMap as called by cv::undistort (stripe by stripe) -------------
