@@ -10,7 +10,7 @@ With one rank the block is the whole grid and no collective runs.
 import numpy as np
 import torch
 
-from .engine import MAX_BLOBS, REC_INTS, MocapContext
+from .engine import MocapContext
 
 
 def shard_plan(n_cams, steps_per_rank, world, rank):
@@ -78,6 +78,9 @@ class BatchTracker:
         self.slot_of = {c: i for i, c in enumerate(local_cams)}
         n_slots = self.n_cam if world == 1 else len(local_cams)
         self.per = self.n_cam * self.T
+        # centroid record of one image: count, pad, (x, y) x max_points -- correspondence reads at most max_points points
+        # per camera, so longer records would only inflate the all-gather
+        self.rec_ints = 2 + 2 * max_points
         self.lanes = []
         for d in range(max(1, int(depth))):
             ctx = MocapContext(width, height, n_slots, device)
@@ -89,7 +92,7 @@ class BatchTracker:
                     ctx.set_undistort(self.slot_of[c], K[c], dist[c])
             ctx.set_cameras(K, dist, R, t)
             ctx.set_fundamentals(F)
-            records = torch.zeros((self.per, REC_INTS), dtype=torch.int32, device=ctx.device)
+            records = torch.zeros((self.per, self.rec_ints), dtype=torch.int32, device=ctx.device)
             stream = torch.cuda.Stream(device=ctx.device) if depth > 1 else None
             self.lanes.append(_Lane(ctx, records, stream))
         self._k = 0
@@ -123,12 +126,13 @@ class BatchTracker:
         Fills and returns self.records ([per, REC] int32, one centroid record per image)."""
         ctx = self.ctx
         if self.world == 1:
-            ctx.blob_centroids(frames, cam_mod=self.n_cam, records=self.records)
+            ctx.blob_centroids(frames, cam_mod=self.n_cam, max_blobs=self.max_points, records=self.records)
             return self.records
         o = 0
         for c, t0, t1 in self.segs:
             n = t1 - t0
-            ctx.blob_centroids(frames[o:o + n], cam_mod=1, slot_base=self.slot_of[c], records=self.records[o:o + n])
+            ctx.blob_centroids(frames[o:o + n], cam_mod=1, slot_base=self.slot_of[c], max_blobs=self.max_points,
+                               records=self.records[o:o + n])
             o += n
         return self.records
 

@@ -1,7 +1,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from mocapv2_amd.engine import MocapContext, REC_INTS
+from mocapv2_amd.engine import MocapContext, REC_INTS  # noqa
 from mocapv2_amd.pipeline import scene_arrays
 from mocapv2_amd.synth import MILD_DIST, Scene
 W, H, C, T = 1920, 1080, 6, 64
