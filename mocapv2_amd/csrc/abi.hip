@@ -463,9 +463,12 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
     }
     EvPair p; bool on;
     if (a.skip_allow >= 0) { // one streaming pass over the frames marks the tiles that can hold set pixels
-        BrightArgs b{a.src, a.image_stride, a.pitch, a.H, a.W, n_images, cam_mod, a.skip_allow / 4, allow_cut1 / 4, allow_cut2 / 4,
+        // floor(i / ncx) = umulhi(i, ceil(2^32 / ncx)) is exact while i * ncx < 2^32
+        const uint64_t ncx64 = (uint64_t)((c->W + 7) / 8), ncells = ncx64 * (uint64_t)((c->H + 7) / 8);
+        const uint32_t ncx_magic = (ncx64 > 1 && ncells * ncx64 < (1ull << 32)) ? (uint32_t)(((1ull << 32) + ncx64 - 1) / ncx64) : 0u;
+        BrightArgs b{a.src, a.image_stride, a.pitch, a.H, a.W, n_images, cam_mod, ncx_magic, a.skip_allow / 4, allow_cut1 / 4, allow_cut2 / 4,
                      c->reach + (size_t)slot_base * source_cells(c), c->cflags + (size_t)slot_base * source_cells(c),
-                     c->tile_rows, tl.n_cgroups * 4, tl.n_strips, tl.rows,
+                     c->tile_rows, tl.n_cgroups * 4, tl.n_strips, (uint32_t)(((1u << 23) + tl.rows - 1) / tl.rows),
                      mask, own_mask ? 0 : (size_t)n_images * c->H * c->wpr, ((uintptr_t)mask & 15) == 0};
         prof_begin(c, 3, s, p, on);
         launch_bright_cells(b, s);

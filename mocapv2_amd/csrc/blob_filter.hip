@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void bright_cells_kernel(BrightArgs a)
         int i = i0 + 256 * u;
         i = i < n ? i : n - 1; // threads past the end recount the last cell (and mark the same tiles again)
         ci[u] = i;
-        cr[u] = i / ncx;
+        cr[u] = a.ncx_magic ? (int)__umulhi((uint32_t)i, a.ncx_magic) : i / ncx; // floor(i / ncx) without the division
         const int cx = i - cr[u] * ncx;
         const int c = 8 * cx, cc = c < a.W - 8 ? c : a.W - 8; // W >= 8 (checked on the host)
         sh[u] = (uint32_t)(8 * (c - cc));
@@ -330,8 +330,11 @@ __global__ __launch_bounds__(256) void bright_cells_kernel(BrightArgs a)
                 // more; the median adds 2 again: exact pixels are needed, and mask bits can be set, within 4 of the reach
                 const int xa = x0 - 4 > 0 ? x0 - 4 : 0, xb = x1 + 4 < a.W - 1 ? x1 + 4 : a.W - 1;
                 const int ya = y0 - 4 > 0 ? y0 - 4 : 0, yb = y1 + 4 < a.H - 1 ? y1 + 4 : a.H - 1;
-                for (int ch = ya / a.rows_per_chunk; ch <= yb / a.rows_per_chunk; ch++)
-                    for (int st = xa / 240; st <= xb / 240; st++) {
+                // floor(v / d) = (v * ceil(2^23 / d)) >> 23 for v < 32768 and d >= 8: no integer division in this kernel
+                const int ch0 = (int)(((uint32_t)ya * a.rows_magic) >> 23), ch1 = (int)(((uint32_t)yb * a.rows_magic) >> 23);
+                const int st0 = (int)(((uint32_t)xa * 34953u) >> 23), st1 = (int)(((uint32_t)xb * 34953u) >> 23);
+                for (int ch = ch0; ch <= ch1; ch++)
+                    for (int st = st0; st <= st1; st++) {
                         const int t = ch * a.n_strips + st;
                         atomicMin(&rows[4 * t], (uint32_t)ya);
                         atomicMax(&rows[4 * t + 1], (uint32_t)yb);

@@ -81,12 +81,14 @@ void launch_filter_mask(const FilterArgs& a, bool remap, hipStream_t s);
 void launch_undistort_patches(const FilterArgs& a, hipStream_t s); // needs a.patch; before launch_filter_mask
 struct BrightArgs {
     const uint8_t* src; size_t image_stride; int pitch, H, W, n_images; // W >= 8
-    int cam_mod;                  // undistort slot of image n = n % cam_mod (hull already points at the first slot)
+    int cam_mod;                  // undistort slot of image n = n % cam_mod (the tables already point at the first slot)
+    uint32_t ncx_magic;           // ceil(2^32 / ceil(W/8)) if that divides every cell index exactly by multiply-high, else 0
     int hot, hot_edge, hot_corner; // a cell with more than this many pixels >= 64 is hot (4 * hot <= skip_allow); _edge /
                                   //   _corner for cells feeding windows the image border cuts in one axis / in both
     const uint2* reach;           // [cam_mod][cells]: box of the output pixels that read the 8x8 source cell, x0 | x1 << 16, y0 | y1 << 16
     const uint8_t* cflags;        // [cam_mod][cells]: 1 / 2 = the cell feeds windows the image border cuts in one axis / in both
-    uint32_t* tile_rows; int n_chunks, n_strips, rows_per_chunk; // reachable mask rows / columns per tile, see FilterArgs
+    uint32_t* tile_rows; int n_chunks, n_strips; uint32_t rows_magic; // reachable mask rows / columns per tile, see FilterArgs;
+                                  //   rows_magic = ceil(2^23 / rows per chunk)
     uint32_t* mask; size_t mask_words; int mask_aligned16; // caller-owned bit masks to clear on the side (mask_words = 0: none)
 };
 void launch_bright_cells(const BrightArgs& a, hipStream_t s);
