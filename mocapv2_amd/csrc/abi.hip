@@ -464,9 +464,14 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
     EvPair p; bool on;
     if (a.skip_allow >= 0) { // one streaming pass over the frames marks the tiles that can hold set pixels
         // floor(i / ncx) = umulhi(i, ceil(2^32 / ncx)) is exact while i * ncx < 2^32
-        const uint64_t ncx64 = (uint64_t)((c->W + 7) / 8), ncells = ncx64 * (uint64_t)((c->H + 7) / 8);
+        uint64_t ncx64 = (uint64_t)((c->W + 7) / 8);
+        const uint64_t ncells = ncx64 * (uint64_t)((c->H + 7) / 8);
+        int wide = (c->W % 16 == 0) && (a.pitch % 16 == 0) && (a.image_stride % 16 == 0) && (((uintptr_t)a.src & 15) == 0) && ncx64 >= 4;
+        if (wide && ncells * (ncx64 / 2) >= (1ull << 32)) wide = 0;
+        { const char* e = getenv("MOCAP_SCAN_WIDE"); if (e && atoi(e) == 0) wide = 0; } // A/B switch
+        if (wide) ncx64 /= 2; // the wide kernel divides pair indices by the pairs per cell row
         const uint32_t ncx_magic = (ncx64 > 1 && ncells * ncx64 < (1ull << 32)) ? (uint32_t)(((1ull << 32) + ncx64 - 1) / ncx64) : 0u;
-        BrightArgs b{a.src, a.image_stride, a.pitch, a.H, a.W, n_images, cam_mod, ncx_magic, a.skip_allow / 4, allow_cut1 / 4, allow_cut2 / 4,
+        BrightArgs b{a.src, a.image_stride, a.pitch, a.H, a.W, n_images, cam_mod, ncx_magic, wide, a.skip_allow / 4, allow_cut1 / 4, allow_cut2 / 4,
                      c->reach + (size_t)slot_base * source_cells(c), c->cflags + (size_t)slot_base * source_cells(c),
                      c->tile_rows, tl.n_cgroups * 4, tl.n_strips, (uint32_t)(((1u << 23) + tl.rows - 1) / tl.rows),
                      mask, own_mask ? 0 : (size_t)n_images * c->H * c->wpr, ((uintptr_t)mask & 15) == 0};

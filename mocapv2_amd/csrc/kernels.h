@@ -82,7 +82,8 @@ void launch_undistort_patches(const FilterArgs& a, hipStream_t s); // needs a.pa
 struct BrightArgs {
     const uint8_t* src; size_t image_stride; int pitch, H, W, n_images; // W >= 8
     int cam_mod;                  // undistort slot of image n = n % cam_mod (the tables already point at the first slot)
-    uint32_t ncx_magic;           // ceil(2^32 / ceil(W/8)) if that divides every cell index exactly by multiply-high, else 0
+    uint32_t ncx_magic;           // ceil(2^32 / d), d = ceil(W/8) (wide: d / 2), if that divides every index exactly by multiply-high, else 0
+    int wide;                     // 1 = 16-byte loads (W, pitch, image stride, base all multiples of 16; ncx_magic != 0)
     int hot, hot_edge, hot_corner; // a cell with more than this many pixels >= 64 is hot (4 * hot <= skip_allow); _edge /
                                   //   _corner for cells feeding windows the image border cuts in one axis / in both
     const uint2* reach;           // [cam_mod][cells]: box of the output pixels that read the 8x8 source cell, x0 | x1 << 16, y0 | y1 << 16
