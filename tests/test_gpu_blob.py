@@ -314,3 +314,46 @@ def test_centroids_odd_sizes_two_batches(torch_cuda, W, H, scale):
             assert cnt[i] == len(exp) and xy[i, :cnt[i]].tolist() == exp, (b, i, cnt[i], exp)
             seen += len(exp)
     assert seen > 0
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_early_out_fuzz_thresholds_and_brightness(torch_cuda, seed):
+    """Random thresholds, background levels, bright clutter and lens models: the mask (caller-owned, scan-cleared) and
+    the centroids (context-owned mask, cleared on demand) equal the oracle's, batch after batch on one context."""
+    from gpu_util import unpack_mask
+    torch = torch_cuda
+    from mocapv2_amd.engine import MocapContext
+    rng = np.random.default_rng(9000 + seed)
+    W, H = int(rng.choice([256, 488, 640, 964])), int(rng.choice([96, 200, 273, 360]))
+    scale = float(rng.choice([0.0, 0.5, 1.0, 3.0, -2.0]))
+    dist = np.array(MILD_DIST) * scale
+    sc = Scene(1, width=W, height=H, dist=dist)
+    ctx = MocapContext(W, H, n_slots=1)
+    ident = ctx.set_undistort(0, sc.K, sc.dist)
+    for b in range(3):
+        thresh = float(rng.choice([255 * 0.85, 130.0, 180.0, 240.0, 90.0]))
+        noise_max = int(rng.choice([20, 60, 63, 64, 100]))
+        frames = dark_frames(rng, 2, H, W, n_discs=int(rng.integers(0, 5)), salt=float(rng.choice([0.0, 0.001, 0.01])),
+                             noise_max=noise_max)
+        # clutter: small saturated squares of 2..6 px, some at the image border
+        for i in range(2):
+            for _ in range(int(rng.integers(0, 12))):
+                k = int(rng.integers(2, 7))
+                y0 = int(rng.integers(0, H - k)) if rng.random() < 0.7 else int(rng.choice([0, H - k]))
+                x0 = int(rng.integers(0, W - k)) if rng.random() < 0.7 else int(rng.choice([0, W - k]))
+                frames[i, y0:y0 + k, x0:x0 + k] = 255
+        ctx.set_blob_params(thresh=thresh, min_area=40.0)
+        prm = oracle.default_params(undistort=True)
+        prm.thresh = thresh
+        prm.min_area = 40.0
+        d = torch.from_numpy(frames).cuda()
+        got, pad = unpack_mask(ctx.filter_mask(d), W)
+        assert not pad.any()
+        xy, cnt = ctx.record_views(ctx.blob_centroids(d))
+        xy, cnt = xy.cpu().numpy(), cnt.cpu().numpy()
+        for i in range(2):
+            und = frames[i] if ident else oracle.undistort(frames[i], sc.K, dist)
+            exp = oracle.image_filter(und, 0, thresh=thresh) != 0
+            assert np.array_equal(got[i], exp), (seed, b, i, thresh, noise_max, np.argwhere(got[i] != exp)[:4])
+            pts = oracle.find_dot(frames[i], sc.K, dist, params=prm)
+            assert cnt[i] == len(pts) and xy[i, :cnt[i]].tolist() == pts, (seed, b, i)
