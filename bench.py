@@ -5,12 +5,13 @@
 
 Workload (BASELINE.json configs[1]): 6 cameras x 1920x1080 synthetic IR frames, 8 markers.  One "step" = one pass
 of the whole hot path (undistort -> box blur -> threshold -> median -> contours -> centroids -> epipolar
-correspondence -> DLT triangulation) over one batch of T = 64 time steps (384 camera images, 796 MB) that is
+correspondence -> DLT triangulation) over one batch of T = 512 time steps (3072 camera images, 6.4 GB) that is
 resident in HBM before the timed region starts.  A "frame" = one time step of all 6 cameras.  With N ranks every
-rank processes its own 384 images (weak scaling; camera-major sharding + one all-gather, mocapv2_amd/pipeline.py).
+rank processes its own 3072 images (weak scaling; camera-major sharding + one all-gather, mocapv2_amd/pipeline.py).
 
-Prints ONE JSON line (rank 0) with the driver's fields plus `roofline` (the fused filter kernel against the HBM
-read roofline, from HIP events recorded on the launch stream) and `cpu_baseline` (the C oracle on host cores).
+Three batches are in flight on three HIP streams (--depth).  Prints ONE JSON line (rank 0) with the driver's fields
+plus `roofline` (the filter stage = streaming scan + patches + filter kernels against the HBM read roofline, from HIP
+events recorded on the launch streams) and `cpu_baseline` (the C oracle on host cores).
 """
 import argparse
 import json
@@ -23,7 +24,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-N_CAM, WIDTH, HEIGHT, N_MARKERS, T_STEPS = 6, 1920, 1080, 8, 256
+N_CAM, WIDTH, HEIGHT, N_MARKERS, T_STEPS = 6, 1920, 1080, 8, 512
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 
 
