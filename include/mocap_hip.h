@@ -62,7 +62,10 @@ MOCAP_API int mocap_abi_version(void);
 MOCAP_API const char* mocap_last_error(void);
 
 /* Context for one GPU and one image geometry.  n_slots = number of undistortion maps kept resident
- * (one per camera; the reference itself always uses camera 0's, lib/ImageOperations.py:37). */
+ * (one per camera; the reference itself always uses camera 0's, lib/ImageOperations.py:37).
+ * A context owns the per-batch scratch of the blob stage (bit mask, occupancy words, patches, contour workspace):
+ * its mocap_blob_centroids / mocap_filter_mask / mocap_image_filter_u8 calls must be ordered on one stream.  For
+ * several batches in flight use one context per stream. */
 MOCAP_API int mocap_ctx_create(int device_id, int width, int height, int n_slots, mocap_ctx_t* out);
 MOCAP_API int mocap_ctx_destroy(mocap_ctx_t ctx);
 MOCAP_API int mocap_sync(mocap_ctx_t ctx, void* stream); /* hipStreamSynchronize */
