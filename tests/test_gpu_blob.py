@@ -357,3 +357,35 @@ def test_early_out_fuzz_thresholds_and_brightness(torch_cuda, seed):
             assert np.array_equal(got[i], exp), (seed, b, i, thresh, noise_max, np.argwhere(got[i] != exp)[:4])
             pts = oracle.find_dot(frames[i], sc.K, dist, params=prm)
             assert cnt[i] == len(pts) and xy[i, :cnt[i]].tolist() == pts, (seed, b, i)
+
+
+@pytest.mark.parametrize("W,H", [(16000, 48), (40, 5000), (4096, 72)])
+def test_extreme_aspect_ratios(torch_cuda, W, H):
+    """More than 64 strips per chunk (lane-parallel tile test in two rounds), many chunk groups, patches per tile."""
+    torch = torch_cuda
+    from mocapv2_amd.engine import MocapContext
+    sc = Scene(1, width=W, height=H, dist=np.array(MILD_DIST) * 0.2)
+    ctx = MocapContext(W, H, n_slots=1)
+    ctx.set_undistort(0, sc.K, sc.dist)
+    ctx.set_blob_params(min_area=60.0)
+    prm = oracle.default_params(undistort=True)
+    prm.min_area = 60.0
+    rng = np.random.default_rng(W + H)
+    seen = 0
+    for b in range(2):
+        frames = rng.integers(0, 60, (2, H, W), dtype=np.uint8)
+        yy, xx = np.mgrid[0:H, 0:W]
+        for i in range(2):
+            for _ in range(6):
+                cx, cy, r = rng.uniform(0, W), rng.uniform(0, H), rng.uniform(6, 14)
+                x0, x1 = max(0, int(cx - r - 2)), min(W, int(cx + r + 3))
+                y0, y1 = max(0, int(cy - r - 2)), min(H, int(cy + r + 3))
+                d = np.sqrt((xx[y0:y1, x0:x1] - cx) ** 2 + (yy[y0:y1, x0:x1] - cy) ** 2)
+                frames[i, y0:y1, x0:x1] = np.maximum(frames[i, y0:y1, x0:x1], (np.clip((r + 0.75 - d) / 1.5, 0, 1) * 255).astype(np.uint8))
+        xy, cnt = ctx.record_views(ctx.blob_centroids(torch.from_numpy(frames).cuda()))
+        xy, cnt = xy.cpu().numpy(), cnt.cpu().numpy()
+        for i in range(2):
+            exp = oracle.find_dot(frames[i], sc.K, sc.dist, params=prm)
+            assert cnt[i] == len(exp) and xy[i, :cnt[i]].tolist() == exp, (b, i, cnt[i], len(exp))
+            seen += len(exp)
+    assert seen > 0
