@@ -77,8 +77,8 @@ def main():
     global T_STEPS
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dist", choices=["mild", "zero"], default="mild")
     ap.add_argument("--time-steps", type=int, default=T_STEPS,
                     help="time steps per batch and GPU (one step = one pass over time_steps x 6 resident images)")
