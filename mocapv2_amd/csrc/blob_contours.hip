@@ -202,10 +202,11 @@ __device__ __forceinline__ void follow(const Mask& M, int sx, int sy, int first,
         by0 = ny < by0 ? ny : by0; by1 = ny > by1 ? ny : by1;
         // move, keeping the three cached rows around the current pixel
         const int lx = nx - x0;
-        if (lx < 1 || lx > 62) { // left the window: re-centre it on the new pixel (rare)
-            x0 = nx - 31;
-            staged = false;
-            rU = row64(M, ny - 1, x0); rM = row64(M, ny, x0); rD = row64(M, ny + 1, x0);
+        if (lx < 1 || lx > 62) { // left the window: re-centre it on the new pixel (rare), or return to the staged one
+            const int wl = nx - (sx - 31); // column of the new pixel in the staged window
+            staged = win != nullptr && wl >= 1 && wl <= 62;
+            x0 = staged ? sx - 31 : nx - 31;
+            rU = fetch(ny - 1); rM = fetch(ny); rD = fetch(ny + 1);
         } else {
             const uint64_t nw = fetch(ny + dy); // (dy = 0: the middle row again, unused)
             const uint64_t oU = rU, oM = rM, oD = rD;
