@@ -84,6 +84,8 @@ def main():
                     help="time steps per batch and GPU (one step = one pass over time_steps x 6 resident images)")
     ap.add_argument("--depth", type=int, default=3,
                     help="batches in flight (software pipelining of consecutive batches on separate HIP streams; 1 = off)")
+    ap.add_argument("--from-host", action="store_true",
+                    help="the batch stays in pinned host memory and is uploaded every step (PCIe-inclusive rate; not the headline)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 ranks share cuda:0 and exchange through gloo (checks the multi-rank code path on a one-GPU box; "
                          "not a measurement)")
@@ -159,7 +161,7 @@ def main():
         tracker = BatchTracker(*arrays, WIDTH, HEIGHT, T_STEPS, world=world, rank=rank, device=local_rank, depth=args.depth)
         images = tracker.local_image_list()
         frames_host = render_local(scene, images)
-        frames = torch.from_numpy(frames_host).cuda()
+        frames = torch.from_numpy(frames_host).pin_memory() if args.from_host else torch.from_numpy(frames_host).cuda()
         torch.cuda.synchronize()
         out, elapsed, prof = timed(tracker, frames)
         return scene, arrays, tracker, images, frames_host, out, elapsed, prof, frames
@@ -233,7 +235,7 @@ def main():
             "config": {"workload": "6-camera 1920x1080 synthetic IR frames, 8 markers (BASELINE.json configs[1])",
                        "cameras": N_CAM, "width": WIDTH, "height": HEIGHT, "markers": N_MARKERS,
                        "time_steps_per_step_per_gpu": T_STEPS, "distortion": args.dist,
-                       "frames_resident_in_hbm": True, "batches_in_flight": args.depth,
+                       "frames_resident_in_hbm": not args.from_host, "batches_in_flight": args.depth,
                        "parallelism": "single launch, time-major" if world == 1 else f"camera-major blocks x{world} + 1 all-gather"},
             "roofline": roof,
             "kernel_ms_per_step": kernel_ms(prof),

@@ -57,6 +57,7 @@ class _Lane:
 
     def __init__(self, ctx, records, stream):
         self.ctx, self.records, self.stream, self.out = ctx, records, stream, None
+        self.staging = None  # device copy of a batch that arrived in host memory
 
 
 class BatchTracker:
@@ -157,10 +158,20 @@ class BatchTracker:
         self._k += 1
         self._cur = lane
         if lane.stream is None:
-            return self._run(frames)
+            return self._run(self._resident(lane, frames))
         lane.stream.wait_stream(torch.cuda.current_stream())  # the frames were produced on the caller's stream
         with torch.cuda.stream(lane.stream):
-            return self._run(frames)
+            return self._run(self._resident(lane, frames))
+
+    def _resident(self, lane, frames):
+        """Frames in (pinned) host memory are uploaded into the batch's own staging buffer on its stream, so the copy
+        of one batch overlaps the kernels of the others; frames already on the GPU are used in place."""
+        if frames.is_cuda:
+            return frames
+        if lane.staging is None or lane.staging.shape != frames.shape:
+            lane.staging = torch.empty(frames.shape, dtype=torch.uint8, device=lane.ctx.device)
+        lane.staging.copy_(frames, non_blocking=True)
+        return lane.staging
 
     def _run(self, frames):
         records = self.extract(frames)

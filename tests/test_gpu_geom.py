@@ -253,3 +253,31 @@ def test_replay_tracker_matches_per_frame_drop_in(helpers):
         assert got[s]["image_points"].shape == img.shape and np.array_equal(got[s]["image_points"], img), s
         assert got[s]["message"] == tracker_message(point), s
     assert seen >= 3 and len(got[2]["object_points"]) == 0 and got[2]["message"] == got[1]["message"]
+
+
+def test_host_fed_batches_equal_resident_ones():
+    """BatchTracker.step accepts a batch in pinned host memory (uploaded on the batch's own stream, three batches in
+    flight) and gives the results of the same batch resident on the GPU."""
+    import torch
+    from mocapv2_amd.pipeline import BatchTracker, scene_arrays
+    C, T, W, H = 2, 3, 640, 360
+    sc = Scene(C, W, H, dist=MILD_DIST)
+    arrays = scene_arrays(sc)
+    batches = [sc.render_batch(seed=30 + b, n_steps=T, n_markers=4, radius_range=(16, 20)).reshape(T * C, H, W) for b in range(4)]
+    ref = BatchTracker(*arrays, W, H, T)
+    expected = []
+    for fr in batches:
+        out = ref.step(torch.from_numpy(fr).cuda())
+        torch.cuda.synchronize()
+        expected.append({k: v.cpu().numpy().copy() for k, v in out.items()})
+    trk = BatchTracker(*arrays, W, H, T, depth=3)
+    outs = []
+    for fr in batches:
+        out = trk.step(torch.from_numpy(fr).pin_memory())
+        trk.synchronize()  # the lane's buffers are reused three batches later: copy the results out now
+        outs.append({k: v.cpu().numpy().copy() for k, v in out.items()})
+    for e, o in zip(expected, outs):
+        assert np.array_equal(e["n"], o["n"]) and (e["n"] > 0).any()
+        for s in range(T):
+            k = e["n"][s]
+            assert np.array_equal(e["xyz"][s, :k], o["xyz"][s, :k]) and np.array_equal(e["grp"][s, :k], o["grp"][s, :k])
