@@ -283,7 +283,8 @@ __device__ __forceinline__ uint32_t bright_count(uint32_t v)
 // and columns (atomic min / max).  Tiles left unmarked, and rows outside the range, provably filter to zeros.
 // WIDE (W, pitch, image stride and base multiples of 16): the two cells of a thread are neighbours in one cell row and
 // come in with one 16-byte load per image row (8 loads of 16 B instead of 16 of 8 B per thread).
-template <bool WIDE>
+// FULL (H a multiple of 8, wide only): every cell has its 8 rows, no row clamping and no per-row validity test.
+template <bool WIDE, bool FULL = false>
 __global__ __launch_bounds__(256) void bright_cells_kernel(BrightArgs a)
 {
     const int ncx = (a.W + 7) >> 3, ncy = (a.H + 7) >> 3, n = ncx * ncy;
@@ -300,12 +301,21 @@ __global__ __launch_bounds__(256) void bright_cells_kernel(BrightArgs a)
         cr[0] = cr[1] = row;
         ci[0] = row * ncx + 2 * cxp; ci[1] = ci[0] + 1;
         sh[0] = sh[1] = 0;
+        if (FULL) {
+            const uint32_t off0 = (uint32_t)(8 * row) * (uint32_t)a.pitch + 16u * (uint32_t)cxp;
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            int r = 8 * row + j;
-            r = r < a.H ? r : a.H - 1;
-            const uint4 q = *(const uint4*)(img + ((uint32_t)r * (uint32_t)a.pitch + 16u * (uint32_t)cxp));
-            v[0][j] = make_uint2(q.x, q.y); v[1][j] = make_uint2(q.z, q.w);
+            for (int j = 0; j < 8; j++) {
+                const uint4 q = *(const uint4*)(img + (off0 + (uint32_t)(j * a.pitch))); // uniform base + 32-bit offset
+                v[0][j] = make_uint2(q.x, q.y); v[1][j] = make_uint2(q.z, q.w);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                int r = 8 * row + j;
+                r = r < a.H ? r : a.H - 1;
+                const uint4 q = *(const uint4*)(img + ((uint32_t)r * (uint32_t)a.pitch + 16u * (uint32_t)cxp));
+                v[0][j] = make_uint2(q.x, q.y); v[1][j] = make_uint2(q.z, q.w);
+            }
         }
     } else {
         const int i0 = blockIdx.x * 512 + threadIdx.x;
@@ -335,9 +345,14 @@ __global__ __launch_bounds__(256) void bright_cells_kernel(BrightArgs a)
         uint32_t acc = 0;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            uint64_t vv = (((uint64_t)v[u][j].y << 32) | v[u][j].x) >> sh[u]; // drops the bytes left of the cell at the right edge
-            uint32_t cnt = bright_count((uint32_t)vv) + bright_count((uint32_t)(vv >> 32));
-            if (8 * cr[u] + j < a.H) acc += cnt;
+            if (WIDE) { // cells are whole
+                const uint32_t cnt = bright_count(v[u][j].x) + bright_count(v[u][j].y);
+                if (FULL || 8 * cr[u] + j < a.H) acc += cnt;
+            } else {
+                uint64_t vv = (((uint64_t)v[u][j].y << 32) | v[u][j].x) >> sh[u]; // drops the bytes left of the cell at the right edge
+                uint32_t cnt = bright_count((uint32_t)vv) + bright_count((uint32_t)(vv >> 32));
+                if (8 * cr[u] + j < a.H) acc += cnt;
+            }
         }
         if ((int)acc > a.hot_corner) { // rare: a few cells per marker
             // reach = bounding box of the output pixels that read this cell (x0 | x1 << 16, y0 | y1 << 16; x0 > x1: none);
@@ -1206,7 +1221,8 @@ void launch_filter_mask(const FilterArgs& a, bool remap, hipStream_t s)
 void launch_bright_cells(const BrightArgs& a, hipStream_t s)
 {
     const int n = ((a.W + 7) >> 3) * ((a.H + 7) >> 3);
-    if (a.wide) hipLaunchKernelGGL(bright_cells_kernel<true>, dim3((n / 2 + 255) / 256, a.n_images), dim3(256), 0, s, a);
+    if (a.wide && a.H % 8 == 0) hipLaunchKernelGGL((bright_cells_kernel<true, true>), dim3((n / 2 + 255) / 256, a.n_images), dim3(256), 0, s, a);
+    else if (a.wide) hipLaunchKernelGGL(bright_cells_kernel<true>, dim3((n / 2 + 255) / 256, a.n_images), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(bright_cells_kernel<false>, dim3((n + 511) / 512, a.n_images), dim3(256), 0, s, a);
 }
 void launch_undistort_map(const MapArgs& m, hipStream_t s)
