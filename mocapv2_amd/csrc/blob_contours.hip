@@ -358,7 +358,7 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
                 // Necessary conditions, evaluated on the 64 columns starting at this word (this word + the next):
                 // a raster-first foreground pixel starts a run none of whose pixels touches (8-connectivity) the
                 // row above; a raster-first hole pixel starts a background run none of whose pixels has
-                // background directly above (4-connectivity).  "Touches" are spread leftwards along the run for 24
+                // background directly above (4-connectivity).  "Touches" are spread leftwards along the run for 12
                 // columns; beyond that the candidate is merely kept -- the follow step decides.
                 uint64_t w64 = (uint64_t)w | ((uint64_t)next_w << 32), n64 = (uint64_t)n | ((uint64_t)next_n << 32);
                 uint64_t above64 = n64 | (n64 << 1) | (uint64_t)(prev_n >> 31) | (n64 >> 1); // NE of column 63 unknown: treated as clear
@@ -366,14 +366,14 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
                 if (outer) {
                     uint64_t touch = w64 & above64;
 #pragma unroll
-                    for (int i = 0; i < 24; i++) touch |= (touch >> 1) & w64;
+                    for (int i = 0; i < 12; i++) touch |= (touch >> 1) & w64;
                     outer &= ~(uint32_t)touch;
                 }
                 uint32_t hole = ~w & Wn & n;
                 if (hole) {
                     uint64_t bg64 = ~w64, touch = bg64 & ~n64;
 #pragma unroll
-                    for (int i = 0; i < 24; i++) touch |= (touch >> 1) & bg64;
+                    for (int i = 0; i < 12; i++) touch |= (touch >> 1) & bg64;
                     hole &= ~(uint32_t)touch;
                 }
                 // keep only this cell's columns (and, for holes, columns inside the image)
