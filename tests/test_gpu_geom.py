@@ -281,3 +281,105 @@ def test_host_fed_batches_equal_resident_ones():
         for s in range(T):
             k = e["n"][s]
             assert np.array_equal(e["xyz"][s, :k], o["xyz"][s, :k]) and np.array_equal(e["grp"][s, :k], o["grp"][s, :k])
+
+
+# ---- calibration-time batch paths (mocapv2_amd/calibrate.py) -----------------------------------------
+def test_cheirality_vote_matches_reference_fixture(helpers):
+    """The four candidates of the bundled capture in one launch: object points, vote counts and winner equal what the
+    reference's triangulate_points + the vote of CalculateCameraPoses.py:199-231 produced (calib_cheirality.npz)."""
+    from mocapv2_amd import calibrate as cal
+    g = load("calib_cheirality")
+    params = params_from(g["K"], g["dist"])
+    R1, R2, t = cal.decompose_essential(g["K"][1].T @ g["F"] @ g["K"][0])
+    base = {"R": np.eye(3), "t": np.zeros((3, 1), np.float32)}
+    ip = g["image_points"]
+    out = cal.select_relative_pose(ip[:, 0], ip[:, 1], base, R1, R2, t, params)
+    # map this decomposition's candidate order onto the fixture's (the SVD's sign freedom may permute it)
+    cand_R, cand_t = [R1, R1, R2, R2], [t, -t, t, -t]
+    for i in range(4):
+        j = [k for k in range(4) if np.abs(cand_R[i] - g["cand_R"][k]).max() < 1e-12
+             and np.abs(cand_t[i].ravel() - g["cand_t"][k]).max() < 1e-12]
+        assert len(j) == 1
+        assert np.abs(out["object_points"][i] - g["objects"][j[0]]).max() < TOL_XYZ
+        assert out["counts"][i] == int(g["counts"][j[0]])
+    assert np.abs(out["pose"]["R"] - g["chosen_R"]).max() < 1e-12
+    assert np.abs(out["pose"]["t"].ravel() - g["chosen_t"]).max() < 1e-12
+    # brute force through the drop-in, one call per candidate, as the reference does it
+    helpers.camera_params = params
+    for i in range(4):
+        o = helpers.triangulate_points(ip, [base, {"R": cand_R[i], "t": cand_t[i]}])
+        assert np.array_equal(o, out["object_points"][i])
+
+
+def test_extrinsics_chain_equals_the_reference_loop(helpers):
+    """Three synthetic cameras, F(i -> i+1) from the true poses, sub-pixel image points.  The batched chain equals the
+    reference's loop (four `triangulate_points` calls per link through the drop-in, the vote of :214-224) pose for
+    pose; rotations are the true relative rotations, translations the unit baseline up to the sign the reference's
+    vote -- which looks at (R^T X).z, not at the depth in the second camera -- leaves open."""
+    from mocapv2_amd import calibrate as cal
+    from mocapv2_amd.synth import ZERO_DIST, fundamental_from_poses, project
+    sc = Scene(3, dist=ZERO_DIST)
+    rng = np.random.default_rng(21)
+    X = sc.markers(rng, 24)
+    K = np.asarray(sc.camera_params[0]["intrinsic_matrix"], float)
+    pts = [project(X, sc.poses[c], K, ZERO_DIST) for c in range(3)]
+    Fs = [fundamental_from_poses(sc.poses[i], sc.poses[i + 1], K, K) for i in range(2)]
+    poses = cal.extrinsics_from_fundamentals(pts, Fs, sc.camera_params)
+    assert len(poses) == 3
+
+    helpers.camera_params = sc.camera_params
+    want = [{"R": np.eye(3), "t": np.zeros((3, 1))}]
+    for i in range(2):
+        R1, R2, t = cal.decompose_essential(K.T @ Fs[i] @ K)
+        best, most = None, 0
+        for R, tt in zip([R1, R1, R2, R2], [t, -t, t, -t]):
+            p = np.transpose([pts[i], pts[i + 1]], [1, 0, 2])
+            o = helpers.triangulate_points(p, [want[-1], {"R": R, "t": tt}])
+            oc = np.array([R.T @ q for q in o])
+            n = np.sum(o[:, 2] > 0) + np.sum(oc[:, 2] > 0)
+            if n > most:
+                best, most = (R, tt), n
+        want.append({"R": best[0] @ want[-1]["R"], "t": want[-1]["t"] + want[-1]["R"] @ best[1]})
+    for got, w in zip(poses, want):
+        assert np.array_equal(got["R"], w["R"]) and np.array_equal(got["t"], w["t"])
+
+    R0, t0 = sc.poses[0]["R"], sc.poses[0]["t"].reshape(3)
+    for i in (1, 2):
+        assert np.abs(poses[i]["R"] - sc.poses[i]["R"] @ R0.T).max() < 1e-9
+    t_rel = sc.poses[1]["t"].reshape(3) - sc.poses[1]["R"] @ R0.T @ t0
+    assert min(np.abs(s * poses[1]["t"].ravel() - t_rel / np.linalg.norm(t_rel)).max() for s in (1, -1)) < 1e-9
+
+
+def test_batched_jacobian_is_scipys_two_point_jacobian():
+    """One triangulation + one reprojection launch over 7 parameter vectors give bit for bit the Jacobian SciPy's
+    `least_squares(jac='2-point')` derives by calling the residual 6 more times."""
+    from scipy.optimize._numdiff import approx_derivative
+    from mocapv2_amd import calibrate as cal
+    g = load("ba_residuals")
+    params = params_from(g["K"], g["dist"])
+    ip = g["image_points"]
+    for x0, want in zip(g["params"], g["residuals"]):
+        f0, J = cal.residual_and_jacobian(ip, x0, params)
+        assert f0.dtype == np.float32
+        assert np.allclose(f0, want, rtol=2e-6, atol=0)  # the reference's residual vector (float32)
+        single = lambda x: cal.residuals_batched(ip, [x], params)[0]  # noqa: E731
+        assert np.array_equal(single(x0), f0)
+        assert np.array_equal(J, approx_derivative(single, x0, method="2-point", f0=f0))
+
+
+def test_bundle_adjustment_reproduces_the_bundled_after_ba_extrinsics():
+    """jsons/before_ba_extrinsics.json --BA--> jsons/after_ba_extrinsics.json is the reference's own known answer for
+    the loop of lib/Helpers.py:158-176 (re-running the reference here lands on that file exactly)."""
+    from mocapv2_amd import calibrate as cal
+    g = load("calib_cheirality")
+    k1 = load("k1_bundled")
+    params = params_from(g["K"], g["dist"])
+    before = [{"R": np.eye(3), "t": np.zeros(3)}, {"R": g["before_ba_R"], "t": g["before_ba_t"]}]
+    runs = []
+    for batched in (True, False):
+        poses, result = cal.bundle_adjustment(g["image_points"], before, params, batched_jacobian=batched)
+        runs.append((poses, result))
+        assert result.status > 0
+        assert np.abs(poses[1]["R"] - k1["R"][1]).max() < 1e-6
+        assert np.abs(np.asarray(poses[1]["t"]) - k1["t"][1]).max() < 1e-6
+    assert np.array_equal(runs[0][1].x, runs[1][1].x) and runs[0][1].nfev == runs[1][1].nfev
