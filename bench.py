@@ -74,7 +74,7 @@ def cpu_baseline(scene, arrays, frames, n_steps):
 
 
 def main():
-    global T_STEPS
+    global T_STEPS, N_MARKERS
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -89,11 +89,15 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 ranks share cuda:0 and exchange through gloo (checks the multi-rank code path on a one-GPU box; "
                          "not a measurement)")
+    ap.add_argument("--markers", type=int, default=N_MARKERS,
+                    help="markers per frame: 8 = BASELINE.json configs[1] (the headline), 32 = configs[2] (a secondary measurement)")
     ap.add_argument("--cpu-steps", type=int, default=256, help="time steps in the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-secondary", dest="secondary", action="store_false",
                     help="skip the second timed run with the other distortion variant")
     args = ap.parse_args()
     T_STEPS = args.time_steps
+    N_MARKERS = args.markers
+    max_points = 32 if N_MARKERS <= 16 else 2 * N_MARKERS  # centroid record capacity per image
 
     import torch
     import torch.distributed as dist
@@ -158,7 +162,8 @@ def main():
         """Build the scene / tracker / resident batch for one distortion variant and time K steps of it."""
         scene = Scene(N_CAM, WIDTH, HEIGHT, dist=MILD_DIST if dist_name == "mild" else ZERO_DIST)
         arrays = scene_arrays(scene)
-        tracker = BatchTracker(*arrays, WIDTH, HEIGHT, T_STEPS, world=world, rank=rank, device=local_rank, depth=args.depth)
+        tracker = BatchTracker(*arrays, WIDTH, HEIGHT, T_STEPS, world=world, rank=rank, device=local_rank, depth=args.depth,
+                               max_points=max_points)
         images = tracker.local_image_list()
         frames_host = render_local(scene, images)
         frames = torch.from_numpy(frames_host).pin_memory() if args.from_host else torch.from_numpy(frames_host).cuda()
@@ -187,7 +192,7 @@ def main():
             if os.path.exists(tpath):  # HBM bytes per launch from the PMC passes (profiles/README.md), same workload
                 with open(tpath) as f:
                     tj = json.load(f)
-                if tj.get("dist") == dist_name and tj.get("images_per_launch") == per_launch:
+                if tj.get("dist") == dist_name and tj.get("images_per_launch") == per_launch and tj.get("markers", 8) == N_MARKERS:
                     traffic = tj.get("hbm_bytes_per_launch", {})
             ent = {}
             for key, name in KERNELS:
@@ -232,7 +237,9 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8+int64+f64",
             "data": "synthetic",
-            "config": {"workload": "6-camera 1920x1080 synthetic IR frames, 8 markers (BASELINE.json configs[1])",
+            "config": {"workload": "6-camera 1920x1080 synthetic IR frames, 8 markers (BASELINE.json configs[1])" if N_MARKERS == 8 else
+                       f"6-camera 1920x1080 synthetic IR frames, {N_MARKERS} markers"
+                       + (" (BASELINE.json configs[2])" if N_MARKERS == 32 else ""),
                        "cameras": N_CAM, "width": WIDTH, "height": HEIGHT, "markers": N_MARKERS,
                        "time_steps_per_step_per_gpu": T_STEPS, "distortion": args.dist,
                        "frames_resident_in_hbm": not args.from_host, "batches_in_flight": args.depth,
