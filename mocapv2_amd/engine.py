@@ -6,6 +6,7 @@ lib.ImageOperations._find_dot and lib.Helpers.find_point_correspondance_and_obje
 (reference RealtimeTracking_FLIR.py:95-143,157-209) for whole batches of frames.
 """
 import ctypes as C
+import threading
 
 import numpy as np
 import torch
@@ -270,15 +271,19 @@ class MocapContext:
                 "patch_ms": ms[4], "patch_launches": n[4]}
 
 
-_contexts = {}
+_contexts = threading.local()
 
 
 def default_context(width=1, height=1, n_slots=1, device=None):
-    """Process-wide context cache keyed by geometry (the drop-in modules under mocapv2_amd.lib use it)."""
+    """Per-thread context cache keyed by geometry (the drop-in modules under mocapv2_amd.lib use it).  A context owns
+    per-batch scratch, so its calls must not interleave; the reference runs one `_find_dot` loop per camera thread
+    (RealtimeTracking_FLIR.py:307-312) -- each of those threads gets a context of its own here, and its buffers go
+    with the thread."""
     if device is None:
         device = torch.cuda.current_device() if torch.cuda.is_available() else 0
     key = (int(width), int(height), int(n_slots), int(device))
-    ctx = _contexts.get(key)
+    cache = _contexts.__dict__.setdefault("cache", {})
+    ctx = cache.get(key)
     if ctx is None:
-        ctx = _contexts[key] = MocapContext(width, height, n_slots, device)
+        ctx = cache[key] = MocapContext(width, height, n_slots, device)
     return ctx

@@ -182,6 +182,65 @@ def test_image_operations_drop_in():
     assert none == [[None, None]]
 
 
+def test_camera_threads_as_in_the_reference_tracker(helpers):
+    """The reference's process layout (RealtimeTracking_FLIR.py:307-312): one thread per camera loops over `_find_dot`
+    and queues its image points, one consumer thread pairs them and calls
+    `find_point_correspondance_and_object_points`.  Same layout here, all threads running at once (ctypes drops the
+    GIL inside the library): every thread works on its own context and the results equal the sequential ones."""
+    import queue
+    import threading
+    import mocapv2_amd.lib.ImageOperations as IO
+    C, T = 4, 6
+    sc = Scene(C, width=640, height=360, dist=MILD_DIST)
+    IO.camera_params = [{"intrinsic_matrix": sc.K.tolist(), "distortion_coef": sc.dist.tolist()}]
+    helpers.camera_params = np.array(sc.camera_params)
+    helpers.Fs = [F.tolist() for F in sc.Fs]
+    frames = []
+    for t_ in range(T):
+        rng = np.random.default_rng(300 + t_)
+        mk = sc.markers(rng, 4, extent=0.8)
+        frames.append([sc.render(rng, mk, c, radius_range=(16, 19), salt=0.001) for c in range(C)])
+    sequential = [[IO._find_dot(frames[t_][c])[1] for c in range(C)] for t_ in range(T)]
+    seq_obj = [helpers.find_point_correspondance_and_object_points([list(l) for l in sequential[t_]], sc.poses, 4)
+               for t_ in range(T)]
+
+    queues = [queue.Queue() for _ in range(C)]
+    errors = []
+    start = threading.Barrier(C + 1)
+
+    def track_points(c):
+        try:
+            start.wait()
+            for t_ in range(T):
+                queues[c].put(IO._find_dot(frames[t_][c])[1])
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            queues[c].put(None)
+
+    results = []
+
+    def track():
+        try:
+            start.wait()
+            for t_ in range(T):
+                pts = [queues[c].get(timeout=120) for c in range(C)]
+                results.append((pts, helpers.find_point_correspondance_and_object_points([list(l) for l in pts], sc.poses, 4)))
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=track_points, args=(c,)) for c in range(C)] + [threading.Thread(target=track)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(300)
+    assert not errors, errors
+    assert len(results) == T
+    for t_ in range(T):
+        assert results[t_][0] == sequential[t_]
+        assert np.array_equal(results[t_][1][0], seq_obj[t_][0]) and np.array_equal(results[t_][1][1], seq_obj[t_][1])
+        assert len(seq_obj[t_][0]) > 0
+
+
 def test_sharded_pipeline_equals_single_rank():
     """The N-rank layout (camera-major blocks, per-segment launches with slot_base, strided reads of the gathered
     records, time-sliced triangulation) gives exactly the single-rank results.  Both 'ranks' run on this one GPU and
