@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define MOCAP_ABI_VERSION 1
+#define MOCAP_ABI_VERSION 2
 #define MOCAP_API __attribute__((visibility("default")))
 
 enum {
@@ -115,6 +115,15 @@ MOCAP_API int mocap_undistort_u8(mocap_ctx_t ctx, int slot, const void* src_dev,
 /* fast_cuda_blur(image, kernel_size) (lib/CudaOperations.py:24-41): uint8 in, uint8 out, any size */
 MOCAP_API int mocap_box_blur_u8(mocap_ctx_t ctx, const void* src_dev, void* dst_dev, int height, int width, int spitch,
                       int dpitch, int ksize, void* stream);
+/* The two pixel steps in front of _find_dot in the camera loop (RealtimeTracking_FLIR.py:103-104):
+ * cv2.cvtColor(raw, cv2.COLOR_BAYER_GR2BGR) then cv2.cvtColor(., cv2.COLOR_BGR2GRAY), fused (no BGR image), for
+ * n_images frames per launch.  pattern 0..3 = BG, GB, RG, GR (cv2.COLOR_BayerBG2BGR + pattern; the reference uses GR = 3);
+ * gray_shift 14 = OpenCV's R2Y/G2Y/B2Y fixed point (4899, 9617, 1868, >> 14), 15 = its 15-bit set (9798, 19235, 3735).
+ * Bilinear demosaic with rounded means; first/last row and column repeat their inner neighbours.  H, W >= 3.
+ * Image i starts at bayer_dev + i * src_image_stride / gray_dev + i * dst_image_stride (bytes). */
+MOCAP_API int mocap_bayer_gray_u8(mocap_ctx_t ctx, const void* bayer_dev, void* gray_dev, int n_images, int height, int width,
+                        long spitch, long dpitch, size_t src_image_stride, size_t dst_image_stride, int pattern,
+                        int gray_shift, void* stream);
 /* fast_cuda_demosaic(bayer) (lib/CudaOperations.py:84-100): uint8[H][W] -> uint8[H][W][3] (B,G,R) */
 MOCAP_API int mocap_demosaic_u8(mocap_ctx_t ctx, const void* bayer_dev, void* bgr_dev, int height, int width, int spitch,
                       void* stream);

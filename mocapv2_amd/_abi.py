@@ -4,7 +4,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmocap_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class MocapError(RuntimeError):
@@ -46,6 +46,7 @@ SIGNATURES = {
     "mocap_undistort_u8": [_vp, _i, _vp, _vp, _i, _i, _vp],
     "mocap_box_blur_u8": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "mocap_demosaic_u8": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "mocap_bayer_gray_u8": [_vp, _vp, _vp, _i, _i, _i, _l, _l, _sz, _sz, _i, _i, _vp],
     "mocap_correspond": [_vp, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, _i, _d, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mocap_triangulate_batch": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "mocap_reproject_batch": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],

@@ -689,6 +689,29 @@ int mocap_box_blur_u8(mocap_ctx_t c, const void* src, void* dst, int H, int W, i
     return MOCAP_OK;
 }
 
+int mocap_bayer_gray_u8(mocap_ctx_t c, const void* bayer, void* gray, int n_images, int H, int W, long spitch, long dpitch,
+                        size_t src_image_stride, size_t dst_image_stride, int pattern, int gray_shift, void* stream)
+{
+    if (!c || !bayer || !gray) return fail(MOCAP_E_INVALID, "null argument");
+    if (n_images < 1 || n_images > 65535 || H < 3 || W < 3 || spitch < W || dpitch < W)
+        return fail(MOCAP_E_INVALID, "bad geometry: n=%d H=%d W=%d pitches %ld %ld (H, W >= 3)", n_images, H, W, spitch, dpitch);
+    if (n_images > 1 && (src_image_stride < (size_t)spitch * (H - 1) + W || dst_image_stride < (size_t)dpitch * (H - 1) + W))
+        return fail(MOCAP_E_INVALID, "image strides smaller than an image");
+    if (pattern < 0 || pattern > 3 || (gray_shift != 14 && gray_shift != 15))
+        return fail(MOCAP_E_INVALID, "pattern %d (0..3 = BG, GB, RG, GR) / gray_shift %d (14 or 15)", pattern, gray_shift);
+    if (set_device(c)) return MOCAP_E_HIP;
+    BayerArgs a{};
+    a.src = (const uint8_t*)bayer; a.dst = (uint8_t*)gray;
+    a.H = H; a.W = W; a.n_images = n_images;
+    a.spitch = spitch; a.dpitch = dpitch; a.sstride = src_image_stride; a.dstride = dst_image_stride;
+    a.ry = pattern >= 2; a.rx = pattern == 1 || pattern == 2;   // red sites: BG (0,0), GB (0,1), RG (1,1), GR (1,0)
+    a.cb = gray_shift == 14 ? 1868u : 3735u; a.cg = gray_shift == 14 ? 9617u : 19235u; a.cr = gray_shift == 14 ? 4899u : 9798u;
+    a.shift = gray_shift;
+    launch_bayer_gray(a, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return MOCAP_OK;
+}
+
 int mocap_demosaic_u8(mocap_ctx_t c, const void* bayer, void* bgr, int H, int W, int spitch, void* stream)
 {
     if (!c || !bayer || !bgr) return fail(MOCAP_E_INVALID, "null argument");

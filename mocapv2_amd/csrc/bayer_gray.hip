@@ -1,0 +1,174 @@
+// bayer_gray.hip -- the pixel steps in front of the path: raw Bayer frame -> gray frame in one pass.
+//
+// Replaces the two OpenCV calls of the reference's camera loop (RealtimeTracking_FLIR.py:103-104)
+//     image = cv2.cvtColor(raw, cv2.COLOR_BAYER_GR2BGR);  image = cv2.cvtColor(image, cv2.COLOR_BGR2GRAY)
+// without the 3-byte BGR image in between: 1 B/px read + 1 B/px written, HBM bound.  Arithmetic as restated in
+// oracle/blob_oracle.c (orc_bayer_gray_u8): bilinear demosaic with rounded means, first/last rows and columns repeat
+// their inner neighbours, fixed-point luma with the 14-bit (default) or 15-bit coefficient set.
+//
+// Fast kernel (widths and pitches that are multiples of 8): one lane = 8 consecutive pixels (one aligned 8-byte load from each
+// of the three rows around them), the pixels left and right of those come from the neighbouring lanes' registers (DPP wave
+// shifts); the two outer lanes of a wave only feed their neighbours, so a wave writes 496 pixels of one row.  The four
+// waves of a workgroup take four consecutive rows: every frame byte is requested three times and comes from HBM once.
+// The generic kernel (any width / pitch) does one pixel per lane.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kernels.h"
+
+namespace mocap {
+
+__device__ __forceinline__ uint32_t luma(int b, int g, int r, const BayerArgs& a)
+{
+    return ((uint32_t)b * a.cb + (uint32_t)g * a.cg + (uint32_t)r * a.cr + (1u << (a.shift - 1))) >> a.shift;
+}
+
+// colours at a site from its 3x3 neighbourhood (centre c, l/r/u/d, the four diagonals)
+__device__ __forceinline__ uint32_t site_gray(int c, int l, int r_, int u, int d, int ul, int ur, int dl, int dr, bool red_row,
+                                              bool red_col, const BayerArgs& a)
+{
+    const int horiz = (l + r_ + 1) >> 1, vert = (u + d + 1) >> 1;
+    const int cross = (l + r_ + u + d + 2) >> 2, diag = (ul + ur + dl + dr + 2) >> 2;
+    int r, g, b;
+    if (red_row == red_col) { // a red or a blue site
+        g = cross;
+        r = red_row ? c : diag;
+        b = red_row ? diag : c;
+    } else {                  // a green site: its row's colour left and right, the other one above and below
+        g = c;
+        r = red_row ? horiz : vert;
+        b = red_row ? vert : horiz;
+    }
+    return luma(b, g, r, a);
+}
+
+// ---- the 8-pixels-per-lane kernel -----------------------------------------------------------------------------------
+// Within a row, sites of equal column parity are of one kind, so the lane keeps its 8 pixels (and their neighbours) as
+// pairs of 16-bit fields: e = columns (0,2) / (4,6), o = columns (1,3) / (5,7), Le = the left neighbours of e, Ro = the
+// right neighbours of o (v_perm_b32 each).  Rounded means are then plain 32-bit adds on two pixels at once, which
+// kind of site the even columns hold is a wave-uniform branch (a wave is one row), and "which of the two interpolated
+// colours is red" only swaps two luma coefficients.  Luma per pixel: three v_dot2_u32_u16 that pick the field as they multiply.
+__device__ __forceinline__ uint32_t prm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+__device__ __forceinline__ uint32_t wave_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); }
+__device__ __forceinline__ uint32_t wave_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); }
+
+struct RowPairs { uint32_t e[2], o[2], Le[2], Ro[2]; };
+
+template <bool NEED_LE, bool NEED_RO>
+__device__ __forceinline__ RowPairs row_pairs(uint2 w)
+{
+    RowPairs r;
+    r.e[0] = prm(0, w.x, 0x0c020c00u); r.e[1] = prm(0, w.y, 0x0c020c00u);
+    r.o[0] = prm(0, w.x, 0x0c030c01u); r.o[1] = prm(0, w.y, 0x0c030c01u);
+    if (NEED_LE) {
+        const uint32_t pw = wave_prev(w.y);               // columns -4..-1
+        r.Le[0] = prm(pw, w.x, 0x0c010c07u);              // columns (-1, 1)
+        r.Le[1] = prm(w.y, w.x, 0x0c050c03u);             // columns (3, 5)
+    }
+    if (NEED_RO) {
+        const uint32_t nw = wave_next(w.x);               // columns 8..11
+        r.Ro[0] = prm(w.y, w.x, 0x0c040c02u);             // columns (2, 4)
+        r.Ro[1] = prm(nw, w.y, 0x0c040c02u);              // columns (6, 8)
+    }
+    return r;
+}
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_shr(uint32_t v, int n)
+{ // both 16-bit fields shifted right on their own (v_pk_lshrrev_b16): nothing leaks from the upper into the lower field
+    return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, v) >> (unsigned short)n));
+}
+__device__ __forceinline__ uint32_t mean2(uint32_t a, uint32_t b) { return pk_shr(a + b + 0x00010001u, 1); }
+__device__ __forceinline__ uint32_t mean4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return pk_shr(a + b + c + d + 0x00020002u, 2); }
+
+// luma of the two pixels held in the 16-bit fields of (x, g, y): x = the row's own colour, y = the other one.
+// v_dot2_u32_u16 against (c, 0) / (0, c) picks the field and multiplies in one instruction.
+struct LumaCoef { uint32_t xa, ga, ya, xb, gb, yb, half; int shift; };
+__device__ __forceinline__ uint32_t dot2(uint32_t v, uint32_t c, uint32_t acc)
+{
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, v), __builtin_bit_cast(u16x2, c), acc, false);
+}
+__device__ __forceinline__ void luma2(uint32_t x, uint32_t g, uint32_t y, const LumaCoef& k, uint32_t& out_a, uint32_t& out_b)
+{
+#ifdef BAYER_LUMA_MUL
+    out_a = ((x & 0xffffu) * k.xa + ((g & 0xffffu) * k.ga + ((y & 0xffffu) * k.ya + k.half))) >> k.shift;
+    out_b = ((x >> 16) * k.xa + ((g >> 16) * k.ga + ((y >> 16) * k.ya + k.half))) >> k.shift;
+#else
+    out_a = dot2(x, k.xa, dot2(g, k.ga, dot2(y, k.ya, k.half))) >> k.shift;
+    out_b = dot2(x, k.xb, dot2(g, k.gb, dot2(y, k.yb, k.half))) >> k.shift;
+#endif
+}
+
+constexpr int BAYER_WAVE_PX = 62 * 8; // output pixels per wave: the two outer lanes only feed their neighbours
+
+__global__ __launch_bounds__(256) void bayer_gray_kernel(BayerArgs a)
+{
+    const int lane = threadIdx.x;                       // blockDim = (64, 4): a wave works on one row
+    const int y = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y); // wave-uniform: row addresses stay scalar
+    if (y >= a.H) return;
+    const int x0 = blockIdx.x * BAYER_WAVE_PX - 8 + 8 * lane;
+    const int yc = y < 1 ? 1 : (y > a.H - 2 ? a.H - 2 : y);
+    const uint8_t* __restrict__ src = a.src + (size_t)blockIdx.z * a.sstride + (size_t)(yc - 1) * a.spitch;
+    const bool in = x0 >= 0 && x0 < a.W;                // W is a multiple of 8
+    const uint32_t off = in ? (uint32_t)x0 : 0u;
+    uint2 wu = *(const uint2*)(src + off), wc = *(const uint2*)(src + a.spitch + off), wd = *(const uint2*)(src + 2 * a.spitch + off);
+    if (!in) { wu = make_uint2(0, 0); wc = wu; wd = wu; }
+
+    const bool red_row = (yc & 1) == a.ry;
+    const bool even_is_colour = (red_row ? a.rx : 1 - a.rx) == 0; // the row's red / blue sites sit on even columns
+    // x = the row's own colour (red on a red row), y = the other one: only their luma coefficients differ
+    const uint32_t cx = red_row ? a.cr : a.cb, cy = red_row ? a.cb : a.cr;
+    const LumaCoef k{cx, a.cg, cy, cx << 16, a.cg << 16, cy << 16, 1u << (a.shift - 1), a.shift};
+
+    uint32_t g[8];
+    const RowPairs C = row_pairs<true, true>(wc);
+    if (even_is_colour) {
+        const RowPairs U = row_pairs<true, false>(wu), D = row_pairs<true, false>(wd);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            // even columns: colour sites -- own value, green from the cross, the other colour from the diagonals
+            luma2(C.e[i], mean4(C.Le[i], C.o[i], U.e[i], D.e[i]), mean4(U.Le[i], U.o[i], D.Le[i], D.o[i]), k, g[4 * i], g[4 * i + 2]);
+            // odd columns: green sites -- the row's colour left and right, the other one above and below
+            luma2(mean2(C.e[i], C.Ro[i]), C.o[i], mean2(U.o[i], D.o[i]), k, g[4 * i + 1], g[4 * i + 3]);
+        }
+    } else {
+        const RowPairs U = row_pairs<false, true>(wu), D = row_pairs<false, true>(wd);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            luma2(mean2(C.Le[i], C.o[i]), C.e[i], mean2(U.e[i], D.e[i]), k, g[4 * i], g[4 * i + 2]);
+            luma2(C.o[i], mean4(C.e[i], C.Ro[i], U.o[i], D.o[i]), mean4(U.e[i], U.Ro[i], D.e[i], D.Ro[i]), k, g[4 * i + 1], g[4 * i + 3]);
+        }
+    }
+    if (x0 == 0) g[0] = g[1];                           // column 0 repeats column 1
+    if (x0 + 8 == a.W) g[7] = g[6];                     // column W-1 repeats column W-2
+    if (in && lane >= 1 && lane <= 62) {
+        uint2 out;
+        out.x = g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24);
+        out.y = g[4] | (g[5] << 8) | (g[6] << 16) | (g[7] << 24);
+        *(uint2*)(a.dst + (size_t)blockIdx.z * a.dstride + (size_t)y * a.dpitch + x0) = out;
+    }
+}
+
+__global__ __launch_bounds__(256) void bayer_gray_any_kernel(BayerArgs a)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= a.W || y >= a.H) return;
+    const int yc = y < 1 ? 1 : (y > a.H - 2 ? a.H - 2 : y), xc = x < 1 ? 1 : (x > a.W - 2 ? a.W - 2 : x);
+    const uint8_t* __restrict__ p = a.src + (size_t)blockIdx.z * a.sstride + (size_t)yc * a.spitch + xc;
+    const long sp = a.spitch;
+    a.dst[(size_t)blockIdx.z * a.dstride + (size_t)y * a.dpitch + x] =
+        (uint8_t)site_gray(p[0], p[-1], p[1], p[-sp], p[sp], p[-sp - 1], p[-sp + 1], p[sp - 1], p[sp + 1], (yc & 1) == a.ry,
+                           (xc & 1) == a.rx, a);
+}
+
+void launch_bayer_gray(const BayerArgs& a, hipStream_t s)
+{
+    const bool fast = a.W % 8 == 0 && a.spitch % 8 == 0 && a.dpitch % 8 == 0 && a.sstride % 8 == 0 && a.dstride % 8 == 0 &&
+                      (uintptr_t)a.src % 8 == 0 && (uintptr_t)a.dst % 8 == 0;
+    if (fast)
+        hipLaunchKernelGGL(bayer_gray_kernel, dim3((a.W + BAYER_WAVE_PX - 1) / BAYER_WAVE_PX, (a.H + 3) / 4, a.n_images), dim3(64, 4),
+                           0, s, a);
+    else
+        hipLaunchKernelGGL(bayer_gray_any_kernel, dim3((a.W + 63) / 64, (a.H + 3) / 4, a.n_images), dim3(64, 4), 0, s, a);
+}
+
+} // namespace mocap

@@ -113,6 +113,17 @@ void launch_undistort(const uint8_t* src, uint8_t* dst, int H, int W, int sp, in
 void launch_mask_expand(const uint32_t* mask, int wpr, uint8_t* dst, int H, int W, int dp, hipStream_t s);
 void launch_median5(const uint8_t* src, uint8_t* dst, int H, int W, int sp, int dp, int ithresh, int apply, hipStream_t s);
 void launch_demosaic(const uint8_t* bayer, uint8_t* bgr, int H, int W, int sp, hipStream_t s);
+// Bayer -> gray (bayer_gray.hip): red sites at row parity ry / column parity rx, luma coefficients cb, cg, cr >> shift
+struct BayerArgs {
+    const uint8_t* src; uint8_t* dst;
+    int H, W, n_images;
+    long spitch, dpitch;
+    size_t sstride, dstride;
+    int ry, rx;
+    uint32_t cb, cg, cr;
+    int shift;
+};
+void launch_bayer_gray(const BayerArgs& a, hipStream_t s);
 
 // ---- geometry ----
 struct CameraTable {           // device-resident, written by mocap_set_cameras / mocap_set_fundamentals

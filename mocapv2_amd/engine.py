@@ -187,6 +187,20 @@ class MocapContext:
                                               bayer.stride(0), _stream()))
         return out
 
+    def bayer_gray(self, bayer, pattern=3, gray_shift=14, out=None):
+        """Raw Bayer frames uint8 [H, W] or [n, H, W] on the GPU -> gray frames of the same shape:
+        cv2.cvtColor(cv2.cvtColor(raw, COLOR_BAYER_GR2BGR), COLOR_BGR2GRAY) of the reference's camera loop
+        (RealtimeTracking_FLIR.py:103-104) in one pass.  pattern 0..3 = BG, GB, RG, GR."""
+        assert bayer.is_cuda and bayer.dtype == torch.uint8 and bayer.dim() in (2, 3) and bayer.stride(-1) == 1
+        b3 = bayer if bayer.dim() == 3 else bayer.unsqueeze(0)
+        n, H, W = b3.shape
+        out = torch.empty((n, H, W), dtype=torch.uint8, device=bayer.device) if out is None else out.reshape(n, H, W)
+        assert out.is_contiguous() and out.dtype == torch.uint8
+        _abi.check(self.lib.mocap_bayer_gray_u8(self._h, _ptr(b3), _ptr(out), n, H, W, b3.stride(1), W,
+                                                b3.stride(0) if n > 1 else H * b3.stride(1), H * W, pattern, gray_shift,
+                                                _stream()))
+        return out if bayer.dim() == 3 else out[0]
+
     # ---- geometry stage ----------------------------------------------------------------------------------------
     def _corr_out(self, T, P, Cn):
         dev = self.device

@@ -33,11 +33,11 @@ def unpack_tracker_message(data):
 
 
 class ReplayTracker:
-    """frames [T, C, H, W] -> per time step (object_points, image_points, message) exactly as `track` would produce
+    """frames [T, C, H, W] (gray, or raw Bayer with `bayer_pattern`) -> per time step (object_points, image_points, message) exactly as `track` would produce
     them from the same detections.  `batch` time steps go through the GPU at once."""
 
     def __init__(self, K, dist, R, t, F, width, height, batch=64, obj_count=OBJ_COUNT, device=0, max_points=32,
-                 max_groups=4096):
+                 max_groups=4096, bayer_pattern=None, gray_shift=14):
         self.n_cam = len(K)
         self.batch = int(batch)
         self.obj_count = obj_count
@@ -45,6 +45,9 @@ class ReplayTracker:
         self.tracker = BatchTracker(K, dist, R, t, F, width, height, self.batch, device=device, max_points=max_points,
                                     max_groups=max_groups)
         self.point = [0, 0, 0, 0, 0, 0, 0, 0]  # RealtimeTracking_FLIR.py:171 (eight zeros until the first detection)
+        # raw sensor frames: the camera loop's cvtColor(BAYER_GR2BGR) + cvtColor(BGR2GRAY) (:103-104) run on the GPU first;
+        # bayer_pattern 0..3 = BG, GB, RG, GR (the reference: 3), None = the frames are gray already
+        self.bayer_pattern, self.gray_shift = bayer_pattern, gray_shift
 
     def _select(self, xyz, order, n):
         idx = order[:n]
@@ -68,7 +71,10 @@ class ReplayTracker:
             if nb < self.batch:  # pad the last batch with black frames (they produce no points)
                 pad = torch.zeros((self.batch - nb,) + tuple(chunk.shape[1:]), dtype=torch.uint8, device=dev)
                 chunk = torch.cat([chunk, pad], dim=0)
-            out = self.tracker.step(chunk.reshape(self.batch * self.n_cam, self.height, self.width))
+            chunk = chunk.reshape(self.batch * self.n_cam, self.height, self.width)
+            if self.bayer_pattern is not None:
+                chunk = self.tracker.ctx.bayer_gray(chunk.contiguous(), self.bayer_pattern, self.gray_shift)
+            out = self.tracker.step(chunk)
             self.tracker.synchronize()
             n = out["n"].cpu().numpy()
             xyz = out["xyz"].cpu().numpy()

@@ -16,6 +16,7 @@
  *   reference lib/ImageOperations.py:15-21   image_filter_cpu     -> orc_filter (order 1)
  *   reference lib/CudaOperations.py:5-41     blur_kernel/fast_cuda_blur -> orc_box_blur_u8
  *   reference lib/CudaOperations.py:43-100   demosaic_kernel      -> orc_demosaic_u8
+ *   reference RealtimeTracking_FLIR.py:103-104  cvtColor BayerGR2BGR + BGR2GRAY -> orc_bayer_gray_u8
  *   cv.undistort / threshold / medianBlur / findContours / contourArea / arcLength / moments
  *                                            -> orc_undistort_u8, orc_threshold_u8,
  *                                               orc_median5_u8, orc_find_contours
@@ -652,4 +653,48 @@ ORC_API void orc_demosaic_u8(const uint8_t *bayer, uint8_t *bgr, int H, int W)
             o[2] = (uint8_t)r;
         }
 #undef GP
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Pre-path pixel steps of the tracker loop (reference RealtimeTracking_FLIR.py:103-104):
+ *     gray = cv2.cvtColor(cv2.cvtColor(raw, cv2.COLOR_BAYER_GR2BGR), cv2.COLOR_BGR2GRAY)
+ * PARITY UNPINNED: both calls live in OpenCV (version unpinned, absent here); this restates the published
+ * behaviour of its portable code paths:
+ *  - bilinear Bayer demosaic: a missing colour is the rounded mean of the nearest samples of that colour --
+ *    (a + b + 1) >> 1 for the two horizontal or vertical neighbours of a green site, (a + b + c + d + 2) >> 2 for the
+ *    cross / diagonal neighbours of a red or blue site; only rows 1..H-2 and columns 1..W-2 are interpolated, column
+ *    0 / W-1 of every row then repeats column 1 / W-2, and rows 0 / H-1 repeat rows 1 / H-2;
+ *  - pattern names give the colours at (row 1, col 1) and (row 1, col 2): GR = G B / R G rows starting with G B;
+ *    pattern: 0 = BG, 1 = GB, 2 = RG, 3 = GR (cv2.COLOR_BayerBG2BGR + pattern);
+ *  - BGR2GRAY, 8 bit: (B*1868 + G*9617 + R*4899 + 2^13) >> 14  (shift 14; OpenCV's R2Y/G2Y/B2Y), or the 15-bit
+ *    coefficient set (3735, 19235, 9798, + 2^14, >> 15) its source names as the alternative (shift 15).
+ * ------------------------------------------------------------------------------------------ */
+ORC_API int orc_bayer_gray_u8(const uint8_t *bayer, uint8_t *gray, int H, int W, int pattern, int shift)
+{
+    if (H < 3 || W < 3 || pattern < 0 || pattern > 3 || (shift != 14 && shift != 15)) return -1;
+    /* the red sites: (ry, rx) parities; blue sits at the opposite parities */
+    const int ry = (pattern == 0) ? 0 : (pattern == 1) ? 0 : 1;
+    const int rx = (pattern == 0) ? 0 : (pattern == 1) ? 1 : (pattern == 2) ? 1 : 0;
+    const int cb = shift == 14 ? 1868 : 3735, cg = shift == 14 ? 9617 : 19235, cr = shift == 14 ? 4899 : 9798;
+#define BP(yy, xx) ((int)bayer[(size_t)(yy) * W + (xx)])
+    for (int y = 0; y < H; y++) {
+        const int yc = y < 1 ? 1 : (y > H - 2 ? H - 2 : y);
+        for (int x = 0; x < W; x++) {
+            const int xc = x < 1 ? 1 : (x > W - 2 ? W - 2 : x);
+            const int c = BP(yc, xc);
+            const int horiz = (BP(yc, xc - 1) + BP(yc, xc + 1) + 1) >> 1;
+            const int vert = (BP(yc - 1, xc) + BP(yc + 1, xc) + 1) >> 1;
+            const int cross = (BP(yc, xc - 1) + BP(yc, xc + 1) + BP(yc - 1, xc) + BP(yc + 1, xc) + 2) >> 2;
+            const int diag = (BP(yc - 1, xc - 1) + BP(yc - 1, xc + 1) + BP(yc + 1, xc - 1) + BP(yc + 1, xc + 1) + 2) >> 2;
+            int r, g, b;
+            const int on_red_row = (yc & 1) == ry, on_red_col = (xc & 1) == rx;
+            if (on_red_row && on_red_col) { r = c; g = cross; b = diag; }
+            else if (!on_red_row && !on_red_col) { b = c; g = cross; r = diag; }
+            else if (on_red_row) { g = c; r = horiz; b = vert; }   /* green between reds */
+            else { g = c; b = horiz; r = vert; }                    /* green between blues */
+            gray[(size_t)y * W + x] = (uint8_t)((b * cb + g * cg + r * cr + (1 << (shift - 1))) >> shift);
+        }
+    }
+#undef BP
+    return 0;
 }

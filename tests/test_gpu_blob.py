@@ -389,3 +389,65 @@ def test_extreme_aspect_ratios(torch_cuda, W, H):
             assert cnt[i] == len(exp) and xy[i, :cnt[i]].tolist() == exp, (b, i, cnt[i], len(exp))
             seen += len(exp)
     assert seen > 0
+
+
+# ---- Bayer -> gray in front of the path (RealtimeTracking_FLIR.py:103-104) --------------------------------------------
+@pytest.mark.parametrize("pattern,shift", [(3, 14), (3, 15), (0, 14), (1, 14), (2, 15)])
+def test_bayer_gray_matches_oracle(pattern, shift):
+    import torch
+    from mocapv2_amd.engine import MocapContext
+    ctx = MocapContext(8, 8)
+    rng = np.random.default_rng(60 + pattern)
+    # dword kernel: widths that are multiples of 4, one / several waves per row, partial last wave; generic kernel: the rest
+    for H, W in ((3, 4), (8, 256), (21, 260), (30, 1920), (3, 3), (5, 7), (37, 29), (16, 258)):
+        raw = rng.integers(0, 256, (H, W), dtype=np.uint8)
+        got = ctx.bayer_gray(torch.from_numpy(raw).cuda(), pattern, shift).cpu().numpy()
+        assert np.array_equal(got, oracle.bayer_gray(raw, pattern, shift)), (H, W)
+    # a batch, rows and images of the source with padding (pitch 272, image stride 20 rows)
+    n, H, W = 3, 18, 264
+    buf = rng.integers(0, 256, (n, 20, 272), dtype=np.uint8)
+    d = torch.from_numpy(buf).cuda()
+    got = ctx.bayer_gray(d[:, :H, :W], pattern, shift).cpu().numpy()
+    for i in range(n):
+        assert np.array_equal(got[i], oracle.bayer_gray(buf[i, :H, :W], pattern, shift))
+    # an unaligned view takes the generic kernel
+    got = ctx.bayer_gray(d[:, 1:1 + H, 1:1 + W], pattern, shift).cpu().numpy()
+    for i in range(n):
+        assert np.array_equal(got[i], oracle.bayer_gray(buf[i, 1:1 + H, 1:1 + W], pattern, shift))
+
+
+def test_bayer_gray_rejects_bad_arguments():
+    import torch
+    from mocapv2_amd._abi import MocapError
+    from mocapv2_amd.engine import MocapContext
+    ctx = MocapContext(8, 8)
+    raw = torch.zeros((8, 8), dtype=torch.uint8, device="cuda")
+    for kw in ({"pattern": 4}, {"pattern": -1}, {"gray_shift": 16}):
+        with pytest.raises(MocapError):
+            ctx.bayer_gray(raw, **kw)
+    with pytest.raises(MocapError):
+        ctx.bayer_gray(raw[:2], 3)
+
+
+def test_replay_from_raw_bayer_frames():
+    """Raw sensor frames through the tracker = the same tracker fed with the oracle's gray conversion of them."""
+    from mocapv2_amd.pipeline import scene_arrays
+    from mocapv2_amd.replay import ReplayTracker
+    sc = Scene(3, width=640, height=360, dist=MILD_DIST)
+    T = 5
+    gray_scene = sc.render_batch(77, T, 4, radius_range=(16, 19), salt=0.001)   # [T, C, H, W]
+    rng = np.random.default_rng(3)
+    # a sensor image whose demosaiced luma shows the same bright discs: scale the colour sites a little differently
+    raw = gray_scene.astype(np.float64)
+    raw[:, :, 0::2, 1::2] *= 0.9
+    raw[:, :, 1::2, 0::2] *= 0.95
+    raw = np.clip(raw + rng.integers(0, 3, raw.shape), 0, 255).astype(np.uint8)
+    gray = np.stack([np.stack([oracle.bayer_gray(raw[t, c], 3, 14) for c in range(3)]) for t in range(T)])
+    arrays = scene_arrays(sc)
+    a = list(ReplayTracker(*arrays, 640, 360, batch=4, bayer_pattern=3).run(raw))
+    b = list(ReplayTracker(*arrays, 640, 360, batch=4).run(gray))
+    assert len(a) == len(b) == T
+    for x, y in zip(a, b):
+        assert np.array_equal(x["object_points"], y["object_points"]) and np.array_equal(x["image_points"], y["image_points"])
+        assert x["message"] == y["message"]
+    assert sum(len(x["object_points"]) > 0 for x in a) >= T - 1

@@ -174,3 +174,59 @@ def test_demosaic_interior():
     assert out[y, x, 0] == b[y, x]
     assert out[y, x, 1] == (b[y, x - 1] + b[y, x + 1] + b[y - 1, x] + b[y + 1, x]) // 4
     assert out[0, 0, 2] == b[1, 1] // 4  # border taps read 0, divisor stays 4
+
+
+# ---- Bayer -> gray (RealtimeTracking_FLIR.py:103-104; oracle/blob_oracle.c orc_bayer_gray_u8) -------------------------
+def _bayer_gray_numpy(raw, pattern, shift):
+    """independent NumPy restatement: full-resolution colour planes by rounded neighbour means, replicated borders"""
+    raw = raw.astype(np.int64)
+    H, W = raw.shape
+    ry, rx = [(0, 0), (0, 1), (1, 1), (1, 0)][pattern]
+    yy, xx = np.mgrid[0:H, 0:W]
+    pad = np.pad(raw, 1)
+    nb = lambda dy, dx: pad[1 + dy:1 + dy + H, 1 + dx:1 + dx + W]  # noqa: E731
+    horiz = (nb(0, -1) + nb(0, 1) + 1) >> 1
+    vert = (nb(-1, 0) + nb(1, 0) + 1) >> 1
+    cross = (nb(0, -1) + nb(0, 1) + nb(-1, 0) + nb(1, 0) + 2) >> 2
+    diag = (nb(-1, -1) + nb(-1, 1) + nb(1, -1) + nb(1, 1) + 2) >> 2
+    red_row, red_col = (yy & 1) == ry, (xx & 1) == rx
+    red, blue = red_row & red_col, ~red_row & ~red_col
+    R = np.where(red, raw, np.where(blue, diag, np.where(red_row, horiz, vert)))
+    B = np.where(blue, raw, np.where(red, diag, np.where(red_row, vert, horiz)))
+    G = np.where(red | blue, cross, raw)
+    cb, cg, cr = (1868, 9617, 4899) if shift == 14 else (3735, 19235, 9798)
+    gray = (B * cb + G * cg + R * cr + (1 << (shift - 1))) >> shift
+    inner = gray[1:-1, 1:-1]
+    return np.pad(inner, 1, mode="edge").astype(np.uint8)
+
+
+@pytest.mark.parametrize("pattern", [0, 1, 2, 3])
+@pytest.mark.parametrize("shift", [14, 15])
+def test_bayer_gray_against_numpy(pattern, shift):
+    rng = np.random.default_rng(40 + pattern)
+    for H, W in ((3, 3), (4, 5), (17, 30), (64, 48)):
+        raw = rng.integers(0, 256, (H, W), dtype=np.uint8)
+        assert np.array_equal(oracle.bayer_gray(raw, pattern, shift), _bayer_gray_numpy(raw, pattern, shift))
+
+
+def test_bayer_gray_properties():
+    # a flat frame stays flat (the luma coefficients sum to 2^shift), whatever the pattern
+    for c in (0, 1, 77, 255):
+        for shift in (14, 15):
+            assert np.all(oracle.bayer_gray(np.full((8, 10), c, np.uint8), 3, shift) == c)
+    # GR (the reference's pattern): rows G B G B / R G R G.  Light only the red sites: R = 255 everywhere, G = B = 0
+    raw = np.zeros((8, 10), np.uint8)
+    raw[1::2, 0::2] = 255
+    assert np.all(oracle.bayer_gray(raw, 3, 14) == (255 * 4899 + 8192) >> 14)
+    raw[:] = 0
+    raw[0::2, 1::2] = 255  # the blue sites
+    assert np.all(oracle.bayer_gray(raw, 3, 14) == (255 * 1868 + 8192) >> 14)
+    raw[:] = 0
+    raw[0::2, 0::2] = 255
+    raw[1::2, 1::2] = 255  # both greens
+    assert np.all(oracle.bayer_gray(raw, 3, 14) == (255 * 9617 + 8192) >> 14)
+    # the border repeats the inner neighbour
+    rng = np.random.default_rng(1)
+    g = oracle.bayer_gray(rng.integers(0, 256, (9, 12), dtype=np.uint8), 3, 14)
+    assert np.array_equal(g[0], g[1]) and np.array_equal(g[-1], g[-2])
+    assert np.array_equal(g[:, 0], g[:, 1]) and np.array_equal(g[:, -1], g[:, -2])
