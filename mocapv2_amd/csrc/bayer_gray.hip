@@ -6,9 +6,10 @@
 // oracle/blob_oracle.c (orc_bayer_gray_u8): bilinear demosaic with rounded means, first/last rows and columns repeat
 // their inner neighbours, fixed-point luma with the 14-bit (default) or 15-bit coefficient set.
 //
-// Fast kernel (widths and pitches that are multiples of 8): one lane = 8 consecutive pixels (one aligned 8-byte load from each
-// of the three rows around them), the pixels left and right of those come from the neighbouring lanes' registers (DPP wave
-// shifts); the two outer lanes of a wave only feed their neighbours, so a wave writes 496 pixels of one row.  The four
+// Fast kernel (widths and pitches that are multiples of 16, or of 8): one lane = 16 (8) consecutive pixels (one aligned 16-
+// (8-)byte load from each of the three rows around them), the pixels left and right of those come from the neighbouring
+// lanes' registers (DPP wave shifts); the two outer lanes of a wave only feed their neighbours, so a wave writes 992 (496)
+// pixels of one row.  The four
 // waves of a workgroup take four consecutive rows: every frame byte is requested three times and comes from HBM once.
 // The generic kernel (any width / pitch) does one pixel per lane.
 #include <hip/hip_runtime.h>
@@ -41,9 +42,9 @@ __device__ __forceinline__ uint32_t site_gray(int c, int l, int r_, int u, int d
     return luma(b, g, r, a);
 }
 
-// ---- the 8-pixels-per-lane kernel -----------------------------------------------------------------------------------
-// Within a row, sites of equal column parity are of one kind, so the lane keeps its 8 pixels (and their neighbours) as
-// pairs of 16-bit fields: e = columns (0,2) / (4,6), o = columns (1,3) / (5,7), Le = the left neighbours of e, Ro = the
+// ---- the 16 (or 8) pixels-per-lane kernel ----------------------------------------------------------------------------
+// Within a row, sites of equal column parity are of one kind, so the lane keeps its pixels (and their neighbours) as
+// pairs of 16-bit fields: e = columns (0,2), (4,6), ..., o = columns (1,3), (5,7), ..., Le = the left neighbours of e, Ro = the
 // right neighbours of o (v_perm_b32 each).  Rounded means are then plain 32-bit adds on two pixels at once, which
 // kind of site the even columns hold is a wave-uniform branch (a wave is one row), and "which of the two interpolated
 // colours is red" only swaps two luma coefficients.  Luma per pixel: three v_dot2_u32_u16 that pick the field as they multiply.
@@ -51,23 +52,29 @@ __device__ __forceinline__ uint32_t prm(uint32_t hi, uint32_t lo, uint32_t sel) 
 __device__ __forceinline__ uint32_t wave_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); }
 __device__ __forceinline__ uint32_t wave_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); }
 
-struct RowPairs { uint32_t e[2], o[2], Le[2], Ro[2]; };
+template <int ND> struct RowPairs { uint32_t e[ND], o[ND], Le[ND], Ro[ND]; };
 
-template <bool NEED_LE, bool NEED_RO>
-__device__ __forceinline__ RowPairs row_pairs(uint2 w)
+// w[i] = columns 4i .. 4i+3 of the lane's ND * 4 pixels
+template <int ND, bool NEED_LE, bool NEED_RO>
+__device__ __forceinline__ RowPairs<ND> row_pairs(const uint32_t (&w)[ND])
 {
-    RowPairs r;
-    r.e[0] = prm(0, w.x, 0x0c020c00u); r.e[1] = prm(0, w.y, 0x0c020c00u);
-    r.o[0] = prm(0, w.x, 0x0c030c01u); r.o[1] = prm(0, w.y, 0x0c030c01u);
+    RowPairs<ND> r;
+#pragma unroll
+    for (int i = 0; i < ND; i++) {
+        r.e[i] = prm(0, w[i], 0x0c020c00u);               // columns (4i, 4i+2)
+        r.o[i] = prm(0, w[i], 0x0c030c01u);               // columns (4i+1, 4i+3)
+    }
     if (NEED_LE) {
-        const uint32_t pw = wave_prev(w.y);               // columns -4..-1
-        r.Le[0] = prm(pw, w.x, 0x0c010c07u);              // columns (-1, 1)
-        r.Le[1] = prm(w.y, w.x, 0x0c050c03u);             // columns (3, 5)
+        const uint32_t pw = wave_prev(w[ND - 1]);         // the four columns left of the lane's
+        r.Le[0] = prm(pw, w[0], 0x0c010c07u);             // columns (-1, 1)
+#pragma unroll
+        for (int i = 1; i < ND; i++) r.Le[i] = prm(w[i], w[i - 1], 0x0c050c03u); // columns (4i-1, 4i+1)
     }
     if (NEED_RO) {
-        const uint32_t nw = wave_next(w.x);               // columns 8..11
-        r.Ro[0] = prm(w.y, w.x, 0x0c040c02u);             // columns (2, 4)
-        r.Ro[1] = prm(nw, w.y, 0x0c040c02u);              // columns (6, 8)
+        const uint32_t nw = wave_next(w[0]);              // the four columns right of the lane's
+#pragma unroll
+        for (int i = 0; i < ND - 1; i++) r.Ro[i] = prm(w[i + 1], w[i], 0x0c040c02u); // columns (4i+2, 4i+4)
+        r.Ro[ND - 1] = prm(nw, w[ND - 1], 0x0c040c02u);
     }
     return r;
 }
@@ -98,20 +105,33 @@ __device__ __forceinline__ void luma2(uint32_t x, uint32_t g, uint32_t y, const 
 #endif
 }
 
-constexpr int BAYER_WAVE_PX = 62 * 8; // output pixels per wave: the two outer lanes only feed their neighbours
+// ND dwords (4 * ND pixels) per lane; the two outer lanes of a wave only feed their neighbours
+template <int ND> struct LaneLoad;
+template <> struct LaneLoad<2> { typedef uint2 type; };
+template <> struct LaneLoad<4> { typedef uint4 type; };
 
+template <int ND>
 __global__ __launch_bounds__(256) void bayer_gray_kernel(BayerArgs a)
 {
+    constexpr int PX = 4 * ND, WAVE_PX = 62 * PX;
+    typedef typename LaneLoad<ND>::type vec_t;
     const int lane = threadIdx.x;                       // blockDim = (64, 4): a wave works on one row
     const int y = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y); // wave-uniform: row addresses stay scalar
     if (y >= a.H) return;
-    const int x0 = blockIdx.x * BAYER_WAVE_PX - 8 + 8 * lane;
+    const int x0 = blockIdx.x * WAVE_PX - PX + PX * lane;
     const int yc = y < 1 ? 1 : (y > a.H - 2 ? a.H - 2 : y);
     const uint8_t* __restrict__ src = a.src + (size_t)blockIdx.z * a.sstride + (size_t)(yc - 1) * a.spitch;
-    const bool in = x0 >= 0 && x0 < a.W;                // W is a multiple of 8
+    const bool in = x0 >= 0 && x0 < a.W;                // W is a multiple of PX
     const uint32_t off = in ? (uint32_t)x0 : 0u;
-    uint2 wu = *(const uint2*)(src + off), wc = *(const uint2*)(src + a.spitch + off), wd = *(const uint2*)(src + 2 * a.spitch + off);
-    if (!in) { wu = make_uint2(0, 0); wc = wu; wd = wu; }
+    uint32_t wu[ND], wc[ND], wd[ND];
+    {
+        const vec_t vu = *(const vec_t*)(src + off), vc = *(const vec_t*)(src + a.spitch + off), vd = *(const vec_t*)(src + 2 * a.spitch + off);
+        __builtin_memcpy(wu, &vu, sizeof(vu)); __builtin_memcpy(wc, &vc, sizeof(vc)); __builtin_memcpy(wd, &vd, sizeof(vd));
+    }
+    if (!in) {
+#pragma unroll
+        for (int i = 0; i < ND; i++) wu[i] = wc[i] = wd[i] = 0u;
+    }
 
     const bool red_row = (yc & 1) == a.ry;
     const bool even_is_colour = (red_row ? a.rx : 1 - a.rx) == 0; // the row's red / blue sites sit on even columns
@@ -119,32 +139,34 @@ __global__ __launch_bounds__(256) void bayer_gray_kernel(BayerArgs a)
     const uint32_t cx = red_row ? a.cr : a.cb, cy = red_row ? a.cb : a.cr;
     const LumaCoef k{cx, a.cg, cy, cx << 16, a.cg << 16, cy << 16, 1u << (a.shift - 1), a.shift};
 
-    uint32_t g[8];
-    const RowPairs C = row_pairs<true, true>(wc);
+    uint32_t g[PX];
+    const RowPairs<ND> C = row_pairs<ND, true, true>(wc);
     if (even_is_colour) {
-        const RowPairs U = row_pairs<true, false>(wu), D = row_pairs<true, false>(wd);
+        const RowPairs<ND> U = row_pairs<ND, true, false>(wu), D = row_pairs<ND, true, false>(wd);
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < ND; i++) {
             // even columns: colour sites -- own value, green from the cross, the other colour from the diagonals
             luma2(C.e[i], mean4(C.Le[i], C.o[i], U.e[i], D.e[i]), mean4(U.Le[i], U.o[i], D.Le[i], D.o[i]), k, g[4 * i], g[4 * i + 2]);
             // odd columns: green sites -- the row's colour left and right, the other one above and below
             luma2(mean2(C.e[i], C.Ro[i]), C.o[i], mean2(U.o[i], D.o[i]), k, g[4 * i + 1], g[4 * i + 3]);
         }
     } else {
-        const RowPairs U = row_pairs<false, true>(wu), D = row_pairs<false, true>(wd);
+        const RowPairs<ND> U = row_pairs<ND, false, true>(wu), D = row_pairs<ND, false, true>(wd);
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < ND; i++) {
             luma2(mean2(C.Le[i], C.o[i]), C.e[i], mean2(U.e[i], D.e[i]), k, g[4 * i], g[4 * i + 2]);
             luma2(C.o[i], mean4(C.e[i], C.Ro[i], U.o[i], D.o[i]), mean4(U.e[i], U.Ro[i], D.e[i], D.Ro[i]), k, g[4 * i + 1], g[4 * i + 3]);
         }
     }
     if (x0 == 0) g[0] = g[1];                           // column 0 repeats column 1
-    if (x0 + 8 == a.W) g[7] = g[6];                     // column W-1 repeats column W-2
+    if (x0 + PX == a.W) g[PX - 1] = g[PX - 2];          // column W-1 repeats column W-2
     if (in && lane >= 1 && lane <= 62) {
-        uint2 out;
-        out.x = g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24);
-        out.y = g[4] | (g[5] << 8) | (g[6] << 16) | (g[7] << 24);
-        *(uint2*)(a.dst + (size_t)blockIdx.z * a.dstride + (size_t)y * a.dpitch + x0) = out;
+        uint32_t out[ND];
+#pragma unroll
+        for (int i = 0; i < ND; i++) out[i] = g[4 * i] | (g[4 * i + 1] << 8) | (g[4 * i + 2] << 16) | (g[4 * i + 3] << 24);
+        vec_t v;
+        __builtin_memcpy(&v, out, sizeof(v));
+        *(vec_t*)(a.dst + (size_t)blockIdx.z * a.dstride + (size_t)y * a.dpitch + x0) = v;
     }
 }
 
@@ -162,11 +184,14 @@ __global__ __launch_bounds__(256) void bayer_gray_any_kernel(BayerArgs a)
 
 void launch_bayer_gray(const BayerArgs& a, hipStream_t s)
 {
-    const bool fast = a.W % 8 == 0 && a.spitch % 8 == 0 && a.dpitch % 8 == 0 && a.sstride % 8 == 0 && a.dstride % 8 == 0 &&
-                      (uintptr_t)a.src % 8 == 0 && (uintptr_t)a.dst % 8 == 0;
-    if (fast)
-        hipLaunchKernelGGL(bayer_gray_kernel, dim3((a.W + BAYER_WAVE_PX - 1) / BAYER_WAVE_PX, (a.H + 3) / 4, a.n_images), dim3(64, 4),
-                           0, s, a);
+    auto aligned = [&](int n) {
+        return a.W % n == 0 && a.spitch % n == 0 && a.dpitch % n == 0 && a.sstride % n == 0 && a.dstride % n == 0 &&
+               (uintptr_t)a.src % n == 0 && (uintptr_t)a.dst % n == 0;
+    };
+    if (aligned(16))
+        hipLaunchKernelGGL(bayer_gray_kernel<4>, dim3((a.W + 62 * 16 - 1) / (62 * 16), (a.H + 3) / 4, a.n_images), dim3(64, 4), 0, s, a);
+    else if (aligned(8))
+        hipLaunchKernelGGL(bayer_gray_kernel<2>, dim3((a.W + 62 * 8 - 1) / (62 * 8), (a.H + 3) / 4, a.n_images), dim3(64, 4), 0, s, a);
     else
         hipLaunchKernelGGL(bayer_gray_any_kernel, dim3((a.W + 63) / 64, (a.H + 3) / 4, a.n_images), dim3(64, 4), 0, s, a);
 }

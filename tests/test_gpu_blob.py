@@ -398,8 +398,10 @@ def test_bayer_gray_matches_oracle(pattern, shift):
     from mocapv2_amd.engine import MocapContext
     ctx = MocapContext(8, 8)
     rng = np.random.default_rng(60 + pattern)
-    # dword kernel: widths that are multiples of 4, one / several waves per row, partial last wave; generic kernel: the rest
-    for H, W in ((3, 4), (8, 256), (21, 260), (30, 1920), (3, 3), (5, 7), (37, 29), (16, 258)):
+    # 16- and 8-pixel-per-lane kernels: widths that are multiples of 16 / of 8, one or several waves per row, partial last
+    # wave; generic kernel: the rest
+    for H, W in ((3, 16), (8, 256), (30, 1920), (9, 2000), (5, 992), (3, 8), (12, 1000), (7, 496), (6, 504), (3, 4), (21, 260),
+                 (3, 3), (5, 7), (37, 29), (16, 258)):
         raw = rng.integers(0, 256, (H, W), dtype=np.uint8)
         got = ctx.bayer_gray(torch.from_numpy(raw).cuda(), pattern, shift).cpu().numpy()
         assert np.array_equal(got, oracle.bayer_gray(raw, pattern, shift)), (H, W)
