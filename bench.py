@@ -41,7 +41,7 @@ def render_local(scene, image_list, seed_base=1000):
     return out
 
 
-def cpu_baseline(scene, arrays, frames, n_steps):
+def cpu_baseline(scene, arrays, frames, n_steps, bayer=False):
     """The oracle (scalar C port of the reference's CPU path) on `n_steps` time steps of the benchmark batch
     (frames uint8 [T, C, H, W], reused cyclically): thread-per-camera blob extraction as the reference does
     (RealtimeTracking_FLIR.py:307-312), then correspondence + DLT."""
@@ -58,7 +58,8 @@ def cpu_baseline(scene, arrays, frames, n_steps):
     n_pts = 0
     for i in range(n_steps):
         s = i % T
-        lists = list(pool.map(lambda c: oracle.find_dot(frames[s, c], K[c], dist[c], params=prm), range(N_CAM)))
+        gray = (lambda im: oracle.bayer_gray(im, 3, 14)) if bayer else (lambda im: im)
+        lists = list(pool.map(lambda c: oracle.find_dot(gray(frames[s, c]), K[c], dist[c], params=prm), range(N_CAM)))
         P = max(1, max(len(l) for l in lists))
         pts = np.zeros((N_CAM, P, 2))
         cnt = np.zeros(N_CAM, np.int32)
@@ -91,6 +92,9 @@ def main():
                          "not a measurement)")
     ap.add_argument("--markers", type=int, default=N_MARKERS,
                     help="markers per frame: 8 = BASELINE.json configs[1] (the headline), 32 = configs[2] (a secondary measurement)")
+    ap.add_argument("--bayer", action="store_true",
+                    help="secondary measurement: the resident frames are raw Bayer GR sensor frames and every step starts with the "
+                         "Bayer -> gray pre-pass (RealtimeTracking_FLIR.py:103-104); not the headline workload")
     ap.add_argument("--cpu-steps", type=int, default=256, help="time steps in the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-secondary", dest="secondary", action="store_false",
                     help="skip the second timed run with the other distortion variant")
@@ -163,7 +167,7 @@ def main():
         scene = Scene(N_CAM, WIDTH, HEIGHT, dist=MILD_DIST if dist_name == "mild" else ZERO_DIST)
         arrays = scene_arrays(scene)
         tracker = BatchTracker(*arrays, WIDTH, HEIGHT, T_STEPS, world=world, rank=rank, device=local_rank, depth=args.depth,
-                               max_points=max_points)
+                               max_points=max_points, bayer_pattern=3 if args.bayer else None)
         images = tracker.local_image_list()
         frames_host = render_local(scene, images)
         frames = torch.from_numpy(frames_host).pin_memory() if args.from_host else torch.from_numpy(frames_host).cuda()
@@ -243,13 +247,14 @@ def main():
                        "cameras": N_CAM, "width": WIDTH, "height": HEIGHT, "markers": N_MARKERS,
                        "time_steps_per_step_per_gpu": T_STEPS, "distortion": args.dist,
                        "frames_resident_in_hbm": not args.from_host, "batches_in_flight": args.depth,
+                       "input": "raw Bayer GR frames, gray conversion inside every step" if args.bayer else "gray frames",
                        "parallelism": "single launch, time-major" if world == 1 else f"camera-major blocks x{world} + 1 all-gather"},
             "roofline": roof,
             "kernel_ms_per_step": kernel_ms(prof),
             "status_ok": status_ok,
             "points_per_frame": float(n_roots.mean()),
             "dark_tile_early_out": {"tiles_per_step": prof["tiles"], "tiles_resolved_without_filtering": prof["tiles_skipped"],
-                                    "note": "exact: bright_cells_kernel reads the frames once and counts pixels >= 64 per 8x8 cell; "
+                                    "note": "exact: bright_cells_kernel reads the frames once and sums the excess over 63 per 8x8 cell; "
                                             "a (240 col x 68 row) filter tile whose cells prove that no mask bit can be set is "
                                             "answered with zeros (DESIGN.md 4.1); disabled run below"},
         }
@@ -280,7 +285,7 @@ def main():
                         "kernel streams the frame without the remap gather (SURVEY.md section 8d lists both variants)"}
             del tr2, fr2
         if world == 1 and args.cpu_steps > 0:
-            fps, dt, n_pts, last = cpu_baseline(scene, arrays, frames_host.reshape(T_STEPS, N_CAM, HEIGHT, WIDTH), args.cpu_steps)
+            fps, dt, n_pts, last = cpu_baseline(scene, arrays, frames_host.reshape(T_STEPS, N_CAM, HEIGHT, WIDTH), args.cpu_steps, args.bayer)
             line["cpu_baseline"] = {"value": round(fps, 3), "unit": "frames/s", "cores": N_CAM, "kind": "port",
                                     "sample": f"{args.cpu_steps} time steps x {N_CAM} cameras of the same workload, "
                                               f"{dt:.1f} s, thread-per-camera C oracle ({os.cpu_count()} host cpus)"}

@@ -157,7 +157,7 @@ MOCAP_API int mocap_triangulate_batch(mocap_ctx_t ctx, const double* pts_dev, co
 MOCAP_API int mocap_reproject_batch(mocap_ctx_t ctx, const double* pts_dev, const uint8_t* valid_dev, const double* xyz_dev,
                           int N, int C, int compact_k, double* mse_dev, int32_t* ok_dev, void* stream);
 
-/* Dark-tile early-out of the filter stage: one streaming kernel counts the pixels >= 64 of every 8x8 cell of the
+/* Dark-tile early-out of the filter stage: one streaming kernel sums the excess max(0, p - 63) of every 8x8 cell of the
  * frames; a filter tile whose source region provably cannot produce a set mask bit (bound in DESIGN.md 4.1) is then
  * answered with zeros without reading its pixels again.  Results are identical either way; MOCAP_SKIP_DARK=0
  * disables it.  mocap_tile_stats: number of (strip, chunk) tiles of the most recent batch and how many of them were

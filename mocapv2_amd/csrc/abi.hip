@@ -415,8 +415,8 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
     { const char* e = getenv("MOCAP_REMAP_MODE"); int cap = e ? atoi(e) : 3; if (cap < 2) cap = 3; if (cap < mode) mode = cap; }
     a.remap_mode = mode;
     int allow_cut1 = -1, allow_cut2 = -1;
-    // dark-tile early-out: largest bright-pixel count per 16x16 block that still proves an all-zero mask
-    //   2 * n * (256 - 64) * Wmax < 1024 * taps_min * (2 * thr_mul - 2 * 64 + 1)     (derivation: blob_filter.hip)
+    // dark-tile early-out: largest doubled excess sum 2E (E = sum of max(0, p - 63)) per 16x16 block that still proves an
+    // all-zero mask:   2E * Wmax < 1024 * taps_min * (2 * thr_mul - 2 * 64 + 1)     (derivation: blob_filter.hip)
     {
         long long wmax = 0;
         bool ok = true;
@@ -431,10 +431,10 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
         allow_cut1 = allow_cut2 = -1;
         if (c->W < 8 || !c->tile_rows || !c->reach || !c->cflags) ok = false;
         if (ok && wmax > 0 && per_tap > 0) {
-            allow = (int)((per_tap * t5full(c->W) * t5full(c->H) - 1) / (2LL * 192 * wmax)); // windows with all their taps
+            allow = (int)((per_tap * t5full(c->W) * t5full(c->H) - 1) / wmax); // windows with all their taps
             const long long taps1 = t5(c->W) * t5full(c->H) < t5full(c->W) * t5(c->H) ? t5(c->W) * t5full(c->H) : t5full(c->W) * t5(c->H);
-            allow_cut1 = (int)((per_tap * taps1 - 1) / (2LL * 192 * wmax));                  // smallest window cut in one axis
-            allow_cut2 = (int)((per_tap * t5(c->W) * t5(c->H) - 1) / (2LL * 192 * wmax));    // smallest window cut in both
+            allow_cut1 = (int)((per_tap * taps1 - 1) / wmax);                  // smallest window cut in one axis
+            allow_cut2 = (int)((per_tap * t5(c->W) * t5(c->H) - 1) / wmax);    // smallest window cut in both
         }
         { const char* e = getenv("MOCAP_SKIP_DARK"); if (e && atoi(e) == 0) allow = -1; }
         a.skip_allow = allow;

@@ -260,24 +260,31 @@ __device__ __forceinline__ uint32_t ldsr_combine(const LTaps& t, const LaneCols&
 
 // ---- dark-tile early-out ---------------------------------------------------------------------------------------
 // A thresholded pixel can only be 1 if its 5x5 box sum reaches thr_mul * taps.  Every undistorted pixel is at most
-// (sum of weight * tap + 512) >> 10 with weights summing to <= 1024, so with "bright" = source value >= 64:
-//     box sum  <=  taps * 63.5  +  (256 - 64) / 1024 * (total weight of the bright source pixels feeding the window)
+// (sum of weight * tap + 512) >> 10 with weights summing to <= 1024, so with the excess e(p) = max(0, p - 63) of a source
+// pixel p (p <= 63 + e(p)):
+//     box sum  <=  taps * 63.5  +  (total of weight * e over the source pixels feeding the window) / 1024
 // and a source pixel's total weight over ALL output pixels is at most Wmax (measured on the table at set-up; 1024 for
 // the identity).  The taps of one 5x5 window span at most 9 source pixels in x and y (checked at set-up), i.e. they
 // lie inside some 2x2 block of 8x8-pixel cells of a fixed grid.  Hence: if no such block of the tile's source region
-// holds more than `allow` bright pixels (allow from the inequality above with the smallest tap count, computed on
-// the host), every threshold bit of the tile is 0, so is the majority, and the tile's mask rows are zero -- without
-// running the filter.  The test is made per cell: no cell of the region with more than hot = allow / 4 bright pixels.
-__device__ __forceinline__ uint32_t bright_count(uint32_t v)
-{ // number of bytes >= 64
-    return (uint32_t)__popc(((v | (v << 1)) & 0x80808080u));
+// has an excess sum E with Wmax * 2E >= 1024 * taps * (2 * thr_mul - 127) (2E <= allow, computed on the host with the
+// smallest tap count), every threshold bit of the tile is 0, so is the majority, and the tile's mask rows are zero --
+// without running the filter.  The test is made per cell: no cell of the region with 2E above hot = allow / 4.
+// (A bound on the excess, not on the number of bright pixels: a background at 100 or the 3x3 halo a demosaiced hot
+// pixel leaves costs what it weighs, not 192 per pixel.)
+__device__ __forceinline__ uint32_t excess2_row(uint32_t lo, uint32_t hi)
+{ // sum over the 8 bytes of |p - 63| + p - 63 = 2 * max(0, p - 63); a zero byte adds nothing
+    uint32_t s = __builtin_amdgcn_sad_u8(lo, 0x3f3f3f3fu, 0u);
+    s = __builtin_amdgcn_sad_u8(lo, 0u, s);
+    s = __builtin_amdgcn_sad_u8(hi, 0x3f3f3f3fu, s);
+    s = __builtin_amdgcn_sad_u8(hi, 0u, s);
+    return s - 8u * 63u;
 }
 
-// One streaming pass over the frames -- the only time a dark tile's pixels are read.  A thread counts the pixels >= 64
+// One streaming pass over the frames -- the only time a dark tile's pixels are read.  A thread sums the excess over 63
 // of two cells of the fixed 8x8-pixel grid (16 eight-byte loads in flight; consecutive lanes take consecutive cells of
-// a cell row, so a wave's loads cover 512 contiguous bytes of each of 8 image rows).  A cell with more than `hot`
-// such pixels (4 * hot <= allow, so four dark cells can never exceed the 2x2-block bound above; `hot_edge` and
-// `hot_corner`, from the bounds of the 15- and 9-tap windows, for the cells that feed windows cut by the image
+// a cell row, so a wave's loads cover 512 contiguous bytes of each of 8 image rows; two v_sad_u8 per dword).  A cell
+// whose doubled excess exceeds `hot` (4 * hot <= allow, so four dark cells can never exceed the 2x2-block bound above;
+// `hot_edge` and `hot_corner`, from the bounds of the 15- and 9-tap windows, for the cells that feed windows cut by the image
 // border in one axis or in both) marks every filter tile its reach touches (reach = the box of output pixels that read
 // the cell, tabulated at set-up, + 4 pixels of blur and median) by widening the tile's range of reachable mask rows
 // and columns (atomic min / max).  Tiles left unmarked, and rows outside the range, provably filter to zeros.
@@ -346,12 +353,12 @@ __global__ __launch_bounds__(256) void bright_cells_kernel(BrightArgs a)
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             if (WIDE) { // cells are whole
-                const uint32_t cnt = bright_count(v[u][j].x) + bright_count(v[u][j].y);
-                if (FULL || 8 * cr[u] + j < a.H) acc += cnt;
+                const uint32_t e2 = excess2_row(v[u][j].x, v[u][j].y);
+                if (FULL || 8 * cr[u] + j < a.H) acc += e2;
             } else {
                 uint64_t vv = (((uint64_t)v[u][j].y << 32) | v[u][j].x) >> sh[u]; // drops the bytes left of the cell at the right edge
-                uint32_t cnt = bright_count((uint32_t)vv) + bright_count((uint32_t)(vv >> 32));
-                if (8 * cr[u] + j < a.H) acc += cnt;
+                const uint32_t e2 = excess2_row((uint32_t)vv, (uint32_t)(vv >> 32));
+                if (8 * cr[u] + j < a.H) acc += e2;
             }
         }
         if ((int)acc > a.hot_corner) { // rare: a few cells per marker
@@ -624,7 +631,7 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
         const size_t cell_index = cell_row + strip;
 
         if (a.skip_allow >= 0) {
-            // ---- dark-tile early-out (see the comment above bright_count) ----
+            // ---- dark-tile early-out (see the comment above excess2_row) ----
             // bright_cells_kernel has left, per tile, the range of mask rows that hot cells of its source region can reach
             // (empty = none: the tile is all zeros).  Only those rows are filtered.  The context's mask keeps the
             // invariant "a tile's mask bytes are zero unless its occupancy word has bit 31 set" from batch to batch, so

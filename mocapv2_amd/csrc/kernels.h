@@ -20,7 +20,7 @@ struct FilterArgs {
                           //   strip's pixels of that row read); used by the LDS-staged remap variant
     int remap_mode;       // 0 plain / 2 per-pixel gather, 3 pipelined gather, 4 LDS-staged
     int skip_allow;       // dark-tile early-out: a tile whose source region has no 16x16 block (2x2 cells of 8x8 px)
-                          //   with more than this many pixels >= 64 provably yields an all-zero mask; -1 = off
+                          //   whose doubled excess sum, 2 * sum of max(0, p - 63), exceeds this provably yields an all-zero mask; -1 = off
     uint32_t* tile_rows;  // [n_images][n_cgroups*4][n_strips][4] (indexed like cells): first / last mask row and first / last
                           //   column that hot cells of the tile's source region can reach, (0xffffffff, 0) = none; written by
                           //   bright_cells_kernel, read and reset by the filter kernel; used if skip_allow >= 0
@@ -84,7 +84,7 @@ struct BrightArgs {
     int cam_mod;                  // undistort slot of image n = n % cam_mod (the tables already point at the first slot)
     uint32_t ncx_magic;           // ceil(2^32 / d), d = ceil(W/8) (wide: d / 2), if that divides every index exactly by multiply-high, else 0
     int wide;                     // 1 = 16-byte loads (W, pitch, image stride, base all multiples of 16; ncx_magic != 0)
-    int hot, hot_edge, hot_corner; // a cell with more than this many pixels >= 64 is hot (4 * hot <= skip_allow); _edge /
+    int hot, hot_edge, hot_corner; // a cell whose doubled excess sum (2 * sum of max(0, p - 63)) exceeds this is hot (4 * hot <= skip_allow); _edge /
                                   //   _corner for cells feeding windows the image border cuts in one axis / in both
     const uint2* reach;           // [cam_mod][cells]: box of the output pixels that read the 8x8 source cell, x0 | x1 << 16, y0 | y1 << 16
     const uint8_t* cflags;        // [cam_mod][cells]: 1 / 2 = the cell feeds windows the image border cuts in one axis / in both

@@ -58,6 +58,7 @@ class _Lane:
     def __init__(self, ctx, records, stream):
         self.ctx, self.records, self.stream, self.out = ctx, records, stream, None
         self.staging = None  # device copy of a batch that arrived in host memory
+        self.gray = None     # gray frames of a batch that arrived as raw Bayer frames
 
 
 class BatchTracker:
@@ -68,12 +69,15 @@ class BatchTracker:
     the next (the streaming scan).  Results of a batch are complete once its stream (or the device) is synchronised."""
 
     def __init__(self, K, dist, R, t, F, width, height, steps_per_rank, world=1, rank=0, device=0, group=None,
-                 max_points=32, max_groups=4096, depth=1):
+                 max_points=32, max_groups=4096, depth=1, bayer_pattern=None, gray_shift=14):
         self.n_cam = len(K)
         self.T = int(steps_per_rank)
         self.world, self.rank, self.group = world, rank, group
         self.t_total = self.T * world
         self.max_points, self.max_groups = max_points, max_groups
+        # raw sensor frames: the camera loop's Bayer -> BGR -> gray (RealtimeTracking_FLIR.py:103-104) runs first, on the
+        # batch's own stream and into the batch's own gray buffer (pattern 0..3 = BG, GB, RG, GR; None = gray frames)
+        self.bayer_pattern, self.gray_shift = bayer_pattern, gray_shift
         self.segs = shard_plan(self.n_cam, self.T, world, rank)
         local_cams = sorted({c for c, _, _ in self.segs})
         self.slot_of = {c: i for i, c in enumerate(local_cams)}
@@ -174,6 +178,11 @@ class BatchTracker:
         return lane.staging
 
     def _run(self, frames):
+        if self.bayer_pattern is not None:
+            lane = self._cur
+            if lane.gray is None or lane.gray.shape != frames.shape:
+                lane.gray = torch.empty(frames.shape, dtype=torch.uint8, device=lane.ctx.device)
+            frames = lane.ctx.bayer_gray(frames, self.bayer_pattern, self.gray_shift, out=lane.gray)
         records = self.extract(frames)
         gathered = allgather_records(records, self.world, self.group)  # [C * T_total, REC] camera-major when world > 1
         return self.triangulate(gathered)

@@ -43,7 +43,7 @@ class ReplayTracker:
         self.obj_count = obj_count
         self.width, self.height = width, height
         self.tracker = BatchTracker(K, dist, R, t, F, width, height, self.batch, device=device, max_points=max_points,
-                                    max_groups=max_groups)
+                                    max_groups=max_groups, bayer_pattern=bayer_pattern, gray_shift=gray_shift)
         self.point = [0, 0, 0, 0, 0, 0, 0, 0]  # RealtimeTracking_FLIR.py:171 (eight zeros until the first detection)
         # raw sensor frames: the camera loop's cvtColor(BAYER_GR2BGR) + cvtColor(BGR2GRAY) (:103-104) run on the GPU first;
         # bayer_pattern 0..3 = BG, GB, RG, GR (the reference: 3), None = the frames are gray already
@@ -71,10 +71,7 @@ class ReplayTracker:
             if nb < self.batch:  # pad the last batch with black frames (they produce no points)
                 pad = torch.zeros((self.batch - nb,) + tuple(chunk.shape[1:]), dtype=torch.uint8, device=dev)
                 chunk = torch.cat([chunk, pad], dim=0)
-            chunk = chunk.reshape(self.batch * self.n_cam, self.height, self.width)
-            if self.bayer_pattern is not None:
-                chunk = self.tracker.ctx.bayer_gray(chunk.contiguous(), self.bayer_pattern, self.gray_shift)
-            out = self.tracker.step(chunk)
+            out = self.tracker.step(chunk.reshape(self.batch * self.n_cam, self.height, self.width).contiguous())
             self.tracker.synchronize()
             n = out["n"].cpu().numpy()
             xyz = out["xyz"].cpu().numpy()

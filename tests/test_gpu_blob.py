@@ -217,6 +217,12 @@ def test_dark_tile_early_out_is_exact(torch_cuda, monkeypatch, scale, salt, nois
         pts = [(y0 + a, x0 + b) for a in range(5) for b in range(5)][:k]
         for (yy, xx) in pts:
             frames[0, yy, xx] = 255
+    # plateaus barely above / below the threshold on a background at the darkest "bright-free" level: every pixel of the
+    # plateau carries a small excess (217 - 63), none is near 255 -- the bound works on excess sums, not on counts
+    frames[1, 200:260, 300:420] = 63
+    frames[1, 215:227, 320:332] = 217   # box mean 217 > 216 inside: mask pixels
+    frames[1, 215:227, 360:372] = 216   # never above the threshold
+    frames[1, 236:241, 322:327] = 250   # too small for the median
     frames[1, :3, :] = 255      # saturated top rows (border taps counts)
     frames[2, :, W - 2:] = 255  # saturated right columns
     dist = np.array(MILD_DIST) * scale
@@ -230,7 +236,7 @@ def test_dark_tile_early_out_is_exact(torch_cuda, monkeypatch, scale, salt, nois
             exp = [oracle.image_filter(frames[i] if ident else oracle.undistort(frames[i], K, dist), 0) != 0 for i in range(3)]
         for i in range(3):
             assert np.array_equal(got[i], exp[i]), (skip, i, np.argwhere(got[i] != exp[i])[:4])
-    assert exp[0].any()
+    assert exp[0].any() and exp[1][200:260, 300:345].any() and not exp[1][200:260, 350:420].any()
 
 
 @pytest.mark.parametrize("scale", [0.0, 1.0])
