@@ -75,7 +75,7 @@ def cpu_baseline(scene, arrays, frames, n_steps, bayer=False):
 
 
 def main():
-    global T_STEPS, N_MARKERS
+    global T_STEPS, N_MARKERS, WIDTH, HEIGHT
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -92,6 +92,9 @@ def main():
                          "not a measurement)")
     ap.add_argument("--markers", type=int, default=N_MARKERS,
                     help="markers per frame: 8 = BASELINE.json configs[1] (the headline), 32 = configs[2] (a secondary measurement)")
+    ap.add_argument("--frame", default=f"{WIDTH}x{HEIGHT}",
+                    help="frame size WxH: 1920x1080 = the headline workload; 3840x2160 = the frame size of BASELINE.json configs[4] "
+                         "(a secondary measurement; lower --time-steps accordingly)")
     ap.add_argument("--bayer", action="store_true",
                     help="secondary measurement: the resident frames are raw Bayer GR sensor frames and every step starts with the "
                          "Bayer -> gray pre-pass (RealtimeTracking_FLIR.py:103-104); not the headline workload")
@@ -101,6 +104,7 @@ def main():
     args = ap.parse_args()
     T_STEPS = args.time_steps
     N_MARKERS = args.markers
+    WIDTH, HEIGHT = (int(v) for v in args.frame.lower().split("x"))
     max_points = 32 if N_MARKERS <= 16 else 2 * N_MARKERS  # centroid record capacity per image
 
     import torch
@@ -196,7 +200,8 @@ def main():
             if os.path.exists(tpath):  # HBM bytes per launch from the PMC passes (profiles/README.md), same workload
                 with open(tpath) as f:
                     tj = json.load(f)
-                if tj.get("dist") == dist_name and tj.get("images_per_launch") == per_launch and tj.get("markers", 8) == N_MARKERS:
+                if tj.get("dist") == dist_name and tj.get("images_per_launch") == per_launch and tj.get("markers", 8) == N_MARKERS \
+                        and (WIDTH, HEIGHT) == (1920, 1080) and not args.bayer:
                     traffic = tj.get("hbm_bytes_per_launch", {})
             ent = {}
             for key, name in KERNELS:
@@ -237,12 +242,13 @@ def main():
 
         roof = roofline_of(prof, len(images), 1 if world == 1 else len(tracker.segs), args.dist)
         line = {
-            "metric": "frames/sec (6-cam 1080p)", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
+            "metric": "frames/sec (6-cam 1080p)" if (WIDTH, HEIGHT) == (1920, 1080) else f"frames/sec (6-cam {WIDTH}x{HEIGHT})", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8+int64+f64",
             "data": "synthetic",
-            "config": {"workload": "6-camera 1920x1080 synthetic IR frames, 8 markers (BASELINE.json configs[1])" if N_MARKERS == 8 else
-                       f"6-camera 1920x1080 synthetic IR frames, {N_MARKERS} markers"
+            "config": {"workload": "6-camera 1920x1080 synthetic IR frames, 8 markers (BASELINE.json configs[1])"
+                       if (N_MARKERS, WIDTH, HEIGHT) == (8, 1920, 1080) else
+                       f"6-camera {WIDTH}x{HEIGHT} synthetic IR frames, {N_MARKERS} markers"
                        + (" (BASELINE.json configs[2])" if N_MARKERS == 32 else ""),
                        "cameras": N_CAM, "width": WIDTH, "height": HEIGHT, "markers": N_MARKERS,
                        "time_steps_per_step_per_gpu": T_STEPS, "distortion": args.dist,
