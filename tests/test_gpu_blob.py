@@ -322,7 +322,7 @@ def test_centroids_odd_sizes_two_batches(torch_cuda, W, H, scale):
     assert seen > 0
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MOCAP_FUZZ_SEEDS", "12"))))
 def test_early_out_fuzz_thresholds_and_brightness(torch_cuda, seed):
     """Random thresholds, background levels, bright clutter and lens models: the mask (caller-owned, scan-cleared) and
     the centroids (context-owned mask, cleared on demand) equal the oracle's, batch after batch on one context."""
