@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define MOCAP_ABI_VERSION 2
+#define MOCAP_ABI_VERSION 3
 #define MOCAP_API __attribute__((visibility("default")))
 
 enum {
@@ -124,6 +124,15 @@ MOCAP_API int mocap_box_blur_u8(mocap_ctx_t ctx, const void* src_dev, void* dst_
 MOCAP_API int mocap_bayer_gray_u8(mocap_ctx_t ctx, const void* bayer_dev, void* gray_dev, int n_images, int height, int width,
                         long spitch, long dpitch, size_t src_image_stride, size_t dst_image_stride, int pattern,
                         int gray_shift, void* stream);
+/* mocap_blob_centroids on raw Bayer frames: the camera loop's cvtColor pair (RealtimeTracking_FLIR.py:103-104) followed by
+ * _find_dot (:105) for a batch.  gray_frames_dev receives the gray frames (same pitch and image stride as the Bayer
+ * frames); where the geometry allows (width a multiple of 16, height of 8, 16-byte aligned) the conversion is fused
+ * with the early-out's streaming pass, so every frame byte is read once and the gray bytes are not read back to be
+ * scanned.  Results equal mocap_bayer_gray_u8 followed by mocap_blob_centroids.  H, W >= 3. */
+MOCAP_API int mocap_blob_centroids_bayer(mocap_ctx_t ctx, const void* bayer_frames_dev, void* gray_frames_dev, int n_images,
+                               int cam_mod, int slot_base, size_t image_stride, int pitch, int pattern, int gray_shift,
+                               int32_t* out_xy_dev, long xy_stride, int32_t* out_count_dev, long count_stride,
+                               int max_blobs, void* stream);
 /* fast_cuda_demosaic(bayer) (lib/CudaOperations.py:84-100): uint8[H][W] -> uint8[H][W][3] (B,G,R) */
 MOCAP_API int mocap_demosaic_u8(mocap_ctx_t ctx, const void* bayer_dev, void* bgr_dev, int height, int width, int spitch,
                       void* stream);

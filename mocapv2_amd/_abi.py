@@ -4,7 +4,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmocap_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class MocapError(RuntimeError):
@@ -40,6 +40,7 @@ SIGNATURES = {
     "mocap_set_cameras": [_vp, _i, _dp, _dp, _dp, _dp],
     "mocap_set_fundamentals": [_vp, _i, _dp],
     "mocap_blob_centroids": [_vp, _vp, _i, _i, _i, _sz, _i, _vp, _l, _vp, _l, _i, _vp],
+    "mocap_blob_centroids_bayer": [_vp, _vp, _vp, _i, _i, _i, _sz, _i, _i, _i, _vp, _l, _vp, _l, _i, _vp],
     "mocap_filter_mask": [_vp, _vp, _i, _i, _i, _sz, _i, _vp, _vp],
     "mocap_contours_from_mask": [_vp, _vp, _i, _vp, _l, _vp, _l, _i, _vp, _vp, _i, _vp],
     "mocap_image_filter_u8": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],

@@ -386,8 +386,10 @@ static int check_frames(mocap_ctx* c, const void* frames, int n_images, int cam_
 }
 
 
+// bayer != nullptr: `frames` (= bayer->dst) does not exist yet -- the Bayer -> gray pass that writes it runs first, fused
+// with the streaming scan where the geometry allows (it has the gray bytes in registers anyway)
 static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mod, int slot_base, size_t image_stride,
-                      int pitch, uint32_t* mask, uint32_t* cells, hipStream_t s)
+                      int pitch, uint32_t* mask, uint32_t* cells, hipStream_t s, const BayerArgs* bayer = nullptr)
 {
     FilterArgs a;
     a.src = (const uint8_t*)frames; a.image_stride = image_stride; a.pitch = pitch; a.H = c->H; a.W = c->W;
@@ -476,8 +478,16 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
                      c->tile_rows, tl.n_cgroups * 4, tl.n_strips, (uint32_t)(((1u << 23) + tl.rows - 1) / tl.rows),
                      mask, own_mask ? 0 : (size_t)n_images * c->H * c->wpr, ((uintptr_t)mask & 15) == 0};
         prof_begin(c, 3, s, p, on);
-        launch_bright_cells(b, s);
+        if (bayer && own_mask && bayer_scan_fusable(*bayer)) launch_bayer_gray_scan(*bayer, b, s);
+        else {
+            if (bayer) launch_bayer_gray(*bayer, s);
+            launch_bright_cells(b, s);
+        }
         prof_end(c, 3, s, p, on);
+        HIP_TRY(hipGetLastError());
+    }
+    else if (bayer) { // no early-out (not provable for this table, or MOCAP_SKIP_DARK=0): the plain gray pass
+        launch_bayer_gray(*bayer, s);
         HIP_TRY(hipGetLastError());
     }
     if (a.patch) {
@@ -623,6 +633,28 @@ int mocap_blob_centroids(mocap_ctx_t c, const void* frames, int n_images, int ca
                         (hipStream_t)stream);
 }
 
+static int bayer_args(BayerArgs& a, const void* bayer, void* gray, int n_images, int H, int W, long spitch, long dpitch,
+                      size_t src_image_stride, size_t dst_image_stride, int pattern, int gray_shift);
+
+int mocap_blob_centroids_bayer(mocap_ctx_t c, const void* bayer_frames, void* gray_frames, int n_images, int cam_mod, int slot_base,
+                               size_t image_stride, int pitch, int pattern, int gray_shift, int32_t* out_xy, long xy_stride,
+                               int32_t* out_count, long count_stride, int max_blobs, void* stream)
+{
+    int rc = check_frames(c, bayer_frames, n_images, cam_mod, slot_base, image_stride, pitch);
+    if (rc) return rc;
+    if (!out_xy || !out_count || max_blobs < 1 || xy_stride < 2L * max_blobs || count_stride < 1)
+        return fail(MOCAP_E_INVALID, "bad output arguments");
+    BayerArgs b;
+    if ((rc = bayer_args(b, bayer_frames, gray_frames, n_images, c->H, c->W, pitch, pitch, image_stride, image_stride, pattern, gray_shift)))
+        return rc;
+    if (set_device(c)) return MOCAP_E_HIP;
+    if ((rc = ensure_mask(c, n_images))) return rc;
+    if ((rc = run_filter(c, gray_frames, n_images, cam_mod, slot_base, image_stride, pitch, c->mask, c->cells, (hipStream_t)stream, &b)))
+        return rc;
+    return run_contours(c, c->mask, c->cells, n_images, out_xy, xy_stride, out_count, count_stride, max_blobs, nullptr, nullptr, 0,
+                        (hipStream_t)stream);
+}
+
 int mocap_undistort_u8(mocap_ctx_t c, int slot, const void* src, void* dst, int spitch, int dpitch, void* stream)
 {
     if (!c || !src || !dst) return fail(MOCAP_E_INVALID, "null argument");
@@ -689,24 +721,34 @@ int mocap_box_blur_u8(mocap_ctx_t c, const void* src, void* dst, int H, int W, i
     return MOCAP_OK;
 }
 
-int mocap_bayer_gray_u8(mocap_ctx_t c, const void* bayer, void* gray, int n_images, int H, int W, long spitch, long dpitch,
-                        size_t src_image_stride, size_t dst_image_stride, int pattern, int gray_shift, void* stream)
+static int bayer_args(BayerArgs& a, const void* bayer, void* gray, int n_images, int H, int W, long spitch, long dpitch,
+                      size_t src_image_stride, size_t dst_image_stride, int pattern, int gray_shift)
 {
-    if (!c || !bayer || !gray) return fail(MOCAP_E_INVALID, "null argument");
+    if (!bayer || !gray) return fail(MOCAP_E_INVALID, "null argument");
     if (n_images < 1 || n_images > 65535 || H < 3 || W < 3 || spitch < W || dpitch < W)
         return fail(MOCAP_E_INVALID, "bad geometry: n=%d H=%d W=%d pitches %ld %ld (H, W >= 3)", n_images, H, W, spitch, dpitch);
     if (n_images > 1 && (src_image_stride < (size_t)spitch * (H - 1) + W || dst_image_stride < (size_t)dpitch * (H - 1) + W))
         return fail(MOCAP_E_INVALID, "image strides smaller than an image");
     if (pattern < 0 || pattern > 3 || (gray_shift != 14 && gray_shift != 15))
         return fail(MOCAP_E_INVALID, "pattern %d (0..3 = BG, GB, RG, GR) / gray_shift %d (14 or 15)", pattern, gray_shift);
-    if (set_device(c)) return MOCAP_E_HIP;
-    BayerArgs a{};
+    a = BayerArgs{};
     a.src = (const uint8_t*)bayer; a.dst = (uint8_t*)gray;
     a.H = H; a.W = W; a.n_images = n_images;
     a.spitch = spitch; a.dpitch = dpitch; a.sstride = src_image_stride; a.dstride = dst_image_stride;
     a.ry = pattern >= 2; a.rx = pattern == 1 || pattern == 2;   // red sites: BG (0,0), GB (0,1), RG (1,1), GR (1,0)
     a.cb = gray_shift == 14 ? 1868u : 3735u; a.cg = gray_shift == 14 ? 9617u : 19235u; a.cr = gray_shift == 14 ? 4899u : 9798u;
     a.shift = gray_shift;
+    return 0;
+}
+
+int mocap_bayer_gray_u8(mocap_ctx_t c, const void* bayer, void* gray, int n_images, int H, int W, long spitch, long dpitch,
+                        size_t src_image_stride, size_t dst_image_stride, int pattern, int gray_shift, void* stream)
+{
+    if (!c) return fail(MOCAP_E_INVALID, "null argument");
+    BayerArgs a;
+    int rc = bayer_args(a, bayer, gray, n_images, H, W, spitch, dpitch, src_image_stride, dst_image_stride, pattern, gray_shift);
+    if (rc) return rc;
+    if (set_device(c)) return MOCAP_E_HIP;
     launch_bayer_gray(a, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return MOCAP_OK;

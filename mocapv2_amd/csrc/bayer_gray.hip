@@ -11,10 +11,12 @@
 // lanes' registers (DPP wave shifts); the two outer lanes of a wave only feed their neighbours, so a wave writes 992 (496)
 // pixels of one row.  The four
 // waves of a workgroup take four consecutive rows: every frame byte is requested three times and comes from HBM once.
-// The generic kernel (any width / pitch) does one pixel per lane.
+// The generic kernel (any width / pitch) does one pixel per lane.  bayer_gray_scan_kernel (below) is the fast kernel fused with
+// the early-out's streaming scan: it walks 8 rows per wave and marks the filter tiles from the gray bytes it has in registers.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "kernels.h"
+#include "scan_mark.h"
 
 namespace mocap {
 
@@ -170,6 +172,106 @@ __global__ __launch_bounds__(256) void bayer_gray_kernel(BayerArgs a)
     }
 }
 
+// ---- Bayer -> gray fused with the early-out's streaming pass (widths that are multiples of 16, heights of 8) ----------
+// One wave = one cell row (8 image rows) x 992 pixels.  A lane walks its 16 columns down the 8 rows with a sliding window
+// of three rows of field pairs -- every source row is loaded and unpacked once instead of three times --, writes the gray
+// rows and sums their excess per 8x8 cell on the way (the gray bytes are in registers: the separate scan of the gray
+// frames, one more read of every byte, disappears); hot cells mark tiles exactly as bright_cells_kernel does.
+// Rows 0 and H-1 repeat rows 1 and H-2: they are not computed, their neighbours are written and counted twice.
+__device__ __forceinline__ LumaCoef luma_coef(const BayerArgs& a, bool red_row)
+{
+    const uint32_t cx = red_row ? a.cr : a.cb, cy = red_row ? a.cb : a.cr;
+    return LumaCoef{cx, a.cg, cy, cx << 16, a.cg << 16, cy << 16, 1u << (a.shift - 1), a.shift};
+}
+
+__global__ __launch_bounds__(256) void bayer_gray_scan_kernel(BayerArgs a, BrightArgs b)
+{
+    constexpr int ND = 4, PX = 16, WAVE_PX = 62 * PX;
+    const int lane = threadIdx.x;                       // blockDim = (64, 4): a wave works on one cell row
+    const int cy = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + threadIdx.y);
+    if (8 * cy >= a.H) return;                          // H is a multiple of 8
+    const int image = blockIdx.z;
+    const int x0 = blockIdx.x * WAVE_PX - PX + PX * lane;
+    const bool in = x0 >= 0 && x0 < a.W;                // W is a multiple of 16
+    const uint32_t off = in ? (uint32_t)x0 : 0u;
+    const uint8_t* __restrict__ src = a.src + (size_t)image * a.sstride;
+    uint8_t* __restrict__ dst = a.dst + (size_t)image * a.dstride;
+
+    // per row parity: which kind of site the even columns hold, and the luma coefficient order (8 * cy is even)
+    const bool red0 = a.ry == 0, red1 = a.ry == 1;
+    const bool eic0 = (red0 ? a.rx : 1 - a.rx) == 0, eic1 = (red1 ? a.rx : 1 - a.rx) == 0;
+    const LumaCoef k0 = luma_coef(a, red0), k1 = luma_coef(a, red1);
+
+    auto load_row = [&](int r) {
+        r = r < 0 ? 0 : (r > a.H - 1 ? a.H - 1 : r);    // rows -1 and H only stand in for windows that are never evaluated
+        uint4 v = *(const uint4*)(src + (size_t)r * a.spitch + off);
+        if (!in) v = make_uint4(0u, 0u, 0u, 0u);
+        return v;
+    };
+    auto pairs_of = [&](uint4 v) {
+        uint32_t w[ND];
+        __builtin_memcpy(w, &v, sizeof(v));
+        return row_pairs<ND, true, true>(w);
+    };
+    uint4 raw[10];
+#pragma unroll
+    for (int r = 0; r < 10; r++) raw[r] = load_row(8 * cy - 1 + r);
+
+    RowPairs<ND> U = pairs_of(raw[0]), C = pairs_of(raw[1]);
+    uint32_t acc0 = 0, acc1 = 0;
+    const bool writer = in && lane >= 1 && lane <= 62;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int y = 8 * cy + j;
+        const RowPairs<ND> D = pairs_of(raw[j + 2]);
+        if (y != 0 && y != a.H - 1) {                   // wave-uniform
+            const bool eic = (j & 1) ? eic1 : eic0;
+            const LumaCoef& k = (j & 1) ? k1 : k0;
+            uint32_t g[PX];
+            if (eic) {
+#pragma unroll
+                for (int i = 0; i < ND; i++) {
+                    luma2(C.e[i], mean4(C.Le[i], C.o[i], U.e[i], D.e[i]), mean4(U.Le[i], U.o[i], D.Le[i], D.o[i]), k, g[4 * i], g[4 * i + 2]);
+                    luma2(mean2(C.e[i], C.Ro[i]), C.o[i], mean2(U.o[i], D.o[i]), k, g[4 * i + 1], g[4 * i + 3]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < ND; i++) {
+                    luma2(mean2(C.Le[i], C.o[i]), C.e[i], mean2(U.e[i], D.e[i]), k, g[4 * i], g[4 * i + 2]);
+                    luma2(C.o[i], mean4(C.e[i], C.Ro[i], U.o[i], D.o[i]), mean4(U.e[i], U.Ro[i], D.e[i], D.Ro[i]), k, g[4 * i + 1], g[4 * i + 3]);
+                }
+            }
+            if (x0 == 0) g[0] = g[1];                   // column 0 repeats column 1
+            if (x0 + PX == a.W) g[PX - 1] = g[PX - 2];  // column W-1 repeats column W-2
+            uint4 out;
+            out.x = g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24);
+            out.y = g[4] | (g[5] << 8) | (g[6] << 16) | (g[7] << 24);
+            out.z = g[8] | (g[9] << 8) | (g[10] << 16) | (g[11] << 24);
+            out.w = g[12] | (g[13] << 8) | (g[14] << 16) | (g[15] << 24);
+            const bool twice = y == 1 || y == a.H - 2;  // wave-uniform
+            if (writer) {
+                *(uint4*)(dst + (size_t)y * a.dpitch + x0) = out;
+                if (y == 1) *(uint4*)(dst + x0) = out;
+                if (y == a.H - 2) *(uint4*)(dst + (size_t)(a.H - 1) * a.dpitch + x0) = out;
+            }
+            const uint32_t e0 = excess2_row(out.x, out.y), e1 = excess2_row(out.z, out.w);
+            acc0 += twice ? 2u * e0 : e0;
+            acc1 += twice ? 2u * e1 : e1;
+        }
+        U = C; C = D;
+    }
+    if (writer) {
+        const int ncx = a.W >> 3, n = ncx * (a.H >> 3);
+        const int slot = image % b.cam_mod;
+        const uint2* __restrict__ reach = b.reach + (size_t)slot * n;
+        const uint8_t* __restrict__ cflags = b.cflags + (size_t)slot * n;
+        uint32_t* __restrict__ rows = b.tile_rows + (size_t)image * b.n_chunks * b.n_strips * 4;
+        const int ci = cy * ncx + (x0 >> 3);
+        mark_hot_cell(b, reach, cflags, rows, ci, acc0);
+        mark_hot_cell(b, reach, cflags, rows, ci + 1, acc1);
+    }
+}
+
 __global__ __launch_bounds__(256) void bayer_gray_any_kernel(BayerArgs a)
 {
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
@@ -194,6 +296,17 @@ void launch_bayer_gray(const BayerArgs& a, hipStream_t s)
         hipLaunchKernelGGL(bayer_gray_kernel<2>, dim3((a.W + 62 * 8 - 1) / (62 * 8), (a.H + 3) / 4, a.n_images), dim3(64, 4), 0, s, a);
     else
         hipLaunchKernelGGL(bayer_gray_any_kernel, dim3((a.W + 63) / 64, (a.H + 3) / 4, a.n_images), dim3(64, 4), 0, s, a);
+}
+
+bool bayer_scan_fusable(const BayerArgs& a)
+{
+    return a.W % 16 == 0 && a.H % 8 == 0 && a.H >= 8 && a.spitch % 16 == 0 && a.dpitch % 16 == 0 && a.sstride % 16 == 0 &&
+           a.dstride % 16 == 0 && (uintptr_t)a.src % 16 == 0 && (uintptr_t)a.dst % 16 == 0;
+}
+
+void launch_bayer_gray_scan(const BayerArgs& a, const BrightArgs& b, hipStream_t s)
+{
+    hipLaunchKernelGGL(bayer_gray_scan_kernel, dim3((a.W + 62 * 16 - 1) / (62 * 16), (a.H / 8 + 3) / 4, a.n_images), dim3(64, 4), 0, s, a, b);
 }
 
 } // namespace mocap

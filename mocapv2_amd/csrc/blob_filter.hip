@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "kernels.h"
+#include "scan_mark.h"
 
 namespace mocap {
 
@@ -271,15 +272,6 @@ __device__ __forceinline__ uint32_t ldsr_combine(const LTaps& t, const LaneCols&
 // without running the filter.  The test is made per cell: no cell of the region with 2E above hot = allow / 4.
 // (A bound on the excess, not on the number of bright pixels: a background at 100 or the 3x3 halo a demosaiced hot
 // pixel leaves costs what it weighs, not 192 per pixel.)
-__device__ __forceinline__ uint32_t excess2_row(uint32_t lo, uint32_t hi)
-{ // sum over the 8 bytes of |p - 63| + p - 63 = 2 * max(0, p - 63); a zero byte adds nothing
-    uint32_t s = __builtin_amdgcn_sad_u8(lo, 0x3f3f3f3fu, 0u);
-    s = __builtin_amdgcn_sad_u8(lo, 0u, s);
-    s = __builtin_amdgcn_sad_u8(hi, 0x3f3f3f3fu, s);
-    s = __builtin_amdgcn_sad_u8(hi, 0u, s);
-    return s - 8u * 63u;
-}
-
 // One streaming pass over the frames -- the only time a dark tile's pixels are read.  A thread sums the excess over 63
 // of two cells of the fixed 8x8-pixel grid (16 eight-byte loads in flight; consecutive lanes take consecutive cells of
 // a cell row, so a wave's loads cover 512 contiguous bytes of each of 8 image rows; two v_sad_u8 per dword).  A cell
@@ -361,30 +353,7 @@ __global__ __launch_bounds__(256) void bright_cells_kernel(BrightArgs a)
                 if (8 * cr[u] + j < a.H) acc += e2;
             }
         }
-        if ((int)acc > a.hot_corner) { // rare: a few cells per marker
-            // reach = bounding box of the output pixels that read this cell (x0 | x1 << 16, y0 | y1 << 16; x0 > x1: none);
-            // flag bits: the cell feeds windows cut by the image border in one axis (1) / in both (2): fewer taps, smaller bound
-            const uint2 rc = reach[ci[u]];
-            const uint32_t fl = cflags[ci[u]];
-            const int x0 = (int)(rc.x & 0xffffu), x1 = (int)(rc.x >> 16), y0 = (int)(rc.y & 0xffffu), y1 = (int)(rc.y >> 16);
-            if (x0 <= x1 && (int)acc > ((fl & 2u) ? a.hot_corner : (fl & 1u) ? a.hot_edge : a.hot)) {
-                // a window with a set threshold bit is centred within 2 pixels of a pixel that reads a hot cell and spans 2
-                // more; the median adds 2 again: exact pixels are needed, and mask bits can be set, within 4 of the reach
-                const int xa = x0 - 4 > 0 ? x0 - 4 : 0, xb = x1 + 4 < a.W - 1 ? x1 + 4 : a.W - 1;
-                const int ya = y0 - 4 > 0 ? y0 - 4 : 0, yb = y1 + 4 < a.H - 1 ? y1 + 4 : a.H - 1;
-                // floor(v / d) = (v * ceil(2^23 / d)) >> 23 for v < 32768 and d >= 8: no integer division in this kernel
-                const int ch0 = (int)(((uint32_t)ya * a.rows_magic) >> 23), ch1 = (int)(((uint32_t)yb * a.rows_magic) >> 23);
-                const int st0 = (int)(((uint32_t)xa * 34953u) >> 23), st1 = (int)(((uint32_t)xb * 34953u) >> 23);
-                for (int ch = ch0; ch <= ch1; ch++)
-                    for (int st = st0; st <= st1; st++) {
-                        const int t = ch * a.n_strips + st;
-                        atomicMin(&rows[4 * t], (uint32_t)ya);
-                        atomicMax(&rows[4 * t + 1], (uint32_t)yb);
-                        atomicMin(&rows[4 * t + 2], (uint32_t)xa);
-                        atomicMax(&rows[4 * t + 3], (uint32_t)xb);
-                    }
-            }
-        }
+        mark_hot_cell(a, reach, cflags, rows, ci[u], acc);
     }
     if (a.mask_words) {
         // caller-owned masks: clear them on the side (16 bytes per thread and round), the filter kernel then only

@@ -124,6 +124,9 @@ struct BayerArgs {
     int shift;
 };
 void launch_bayer_gray(const BayerArgs& a, hipStream_t s);
+// the same pass fused with the early-out's scan of the gray frames it writes (bayer_scan_fusable: W % 16 == 0, H % 8 == 0, aligned)
+bool bayer_scan_fusable(const BayerArgs& a);
+void launch_bayer_gray_scan(const BayerArgs& a, const BrightArgs& b, hipStream_t s);
 
 // ---- geometry ----
 struct CameraTable {           // device-resident, written by mocap_set_cameras / mocap_set_fundamentals

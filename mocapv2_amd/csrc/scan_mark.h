@@ -1,0 +1,52 @@
+// scan_mark.h -- device helpers shared by the kernels that look at every frame byte (bright_cells_kernel in
+// blob_filter.hip, bayer_gray_scan_kernel in bayer_gray.hip): the excess sum of a cell row and what a hot cell does.
+// The bound behind them is derived in blob_filter.hip ("dark-tile early-out").
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kernels.h"
+
+namespace mocap {
+
+__device__ __forceinline__ uint32_t excess2_row(uint32_t lo, uint32_t hi)
+{ // sum over the 8 bytes of |p - 63| + p - 63 = 2 * max(0, p - 63); a zero byte adds nothing
+    uint32_t s = __builtin_amdgcn_sad_u8(lo, 0x3f3f3f3fu, 0u);
+    s = __builtin_amdgcn_sad_u8(lo, 0u, s);
+    s = __builtin_amdgcn_sad_u8(hi, 0x3f3f3f3fu, s);
+    s = __builtin_amdgcn_sad_u8(hi, 0u, s);
+    return s - 8u * 63u;
+}
+
+// A cell whose doubled excess sum `acc` exceeds its threshold widens, for every filter tile its reach (+ 4 pixels of blur
+// and median) overlaps, that tile's box of reachable mask rows and columns.  reach / cflags: the tables of the image's
+// undistort slot; rows: the image's tile boxes.
+__device__ __forceinline__ void mark_hot_cell(const BrightArgs& a, const uint2* __restrict__ reach, const uint8_t* __restrict__ cflags,
+                                              uint32_t* __restrict__ rows, int ci, uint32_t acc)
+{
+    if ((int)acc > a.hot_corner) { // rare: a few cells per marker
+        // reach = bounding box of the output pixels that read this cell (x0 | x1 << 16, y0 | y1 << 16; x0 > x1: none);
+        // flag bits: the cell feeds windows cut by the image border in one axis (1) / in both (2): fewer taps, smaller bound
+        const uint2 rc = reach[ci];
+        const uint32_t fl = cflags[ci];
+        const int x0 = (int)(rc.x & 0xffffu), x1 = (int)(rc.x >> 16), y0 = (int)(rc.y & 0xffffu), y1 = (int)(rc.y >> 16);
+        if (x0 <= x1 && (int)acc > ((fl & 2u) ? a.hot_corner : (fl & 1u) ? a.hot_edge : a.hot)) {
+            // a window with a set threshold bit is centred within 2 pixels of a pixel that reads a hot cell and spans 2
+            // more; the median adds 2 again: exact pixels are needed, and mask bits can be set, within 4 of the reach
+            const int xa = x0 - 4 > 0 ? x0 - 4 : 0, xb = x1 + 4 < a.W - 1 ? x1 + 4 : a.W - 1;
+            const int ya = y0 - 4 > 0 ? y0 - 4 : 0, yb = y1 + 4 < a.H - 1 ? y1 + 4 : a.H - 1;
+            // floor(v / d) = (v * ceil(2^23 / d)) >> 23 for v < 32768 and d >= 8: no integer division in this kernel
+            const int ch0 = (int)(((uint32_t)ya * a.rows_magic) >> 23), ch1 = (int)(((uint32_t)yb * a.rows_magic) >> 23);
+            const int st0 = (int)(((uint32_t)xa * 34953u) >> 23), st1 = (int)(((uint32_t)xb * 34953u) >> 23);
+            for (int ch = ch0; ch <= ch1; ch++)
+                for (int st = st0; st <= st1; st++) {
+                    const int t = ch * a.n_strips + st;
+                    atomicMin(&rows[4 * t], (uint32_t)ya);
+                    atomicMax(&rows[4 * t + 1], (uint32_t)yb);
+                    atomicMin(&rows[4 * t + 2], (uint32_t)xa);
+                    atomicMax(&rows[4 * t + 3], (uint32_t)xb);
+                }
+        }
+    }
+}
+
+} // namespace mocap

@@ -110,19 +110,30 @@ class MocapContext:
         stride = flat.stride(0) if n > 1 else pitch * self.height
         return flat, n, stride, pitch
 
-    def blob_centroids(self, frames, cam_mod=1, slot_base=0, max_blobs=MAX_BLOBS, records=None):
+    def blob_centroids(self, frames, cam_mod=1, slot_base=0, max_blobs=MAX_BLOBS, records=None, bayer_pattern=None,
+                       gray_shift=14, gray=None):
         """_find_dot over uint8 frames [..., H, W] resident on the GPU (image n uses undistort slot
         slot_base + n % cam_mod).  Results land in centroid records, int32 [n, 2 + 2*max_blobs]:
         record[0] = number of image points, record[2:] = (cx, cy) pairs in the reference's contour order.
-        Returns the records tensor (use record_views for xy / count views)."""
+        Returns the records tensor (use record_views for xy / count views).
+        bayer_pattern 0..3 (BG, GB, RG, GR): the frames are raw sensor frames; the camera loop's cvtColor pair
+        (RealtimeTracking_FLIR.py:103-104) runs first, into `gray` (same shape as frames; allocated when None)."""
         flat, n, stride, pitch = self._frames(frames)
         rec_ints = 2 + 2 * max_blobs
         if records is None:
             records = torch.empty((n, rec_ints), dtype=torch.int32, device=self.device)
         assert records.is_contiguous() and records.shape == (n, rec_ints) and records.dtype == torch.int32
         xy_ptr = C.c_void_p(records.data_ptr() + 8)
-        _abi.check(self.lib.mocap_blob_centroids(self._h, _ptr(flat), n, cam_mod, slot_base, stride, pitch, xy_ptr, rec_ints,
-                                                 _ptr(records), rec_ints, max_blobs, _stream()))
+        if bayer_pattern is None:
+            _abi.check(self.lib.mocap_blob_centroids(self._h, _ptr(flat), n, cam_mod, slot_base, stride, pitch, xy_ptr, rec_ints,
+                                                     _ptr(records), rec_ints, max_blobs, _stream()))
+            return records
+        if gray is None:
+            gray = torch.empty_strided(flat.shape, flat.stride(), dtype=torch.uint8, device=self.device)
+        assert gray.dtype == torch.uint8 and gray.is_cuda and gray.reshape(flat.shape).stride() == flat.stride()
+        _abi.check(self.lib.mocap_blob_centroids_bayer(self._h, _ptr(flat), _ptr(gray), n, cam_mod, slot_base, stride, pitch,
+                                                       bayer_pattern, gray_shift, xy_ptr, rec_ints, _ptr(records), rec_ints,
+                                                       max_blobs, _stream()))
         return records
 
     @staticmethod

@@ -127,17 +127,28 @@ class BatchTracker:
         return [(c, t) for c, t0, t1 in self.segs for t in range(t0, t1)]
 
     def extract(self, frames):
-        """Stage A on this rank's block.  frames: uint8 [per, H, W] on the GPU, ordered as local_image_list().
+        """Stage A on this rank's block.  frames: uint8 [per, H, W] on the GPU, ordered as local_image_list(); raw Bayer
+        frames when the tracker was built with `bayer_pattern` (their gray version goes to the batch's own buffer).
         Fills and returns self.records ([per, REC] int32, one centroid record per image)."""
         ctx = self.ctx
+        kw = {}
+        if self.bayer_pattern is not None:
+            lane = self._cur
+            if lane.gray is None or lane.gray.shape != frames.shape:
+                lane.gray = torch.empty(frames.shape, dtype=torch.uint8, device=ctx.device)
+            kw = {"bayer_pattern": self.bayer_pattern, "gray_shift": self.gray_shift}
         if self.world == 1:
-            ctx.blob_centroids(frames, cam_mod=self.n_cam, max_blobs=self.max_points, records=self.records)
+            if kw:
+                kw["gray"] = self._cur.gray
+            ctx.blob_centroids(frames, cam_mod=self.n_cam, max_blobs=self.max_points, records=self.records, **kw)
             return self.records
         o = 0
         for c, t0, t1 in self.segs:
             n = t1 - t0
+            if kw:
+                kw["gray"] = self._cur.gray[o:o + n]
             ctx.blob_centroids(frames[o:o + n], cam_mod=1, slot_base=self.slot_of[c], max_blobs=self.max_points,
-                               records=self.records[o:o + n])
+                               records=self.records[o:o + n], **kw)
             o += n
         return self.records
 
@@ -178,11 +189,6 @@ class BatchTracker:
         return lane.staging
 
     def _run(self, frames):
-        if self.bayer_pattern is not None:
-            lane = self._cur
-            if lane.gray is None or lane.gray.shape != frames.shape:
-                lane.gray = torch.empty(frames.shape, dtype=torch.uint8, device=lane.ctx.device)
-            frames = lane.ctx.bayer_gray(frames, self.bayer_pattern, self.gray_shift, out=lane.gray)
         records = self.extract(frames)
         gathered = allgather_records(records, self.world, self.group)  # [C * T_total, REC] camera-major when world > 1
         return self.triangulate(gathered)

@@ -459,3 +459,39 @@ def test_replay_from_raw_bayer_frames():
         assert np.array_equal(x["object_points"], y["object_points"]) and np.array_equal(x["image_points"], y["image_points"])
         assert x["message"] == y["message"]
     assert sum(len(x["object_points"]) > 0 for x in a) >= T - 1
+
+
+@pytest.mark.parametrize("W,H", [(640, 360), (1920, 1080), (648, 364), (96, 64)])
+@pytest.mark.parametrize("scale", [0.0, 1.0])
+def test_blob_centroids_from_bayer_equals_the_two_steps(torch_cuda, monkeypatch, W, H, scale):
+    """mocap_blob_centroids_bayer (gray conversion fused with the early-out's scan where width % 16 == 0 and
+    height % 8 == 0, separate kernels otherwise) = mocap_bayer_gray_u8 followed by mocap_blob_centroids, and the gray
+    frames it leaves behind are the oracle's; two batches on one context, then once more with the early-out off."""
+    torch = torch_cuda
+    from mocapv2_amd.engine import MocapContext
+    rng = np.random.default_rng(W + H + int(scale))
+    dist = np.array(MILD_DIST) * scale
+    sc = Scene(2, width=W, height=H, dist=dist)
+    n_discs = 4 if W >= 640 else 1
+    for skip in ("1", "0"):
+        monkeypatch.setenv("MOCAP_SKIP_DARK", skip)
+        ctx = MocapContext(W, H, n_slots=2)
+        ref = MocapContext(W, H, n_slots=2)
+        for sl in range(2):
+            ctx.set_undistort(sl, sc.K, sc.dist)
+            ref.set_undistort(sl, sc.K, sc.dist)
+        ctx.set_blob_params(min_area=60.0)
+        ref.set_blob_params(min_area=60.0)
+        for b in range(2):
+            raw = dark_frames(rng, 4, H, W, n_discs=n_discs, salt=0.002, noise_max=60)
+            raw[:, 0::2, 1::2] = (raw[:, 0::2, 1::2] * 0.9).astype(np.uint8)   # the colour sites respond differently
+            d = torch.from_numpy(raw).cuda()
+            gray = torch.zeros_like(d)
+            rec = ctx.blob_centroids(d, cam_mod=2, bayer_pattern=3, gray=gray).cpu().numpy()
+            two = ref.blob_centroids(ref.bayer_gray(d, 3, 14), cam_mod=2).cpu().numpy()
+            g = gray.cpu().numpy()
+            for i in range(4):
+                assert np.array_equal(g[i], oracle.bayer_gray(raw[i], 3, 14)), (skip, b, i)
+                n = rec[i, 0]
+                assert n == two[i, 0] and n >= 0 and np.array_equal(rec[i, 2:2 + 2 * n], two[i, 2:2 + 2 * n]), (skip, b, i)
+            assert rec[:, 0].sum() >= (4 if W >= 640 else 0)
