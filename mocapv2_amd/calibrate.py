@@ -14,6 +14,7 @@ What is batched that the reference loops over:
 Image capture, `cv.findFundamentalMat` (RANSAC) and the plotting / JSON writing of that script are outside the path;
 fundamental matrices come in as arguments.
 """
+import json
 from itertools import combinations
 
 import numpy as np
@@ -270,6 +271,61 @@ def set_floor(camera_poses, points_3d):
     return Rf
 
 
+# ---- stage files: the JSON artefacts the reference's stages hand to each other ----------------------
+def get_points(path="./jsons/image_points.json"):
+    """reference `get_points` (:80-89): jsons/image_points.json holds [point][camera][2]; returned as
+    [camera][point][2]."""
+    with open(path) as file:
+        image_points = json.load(file)
+    return np.transpose(np.array(image_points), (1, 0, 2))
+
+
+def save_extrinsics(camera_poses, prefix="", directory="./jsons", camera_count=None):
+    """reference `save_extrinsics` (:257-273) without its module globals: writes `{directory}/{prefix}extrinsics.json`
+    = [{"R": 3x3 list, "t": flat list of 3}, ...], the layout `lib.Helpers.get_extrinsics` reads back (:282-291).
+    Returns the file name."""
+    n = len(camera_poses) if camera_count is None else camera_count
+    extrinsics = []
+    for i in range(0, n):
+        extrinsics.append({"R": np.asarray(camera_poses[i]["R"]).tolist(),
+                           "t": np.asarray(camera_poses[i]["t"]).flatten().tolist()})
+    extrinsics_filename = f"{directory}/{prefix}extrinsics.json"
+    with open(extrinsics_filename, "w") as outfile:
+        json.dump(extrinsics, outfile)
+    print("Extrinsics saved to", extrinsics_filename)
+    return extrinsics_filename
+
+
+def save_objects(prefix="", object_points=None, directory="./jsons"):
+    """reference `save_objects` (:275-281): `{directory}/{prefix}objects.json` = [[x, y, z], ...]."""
+    objects_filename = f"{directory}/{prefix}objects.json"
+    with open(objects_filename, "w") as outfile:
+        json.dump(np.asarray(object_points).tolist(), outfile)
+    print("Object points saved to", objects_filename)
+    return objects_filename
+
+
+def save_fundamentals(pair_Fs, directory="./jsons"):
+    """The fundamentals.json dump of reference `calculate_extrinsics` (:189-191,236-240): every camera pair's F is
+    appended TWICE (`Fs.append(F.tolist())` twice), so that `lib.Helpers.Fs[i - 1]` of a two-camera rig finds its
+    matrix at index 0 and a copy at index 1.  pair_Fs: one 3x3 matrix per consecutive camera pair."""
+    Fs = []
+    for F in pair_Fs:
+        Fs.append(np.asarray(F, float).tolist())
+        Fs.append(np.asarray(F, float).tolist())
+    filename = f"{directory}/fundamentals.json"
+    with open(filename, "w") as outfile:
+        json.dump(Fs, outfile)
+    return filename
+
+
+def pair_fundamentals(Fs):
+    """Inverse of `save_fundamentals`' doubling: the one-per-pair list `extrinsics_from_fundamentals` expects from
+    the list a fundamentals.json written by the reference holds (entries 0, 2, 4, ...)."""
+    return [np.asarray(F, float) for F in Fs[::2]]
+
+
 __all__ = ["poses_to_fundamental_matrix", "decompose_essential", "select_relative_pose", "extrinsics_from_fundamentals",
            "residuals_batched", "forward_difference_steps", "residual_and_jacobian", "bundle_adjustment", "set_origin",
-           "calculate_normal", "rotation_matrix_from_vectors", "set_floor"]
+           "calculate_normal", "rotation_matrix_from_vectors", "set_floor", "get_points", "save_extrinsics", "save_objects",
+           "save_fundamentals", "pair_fundamentals"]
