@@ -1,21 +1,31 @@
 #!/usr/bin/env python3
 """Throughput of the MocapV2 per-frame hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dist mild|zero]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--cameras C] [--markers M] [--frame WxH] [--dist mild|zero]
 
-Workload (BASELINE.json configs[1]): 6 cameras x 1920x1080 synthetic IR frames, 8 markers.  One "step" = one pass
-of the whole hot path (undistort -> box blur -> threshold -> median -> contours -> centroids -> epipolar
-correspondence -> DLT triangulation) over one batch of T = 512 time steps (3072 camera images, 6.4 GB) that is
-resident in HBM before the timed region starts.  A "frame" = one time step of all 6 cameras.  With N ranks every
-rank processes its own 3072 images (weak scaling; camera-major sharding + one all-gather, mocapv2_amd/pipeline.py).
+Default workload (BASELINE.json configs[1]): 6 cameras x 1920x1080 synthetic IR frames, 8 markers.  One "step" = one
+pass of the whole hot path (undistort -> box blur -> threshold -> median -> contours -> centroids -> epipolar
+correspondence -> DLT triangulation) over one batch of T time steps (T x C camera images, 6.4 GB by default) that is
+resident in HBM before the timed region starts.  A "frame" = one time step of all C cameras.  With N ranks every rank
+processes its own T x C images (weak scaling; camera-major sharding + ONE all-gather of centroid records per batch,
+mocapv2_amd/pipeline.py).  Other BASELINE.json configs:
+    configs[2]   --markers 32
+    configs[3]   --gpus 8 --cameras 8                       (one camera per GPU, all-gather of centroids over xGMI)
+    configs[4]   --gpus 8 --cameras 16 --frame 3840x2160 --markers 64   (two 4K cameras per GPU; + BA residual evaluation)
+`--gpus N` without a torchrun environment launches the N ranks itself (python -m torch.distributed.run, before this
+process touches a GPU); `--rehearse-on-one-gpu` lets the N ranks share cuda:0 and exchange through gloo (a check of the
+multi-rank code path on a one-GPU box, not a measurement).
 
-Three batches are in flight on three HIP streams (--depth).  Prints ONE JSON line (rank 0) with the driver's fields
-plus `roofline` (the filter stage = streaming scan + patches + filter kernels against the HBM read roofline, from HIP
-events recorded on the launch streams) and `cpu_baseline` (the C oracle on host cores).
+Three batches are in flight on three HIP streams (--depth).  Prints ONE JSON line (rank 0) with the driver's fields plus
+`roofline` (the filter stage against the HBM read roofline, from HIP events recorded on the launch streams),
+`cpu_baseline` (the C oracle on host cores), `parity` (3-D RMSE / centroid mismatches of the timed batch against that
+oracle) and, with one GPU, `extra` sections (32 markers, bright background, 4K) measured the same way.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,65 +34,19 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-N_CAM, WIDTH, HEIGHT, N_MARKERS, T_STEPS = 6, 1920, 1080, 8, 512
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+DEFAULT_BATCH_BYTES = 3072 * 1920 * 1080  # images x bytes of the default batch per GPU
 
 
-def render_local(scene, image_list, seed_base=1000):
-    """uint8 [n, H, W] frames for (camera, global time step) pairs; time step t uses seed seed_base + t."""
-    out = np.empty((len(image_list), scene.height, scene.width), np.uint8)
-    cache = {}
-    for i, (c, t) in enumerate(image_list):
-        if t not in cache:
-            rng = np.random.default_rng(seed_base + t)
-            cache = {t: scene.markers(rng, N_MARKERS)}
-        rng = np.random.default_rng((seed_base + t) * 64 + c)
-        out[i] = scene.render(rng, cache[t], c, radius_range=(16.0, 22.0), salt=0.001)
-    return out
-
-
-def cpu_baseline(scene, arrays, frames, n_steps, bayer=False):
-    """The oracle (scalar C port of the reference's CPU path) on `n_steps` time steps of the benchmark batch
-    (frames uint8 [T, C, H, W], reused cyclically): thread-per-camera blob extraction as the reference does
-    (RealtimeTracking_FLIR.py:307-312), then correspondence + DLT."""
-    import ctypes
-    from concurrent.futures import ThreadPoolExecutor
-
-    import oracle
-    K, dist, R, t, F = arrays
-    prm = oracle.default_params(undistort=True, filter_order=2)
-    oracle.lib()
-    T = frames.shape[0]
-    pool = ThreadPoolExecutor(N_CAM)
-    t0 = time.perf_counter()
-    n_pts = 0
-    for i in range(n_steps):
-        s = i % T
-        gray = (lambda im: oracle.bayer_gray(im, 3, 14)) if bayer else (lambda im: im)
-        lists = list(pool.map(lambda c: oracle.find_dot(gray(frames[s, c]), K[c], dist[c], params=prm), range(N_CAM)))
-        P = max(1, max(len(l) for l in lists))
-        pts = np.zeros((N_CAM, P, 2))
-        cnt = np.zeros(N_CAM, np.int32)
-        for c, l in enumerate(lists):
-            cnt[c] = len(l)
-            if l:
-                pts[c, :len(l)] = l
-        res = oracle.correspond(pts, cnt, K, dist, R, t, F)
-        n_pts += len(res["root"])
-    dt = time.perf_counter() - t0
-    pool.shutdown()
-    return n_steps / dt, dt, n_pts, (lists, res)
-
-
-def main():
-    global T_STEPS, N_MARKERS, WIDTH, HEIGHT
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dist", choices=["mild", "zero"], default="mild")
-    ap.add_argument("--time-steps", type=int, default=T_STEPS,
-                    help="time steps per batch and GPU (one step = one pass over time_steps x 6 resident images)")
+    ap.add_argument("--cameras", type=int, default=6, help="cameras of the rig: 6 = configs[1]/[2], 8 = configs[3], 16 = configs[4]")
+    ap.add_argument("--time-steps", type=int, default=0,
+                    help="time steps per batch and GPU (default: as many as make the batch 6.4 GB, 512 for 6 x 1080p)")
     ap.add_argument("--depth", type=int, default=3,
                     help="batches in flight (software pipelining of consecutive batches on separate HIP streams; 1 = off)")
     ap.add_argument("--from-host", action="store_true",
@@ -90,34 +54,227 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 ranks share cuda:0 and exchange through gloo (checks the multi-rank code path on a one-GPU box; "
                          "not a measurement)")
-    ap.add_argument("--markers", type=int, default=N_MARKERS,
-                    help="markers per frame: 8 = BASELINE.json configs[1] (the headline), 32 = configs[2] (a secondary measurement)")
-    ap.add_argument("--frame", default=f"{WIDTH}x{HEIGHT}",
-                    help="frame size WxH: 1920x1080 = the headline workload; 3840x2160 = the frame size of BASELINE.json configs[4] "
-                         "(a secondary measurement; lower --time-steps accordingly)")
+    ap.add_argument("--collective", choices=["auto", "rccl", "torch"], default="auto",
+                    help="exchange of centroid records: rccl = mocap_allgather_centroids (ncclAllGather behind the C-ABI), "
+                         "torch = torch.distributed; auto = rccl on GPUs")
+    ap.add_argument("--markers", type=int, default=8,
+                    help="markers per frame: 8 = BASELINE.json configs[1] (the headline), 32 = configs[2], 64 = configs[4]")
+    ap.add_argument("--frame", default="1920x1080", help="frame size WxH: 1920x1080 = the headline; 3840x2160 = configs[4]")
+    ap.add_argument("--background", default="0-60",
+                    help="uniform background noise range lo-hi of the synthetic frames (0-60 = the headline scene)")
     ap.add_argument("--bayer", action="store_true",
                     help="secondary measurement: the resident frames are raw Bayer GR sensor frames and every step starts with the "
                          "Bayer -> gray pre-pass (RealtimeTracking_FLIR.py:103-104); not the headline workload")
-    ap.add_argument("--cpu-steps", type=int, default=256, help="time steps in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=256, help="time steps in the CPU baseline / parity sample (0 = skip)")
     ap.add_argument("--no-secondary", dest="secondary", action="store_false",
-                    help="skip the second timed run with the other distortion variant")
-    args = ap.parse_args()
-    T_STEPS = args.time_steps
-    N_MARKERS = args.markers
-    WIDTH, HEIGHT = (int(v) for v in args.frame.lower().split("x"))
-    max_points = 32 if N_MARKERS <= 16 else 2 * N_MARKERS  # centroid record capacity per image
+                    help="skip the early-out-off rerun and the other distortion variant")
+    ap.add_argument("--no-extra", dest="extra", action="store_false", help="skip the extra workload sections")
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as children of a launcher process.  Nothing in this
+    process has touched a GPU yet (device_count() does not initialise HIP on this image)."""
+    import torch
+    n_dev = torch.cuda.device_count()
+    extra = []
+    if n_dev < args.gpus and not args.rehearse_on_one_gpu:
+        raise SystemExit(f"--gpus {args.gpus}: only {n_dev} GPU(s) visible (add --rehearse-on-one-gpu to run the ranks on one GPU "
+                         "through gloo: a functional check, not a measurement)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:] + extra
+    return subprocess.run(cmd, env=env).returncode
+
+
+class Workload:
+    """Scene + frame recipe of one measured configuration."""
+
+    def __init__(self, cameras, width, height, markers, dist_name, background=(0, 60), bayer=False):
+        self.cameras, self.width, self.height, self.markers = cameras, width, height, markers
+        self.dist_name, self.background, self.bayer = dist_name, tuple(background), bayer
+        self.max_points = 32 if markers <= 16 else 2 * markers  # centroid record capacity per image
+
+    def default_time_steps(self):
+        t = DEFAULT_BATCH_BYTES // (self.cameras * self.width * self.height)
+        return max(8, (t // 8) * 8)
+
+    def name(self, world):
+        std = self.dist_name == "mild" and self.background == (0, 60) and not self.bayer
+        c, w, h, m = self.cameras, self.width, self.height, self.markers
+        if std and (c, w, h, m) == (6, 1920, 1080, 8):
+            return "6-camera 1920x1080 synthetic IR frames, 8 markers (BASELINE.json configs[1])"
+        if std and (c, w, h, m) == (6, 1920, 1080, 32):
+            return "6-camera 1080p, 32 markers, epipolar correspondence + batched DLT (BASELINE.json configs[2])"
+        if std and (c, w, h) == (8, 1920, 1080) and world == 8:
+            return f"8-camera 1080p sharded 1 cam/GPU over 8 GPUs, all-gather of centroids, {m} markers (BASELINE.json configs[3])"
+        if std and (c, w, h, m) == (16, 3840, 2160, 64) and world == 8:
+            return "16-camera 4K synthetic, 64 markers, 2 cameras/GPU over 8 GPUs (BASELINE.json configs[4])"
+        s = f"{c}-camera {w}x{h} synthetic IR frames, {m} markers"
+        if self.background != (0, 60):
+            s += f", background {self.background[0]}-{self.background[1]}"
+        return s
+
+    def scene(self):
+        from mocapv2_amd.synth import MILD_DIST, ZERO_DIST, Scene
+        return Scene(self.cameras, self.width, self.height, dist=MILD_DIST if self.dist_name == "mild" else ZERO_DIST)
+
+    def render(self, scene, image_list, seed_base=1000):
+        """uint8 [n, H, W] frames for (camera, global time step) pairs; time step t uses seed seed_base + t."""
+        out = np.empty((len(image_list), scene.height, scene.width), np.uint8)
+        cache = {}
+        for i, (c, t) in enumerate(image_list):
+            if t not in cache:
+                rng = np.random.default_rng(seed_base + t)
+                cache = {t: scene.markers(rng, self.markers)}
+            rng = np.random.default_rng((seed_base + t) * 64 + c)
+            out[i] = scene.render(rng, cache[t], c, radius_range=(16.0, 22.0), noise_min=self.background[0],
+                                  noise_max=self.background[1], salt=0.001)
+        return out
+
+
+def cpu_baseline(wl, arrays, frames, n_steps):
+    """The oracle (scalar C port of the reference's CPU path) on `n_steps` time steps of the benchmark batch
+    (frames uint8 [T, C, H, W], reused cyclically): thread-per-camera blob extraction as the reference does
+    (RealtimeTracking_FLIR.py:307-312), then correspondence + DLT.  Returns the rate and every time step's results
+    (image-point lists per camera, correspondence output) for the parity comparison."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    import oracle
+    K, dist, R, t, F = arrays
+    C = wl.cameras
+    prm = oracle.default_params(undistort=True, filter_order=2)
+    oracle.lib()
+    T = frames.shape[0]
+    pool = ThreadPoolExecutor(C)
+    gray = (lambda im: oracle.bayer_gray(im, 3, 14)) if wl.bayer else (lambda im: im)
+    results = []
+    t0 = time.perf_counter()
+    for i in range(n_steps):
+        s = i % T
+        lists = list(pool.map(lambda c: oracle.find_dot(gray(frames[s, c]), K[c], dist[c], params=prm), range(C)))
+        P = max(1, max(len(l) for l in lists))
+        pts = np.zeros((C, P, 2))
+        cnt = np.zeros(C, np.int32)
+        for c, l in enumerate(lists):
+            cnt[c] = len(l)
+            if l:
+                pts[c, :len(l)] = l
+        res = oracle.correspond(pts, cnt, K, dist, R, t, F)
+        results.append((s, lists, res))
+    dt = time.perf_counter() - t0
+    pool.shutdown()
+    return n_steps / dt, dt, results
+
+
+def parity_report(results, records, out, n_cam, max_points):
+    """The timed GPU batch against the oracle on every time step of the CPU sample: image points per camera (bit-exact
+    bar) and 3-D points (1e-7 world units = 1e-4 mm bar).  records [T*C, rec] host, out: host arrays."""
+    mism_images = mism_roots = n_points = 0
+    sq = 0.0
+    max_abs = 0.0
+    for s, lists, ref in results:
+        for c in range(n_cam):
+            rec = records[s * n_cam + c]
+            n = int(rec[0])
+            got = rec[2:2 + 2 * max(0, min(n, max_points))].reshape(-1, 2).tolist()
+            if n != len(lists[c]) or got != [list(p) for p in lists[c]]:
+                mism_images += 1
+        k = int(out["n"][s])
+        if k != len(ref["root"]) or (k and not np.array_equal(out["grp"][s, :k], ref["groups"])):
+            mism_roots += 1
+            continue
+        if k:
+            d = out["xyz"][s, :k] - ref["xyz"]
+            sq += float((d * d).sum())
+            max_abs = max(max_abs, float(np.abs(d).max()))
+            n_points += k
+    rmse = (sq / max(1, n_points)) ** 0.5
+    return {"time_steps_compared": len(results), "points_compared": n_points,
+            "centroid_mismatches": mism_images, "correspondence_mismatches": mism_roots,
+            "rmse_3d_vs_oracle": rmse, "max_abs_3d": max_abs, "unit": "world units (m)",
+            "rmse_3d_mm": rmse * 1e3, "tolerance_mm": 1e-4,
+            "ok": bool(mism_images == 0 and mism_roots == 0 and max_abs < 1e-7),
+            "oracle": "oracle/ C restatement (geometry half pinned to the reference, blob half parity unpinned: DESIGN.md 2)"}
+
+
+KERNELS = (("scan", "bright_cells_kernel"), ("patch", "undistort_patches_kernel"), ("filter", "filter_mask_kernel"))
+
+
+def roofline_of(prof, wl, n_images, n_launch_groups, traffic_key):
+    """Roofline entries of the filter stage; the streaming scan (the kernel that reads every frame byte) leads.
+    Durations are HIP-event averages recorded by the library on the launch stream: `avg_launch_ms` from the sequential
+    pass (one batch at a time), `avg_launch_ms_in_timed_region` from the timed region itself, where `--depth` batches
+    are in flight and a kernel shares the chip with its neighbours' kernels."""
+    per_launch = n_images / n_launch_groups
+    bytes_img = wl.width * wl.height
+    traffic, source = {}, None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if traffic_key and os.path.exists(tpath):  # HBM bytes per launch from the builder's PMC passes (profiles/README.md)
+        with open(tpath) as f:
+            tj = json.load(f)
+        if tj.get("workload_key") == traffic_key and tj.get("images_per_launch") == per_launch:
+            traffic = tj.get("hbm_bytes_per_launch", {})
+            source = "profiles/hbm_traffic.json (builder's rocprofv3 PMC passes on this workload; not re-measured in this run)"
+    ent = {}
+    for key, name in KERNELS:
+        n = prof[key + "_launches"]
+        if n == 0:
+            continue
+        ms = prof[key + "_ms"] / n
+        ent[name] = {"kernel": name, "avg_launch_ms": round(ms, 4), "traffic": traffic.get(name)}
+        if key == "scan" or len([k for k, _ in KERNELS if prof[k + "_launches"]]) == 1:
+            ach = bytes_img * per_launch / (ms * 1e-3) / 1e9
+            ent[name].update({"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(ach / HBM_PEAK_GBS, 4)})
+        tr = prof.get("timed_region")
+        if tr and tr[key + "_launches"]:
+            ent[name]["avg_launch_ms_in_timed_region"] = round(tr[key + "_ms"] / tr[key + "_launches"], 4)
+    stage_ms = sum(e["avg_launch_ms"] for e in ent.values())
+    ach = bytes_img * per_launch / (stage_ms * 1e-3) / 1e9
+    tr_known = [traffic.get(k) for k in ent]
+    roof = {"bound": "hbm", "kernel": " + ".join(ent), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4),
+            "traffic": sum(tr_known) if tr_known and all(t is not None for t in tr_known) else None,
+            "traffic_source": source,
+            "avg_launch_ms": round(stage_ms, 4), "images_per_launch": per_launch, "algorithmic_bytes_per_image": bytes_img,
+            "per_kernel": ent,
+            "note": "algorithmic traffic = one read of the frames (SURVEY.md 8d); the scan kernel moves those bytes (priced alone "
+                    "in per_kernel), the other kernels touch the marked tiles only"}
+    if prof["contour_launches"]:
+        # frame -> centroid: the filter stage plus the contour kernel (north_star's 'blob-centroid kernel' as a whole)
+        cms = prof["contour_ms"] / prof["contour_launches"]
+        b2c = bytes_img * per_launch / ((stage_ms + cms) * 1e-3) / 1e9
+        roof["blob_to_centroid"] = {"kernel": roof["kernel"] + " + contours_kernel", "avg_launch_ms": round(stage_ms + cms, 4),
+                                    "achieved": round(b2c, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b2c / HBM_PEAK_GBS, 4)}
+    return roof
+
+
+def kernel_ms(prof):
+    n = prof["steps"]
+    return {"scan": round(prof["scan_ms"] / n, 4), "patches": round(prof["patch_ms"] / n, 4), "filter": round(prof["filter_ms"] / n, 4),
+            "contours": round(prof["contour_ms"] / n, 4), "correspond": round(prof["corr_ms"] / n, 4)}
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     import torch
     import torch.distributed as dist
-    from mocapv2_amd.pipeline import BatchTracker, scene_arrays
-    from mocapv2_amd.synth import MILD_DIST, ZERO_DIST, Scene
+    from mocapv2_amd.pipeline import BatchTracker, check_status, scene_arrays
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with python -m torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.rehearse_on_one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -127,30 +284,33 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    W, H = (int(v) for v in args.frame.lower().split("x"))
+    bg = tuple(int(v) for v in args.background.split("-"))
+    main_wl = Workload(args.cameras, W, H, args.markers, args.dist, bg, args.bayer)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(tracker, frames):
+    def timed(tracker, frames, steps, warmup):
         """W untimed + K timed steps of the resident batch, barrier + synchronize on both sides, max over ranks.
         Then a short sequential pass (one batch at a time, a synchronize after each) for per-kernel durations that are
         not stretched by the neighbouring batches' kernels (in the timed region `--depth` batches share the chip)."""
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             tracker.step(frames)
         tracker.synchronize()
         barrier()
         tracker.profile(True)
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             out = tracker.step(frames)
         tracker.synchronize()
         barrier()
         elapsed = time.perf_counter() - t0
         tracker.profile(False)
         prof_timed = tracker.profile_read()
-        n_seq = max(1, min(args.steps, 6))
+        n_seq = max(1, min(steps, 6))
         tracker.profile(True)
         for _ in range(n_seq):
             out = tracker.step(frames)
@@ -166,141 +326,126 @@ def main():
             elapsed = float(tmax.item())
         return out, elapsed, prof
 
-    def measure(dist_name):
-        """Build the scene / tracker / resident batch for one distortion variant and time K steps of it."""
-        scene = Scene(N_CAM, WIDTH, HEIGHT, dist=MILD_DIST if dist_name == "mild" else ZERO_DIST)
+    def measure(wl, time_steps, steps, warmup):
+        """Build the scene / tracker / resident batch of one workload and time `steps` steps of it."""
+        scene = wl.scene()
         arrays = scene_arrays(scene)
-        tracker = BatchTracker(*arrays, WIDTH, HEIGHT, T_STEPS, world=world, rank=rank, device=local_rank, depth=args.depth,
-                               max_points=max_points, bayer_pattern=3 if args.bayer else None)
+        tracker = BatchTracker(*arrays, wl.width, wl.height, time_steps, world=world, rank=rank, device=local_rank, depth=args.depth,
+                               max_points=wl.max_points, bayer_pattern=3 if wl.bayer else None, collective=args.collective)
         images = tracker.local_image_list()
-        frames_host = render_local(scene, images)
+        frames_host = wl.render(scene, images)
         frames = torch.from_numpy(frames_host).pin_memory() if args.from_host else torch.from_numpy(frames_host).cuda()
         torch.cuda.synchronize()
-        out, elapsed, prof = timed(tracker, frames)
-        return scene, arrays, tracker, images, frames_host, out, elapsed, prof, frames
+        out, elapsed, prof = timed(tracker, frames, steps, warmup)
+        return {"scene": scene, "arrays": arrays, "tracker": tracker, "images": images, "frames_host": frames_host, "frames": frames,
+                "out": out, "elapsed": elapsed, "prof": prof, "T": time_steps}
 
-    scene, arrays, tracker, images, frames_host, out, elapsed, prof, frames = measure(args.dist)
+    def status_of(m):
+        n_roots = m["out"]["n"].cpu().numpy()
+        try:
+            check_status(n_roots)
+            ok = bool((m["tracker"].records[:, 0].cpu().numpy() >= 0).all())
+        except RuntimeError:
+            ok = False
+        return ok, n_roots
 
-    n_roots = out["n"].cpu().numpy()
-    status_ok = bool((n_roots >= 0).all()) and bool((tracker.records[:, 0] >= 0).all().item())
+    def section(wl, m, steps):
+        ok, n_roots = status_of(m)
+        el, prof, T = m["elapsed"], m["prof"], m["T"]
+        return {"workload": wl.name(world), "value": round(T * world * steps / el, 2), "unit": "frames/s", "ms_per_step": round(1e3 * el / steps, 4),
+                "time_steps_per_step": T, "steps": steps, "images_per_step": len(m["images"]),
+                "roofline": roofline_of(prof, wl, len(m["images"]), 1 if world == 1 else len(m["tracker"].segs), None),
+                "kernel_ms_per_step": kernel_ms(prof), "status_ok": ok, "points_per_frame": float(np.maximum(n_roots, 0).mean()),
+                "dark_tile_early_out": {"tiles_per_step": prof["tiles"], "tiles_resolved_without_filtering": prof["tiles_skipped"]}}
+
+    T_STEPS = args.time_steps or main_wl.default_time_steps()
+    m = measure(main_wl, T_STEPS, args.steps, args.warmup)
+    tracker, out, elapsed, prof = m["tracker"], m["out"], m["elapsed"], m["prof"]
+    status_ok, n_roots = status_of(m)
 
     if rank == 0:
-        frames_per_step = T_STEPS * world
-        value = frames_per_step * args.steps / elapsed
-        KERNELS = (("scan", "bright_cells_kernel"), ("patch", "undistort_patches_kernel"), ("filter", "filter_mask_kernel"))
-
-        def roofline_of(prof, n_images, n_launch_groups, dist_name):
-            """Roofline entries of the two HBM-bound kernels of the filter stage; the one with the longer launches leads.
-            Durations are HIP-event averages recorded by the library on the launch stream: `avg_launch_ms` from the
-            sequential pass (one batch at a time), `avg_launch_ms_in_timed_region` from the timed region itself, where
-            `--depth` batches are in flight and a kernel shares the chip with its neighbours' kernels."""
-            per_launch = n_images / n_launch_groups
-            traffic = {}
-            tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-            if os.path.exists(tpath):  # HBM bytes per launch from the PMC passes (profiles/README.md), same workload
-                with open(tpath) as f:
-                    tj = json.load(f)
-                if tj.get("dist") == dist_name and tj.get("images_per_launch") == per_launch and tj.get("markers", 8) == N_MARKERS \
-                        and (WIDTH, HEIGHT) == (1920, 1080) and not args.bayer:
-                    traffic = tj.get("hbm_bytes_per_launch", {})
-            ent = {}
-            for key, name in KERNELS:
-                n = prof[key + "_launches"]
-                if n == 0:
-                    continue
-                ms = prof[key + "_ms"] / n
-                ach = WIDTH * HEIGHT * per_launch / (ms * 1e-3) / 1e9
-                ent[name] = {"kernel": name, "avg_launch_ms": round(ms, 4), "traffic": traffic.get(name)}
-                if key == "scan" or len([k for k, _ in KERNELS if prof[k + "_launches"]]) == 1:
-                    # the kernel that reads every frame byte: priced alone against the same algorithmic traffic
-                    ent[name].update({"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                      "frac": round(ach / HBM_PEAK_GBS, 4), "images_per_launch": per_launch,
-                                      "algorithmic_bytes_per_image": WIDTH * HEIGHT})
-                tr = prof.get("timed_region")
-                if tr and tr[key + "_launches"]:
-                    ent[name]["avg_launch_ms_in_timed_region"] = round(tr[key + "_ms"] / tr[key + "_launches"], 4)
-            # The filter stage = the streaming scan (reads every pixel once, marks the tiles that can hold set pixels) + the
-            # filter kernel (re-reads and filters only those tiles).  Its algorithmic traffic is one read of the frames,
-            # so the stage is priced as a whole: bytes / (sum of the two kernels' average launch durations).
-            both_ms = sum(e["avg_launch_ms"] for e in ent.values())
-            ach = WIDTH * HEIGHT * per_launch / (both_ms * 1e-3) / 1e9
-            tr_known = [traffic.get(k) for k in ent]
-            roof = {"bound": "hbm", "kernel": " + ".join(ent), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": sum(tr_known) if all(t is not None for t in tr_known) else None,
-                    "avg_launch_ms": round(both_ms, 4), "images_per_launch": per_launch,
-                    "algorithmic_bytes_per_image": WIDTH * HEIGHT,
-                    "per_kernel": ent,
-                    "note": "the stage's algorithmic traffic is one read of the frames; bright_cells_kernel is the kernel that "
-                            "moves those bytes (priced alone in per_kernel), the other kernels touch the marked tiles only"}
-            return roof
-
-        def kernel_ms(prof):
-            n = prof["steps"]
-            return {"scan": round(prof["scan_ms"] / n, 4), "patches": round(prof["patch_ms"] / n, 4),
-                    "filter": round(prof["filter_ms"] / n, 4),
-                    "contours": round(prof["contour_ms"] / n, 4), "correspond": round(prof["corr_ms"] / n, 4)}
-
-        roof = roofline_of(prof, len(images), 1 if world == 1 else len(tracker.segs), args.dist)
+        value = T_STEPS * world * args.steps / elapsed
+        std = (main_wl.cameras, main_wl.width, main_wl.height, main_wl.markers, main_wl.background, main_wl.bayer) == \
+            (6, 1920, 1080, 8, (0, 60), False)
+        roof = roofline_of(prof, main_wl, len(m["images"]), 1 if world == 1 else len(tracker.segs),
+                           f"6x1920x1080-m8-{args.dist}" if std and world == 1 else None)
+        res = f"{main_wl.width}x{main_wl.height}"
         line = {
-            "metric": "frames/sec (6-cam 1080p)" if (WIDTH, HEIGHT) == (1920, 1080) else f"frames/sec (6-cam {WIDTH}x{HEIGHT})", "value": round(value, 2), "unit": "frames/s", "n_gpus": world,
+            "metric": f"frames/sec ({main_wl.cameras}-cam {'1080p' if res == '1920x1080' else res})", "value": round(value, 2),
+            "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8+int64+f64",
             "data": "synthetic",
-            "config": {"workload": "6-camera 1920x1080 synthetic IR frames, 8 markers (BASELINE.json configs[1])"
-                       if (N_MARKERS, WIDTH, HEIGHT) == (8, 1920, 1080) else
-                       f"6-camera {WIDTH}x{HEIGHT} synthetic IR frames, {N_MARKERS} markers"
-                       + (" (BASELINE.json configs[2])" if N_MARKERS == 32 else ""),
-                       "cameras": N_CAM, "width": WIDTH, "height": HEIGHT, "markers": N_MARKERS,
-                       "time_steps_per_step_per_gpu": T_STEPS, "distortion": args.dist,
+            "config": {"workload": main_wl.name(world),
+                       "cameras": main_wl.cameras, "width": main_wl.width, "height": main_wl.height, "markers": main_wl.markers,
+                       "time_steps_per_step_per_gpu": T_STEPS, "distortion": args.dist, "background": list(main_wl.background),
                        "frames_resident_in_hbm": not args.from_host, "batches_in_flight": args.depth,
                        "input": "raw Bayer GR frames, gray conversion inside every step" if args.bayer else "gray frames",
-                       "parallelism": "single launch, time-major" if world == 1 else f"camera-major blocks x{world} + 1 all-gather"},
+                       "parallelism": "single launch, time-major" if world == 1 else f"camera-major blocks x{world} + 1 all-gather per batch",
+                       "collective": None if world == 1 else
+                       ("mocap_allgather_centroids (ncclAllGather behind the C-ABI, RCCL)" if tracker.collective == "rccl"
+                        else ("torch.distributed over gloo (one-GPU rehearsal)" if args.rehearse_on_one_gpu else "torch.distributed all_gather_into_tensor (RCCL)"))},
             "roofline": roof,
             "kernel_ms_per_step": kernel_ms(prof),
             "status_ok": status_ok,
-            "points_per_frame": float(n_roots.mean()),
+            "points_per_frame": float(np.maximum(n_roots, 0).mean()),
             "dark_tile_early_out": {"tiles_per_step": prof["tiles"], "tiles_resolved_without_filtering": prof["tiles_skipped"],
-                                    "note": "exact: bright_cells_kernel reads the frames once and sums the excess over 63 per 8x8 cell; "
-                                            "a (240 col x 68 row) filter tile whose cells prove that no mask bit can be set is "
-                                            "answered with zeros (DESIGN.md 4.1); disabled run below"},
+                                    "note": "exact: the scan kernel reads the frames once and sums every 8x8 cell's excess over a base "
+                                            "derived from the threshold; a filter tile whose cells prove that no mask bit can be set is "
+                                            "answered with zeros (DESIGN.md 4.1); disabled run in without_early_out"},
         }
+        if args.rehearse_on_one_gpu:
+            line["rehearsal"] = "N ranks on one GPU over gloo: a functional check of the multi-rank path, NOT a measurement"
+        ref_out = {k: v.clone() for k, v in out.items()}  # the tracker reuses its output buffers
+        ref_rec = tracker.records.clone()
         if world == 1 and args.secondary:
-            ref_out = {k: v.clone() for k, v in out.items()}  # the tracker reuses its output buffers
-            ref_rec = tracker.records.clone()
             os.environ["MOCAP_SKIP_DARK"] = "0"  # same batch, early-out off: every tile runs the full filter
-            out_d, el_d, prof_d = timed(tracker, frames)
+            out_d, el_d, prof_d = timed(tracker, m["frames"], max(3, args.steps // 3), 2)
             del os.environ["MOCAP_SKIP_DARK"]
-            roof_d = roofline_of(prof_d, len(images), 1, None)
-            line["without_early_out"] = {"value": round(T_STEPS * args.steps / el_d, 2), "unit": "frames/s",
-                                         "ms_per_step": round(1e3 * el_d / args.steps, 4),
+            roof_d = roofline_of(prof_d, main_wl, len(m["images"]), 1, None)
+            line["without_early_out"] = {"value": round(T_STEPS * max(3, args.steps // 3) / el_d, 2), "unit": "frames/s",
+                                         "ms_per_step": round(1e3 * el_d / max(3, args.steps // 3), 4),
                                          "filter_avg_launch_ms": roof_d["avg_launch_ms"], "roofline_frac": roof_d["frac"],
                                          "same_results": bool(torch.equal(tracker.records, ref_rec) and torch.equal(out_d["n"], ref_out["n"])
                                                               and torch.equal(out_d["xyz"], ref_out["xyz"]))}
+        if world == 1 and args.cpu_steps > 0:
+            fps, dt, results = cpu_baseline(main_wl, m["arrays"], m["frames_host"].reshape(T_STEPS, main_wl.cameras, main_wl.height, main_wl.width),
+                                            args.cpu_steps)
+            line["cpu_baseline"] = {"value": round(fps, 3), "unit": "frames/s", "cores": main_wl.cameras, "kind": "port",
+                                    "sample": f"{args.cpu_steps} time steps x {main_wl.cameras} cameras of the same workload, "
+                                              f"{dt:.1f} s, thread-per-camera C oracle ({os.cpu_count()} host cpus)"}
+            # parity of the timed batch against the oracle (not timed): every time step of the CPU sample
+            host_out = {k: v.cpu().numpy() for k, v in ref_out.items()}
+            line["parity"] = parity_report([r for r in results if r[0] < T_STEPS][:T_STEPS], ref_rec.cpu().numpy(), host_out,
+                                           main_wl.cameras, main_wl.max_points)
+            line["parity_spot_check"] = line["parity"]["ok"]
+        # release the main workload before the next ones are built
+        del ref_out, ref_rec
+        m.clear()
+        del tracker, out
+        torch.cuda.empty_cache()
         if world == 1 and args.secondary:
             other = "zero" if args.dist == "mild" else "mild"
-            _, _, tr2, im2, _, out2, el2, prof2, fr2 = measure(other)
-            roof2 = roofline_of(prof2, len(im2), 1, other)
-            line["other_distortion_variant"] = {
-                "distortion": other, "value": round(T_STEPS * args.steps / el2, 2), "unit": "frames/s",
-                "ms_per_step": round(1e3 * el2 / args.steps, 4),
-                "roofline": roof2,
-                "kernel_ms_per_step": kernel_ms(prof2),
-                "status_ok": bool((out2["n"].cpu().numpy() >= 0).all()),
-                "dark_tile_early_out": {"tiles_per_step": prof2["tiles"], "tiles_resolved_without_filtering": prof2["tiles_skipped"]},
-                "note": "same workload with zero lens distortion: cv.undistort is then the identity map and the "
-                        "kernel streams the frame without the remap gather (SURVEY.md section 8d lists both variants)"}
-            del tr2, fr2
-        if world == 1 and args.cpu_steps > 0:
-            fps, dt, n_pts, last = cpu_baseline(scene, arrays, frames_host.reshape(T_STEPS, N_CAM, HEIGHT, WIDTH), args.cpu_steps, args.bayer)
-            line["cpu_baseline"] = {"value": round(fps, 3), "unit": "frames/s", "cores": N_CAM, "kind": "port",
-                                    "sample": f"{args.cpu_steps} time steps x {N_CAM} cameras of the same workload, "
-                                              f"{dt:.1f} s, thread-per-camera C oracle ({os.cpu_count()} host cpus)"}
-            # parity spot check of the timed batch against the oracle (not timed): last CPU time step
-            s = (args.cpu_steps - 1) % T_STEPS
-            k = int(n_roots[s])
-            gpu_xyz = out["xyz"][s, :k].cpu().numpy()
-            ref = last[1]
-            line["parity_spot_check"] = bool(k == len(ref["root"]) and (k == 0 or np.abs(gpu_xyz - ref["xyz"]).max() < 1e-7))
+            wl2 = Workload(main_wl.cameras, main_wl.width, main_wl.height, main_wl.markers, other, main_wl.background, main_wl.bayer)
+            m2 = measure(wl2, T_STEPS, args.steps, args.warmup)
+            sec = section(wl2, m2, args.steps)
+            sec["distortion"] = other
+            sec["note"] = ("same workload with zero lens distortion: cv.undistort is then the identity map and the kernels read "
+                           "the frame without the remap gather (SURVEY.md section 8d lists both variants)")
+            line["other_distortion_variant"] = sec
+            m2.clear()
+            torch.cuda.empty_cache()
+        if world == 1 and args.extra and std:
+            extra = {}
+            for key, wl in (("markers32_configs2", Workload(6, 1920, 1080, 32, args.dist)),
+                            ("bright_background", Workload(6, 1920, 1080, 8, args.dist, (90, 110))),
+                            ("frame_4k", Workload(6, 3840, 2160, 8, args.dist))):
+                Tx = wl.default_time_steps()
+                mx = measure(wl, Tx, args.steps, args.warmup)
+                extra[key] = section(wl, mx, args.steps)
+                mx.clear()
+                torch.cuda.empty_cache()
+            line["extra"] = extra
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define MOCAP_ABI_VERSION 3
+#define MOCAP_ABI_VERSION 4
 #define MOCAP_API __attribute__((visibility("default")))
 
 enum {
@@ -36,7 +36,10 @@ enum {
     MOCAP_BLOB_E_CONTOURS = -3,   /* more than 384 borders or 256 kept contours in one image */
     MOCAP_BLOB_E_STEPS = -4,      /* a border longer than the step limit */
     MOCAP_BLOB_E_DEPTH = -5,      /* a kept contour nested deeper than 8 levels */
-    MOCAP_CORR_E_GROUPS = -2      /* more than 16 candidates for one (root, camera) or > max_groups groups */
+    MOCAP_CORR_E_GROUPS = -2,     /* more than 16 candidates for one (root, camera), > max_groups groups for one root, or
+                                     > max(max_groups, 8192) groups in the whole time step */
+    MOCAP_CORR_E_TRUNCATED = -3,  /* a camera holds more image points than the P that mocap_correspond was told to read */
+    MOCAP_CORR_E_BLOB = -4        /* a camera's point count is negative: its blob stage reported MOCAP_BLOB_E_* */
 };
 
 typedef struct mocap_ctx* mocap_ctx_t;
@@ -148,7 +151,9 @@ MOCAP_API int mocap_demosaic_u8(mocap_ctx_t ctx, const void* bayer_dev, void* bg
  *   root_grp [T][P][C][2] the first group's image points             (Helpers.py:268)
  *   root_idx [T][P]     camera-0 index of the root
  *   order    [T][P]     argsort of root_err                          (Helpers.py:274)
- *   n_roots  [T]        number of surviving roots, or MOCAP_CORR_E_GROUPS
+ *   n_roots  [T]        number of surviving roots, or MOCAP_CORR_E_* (< 0): the time step has no result.  Nothing is
+ *                       ever shortened silently: counts above P or below 0 fail the step (the reference has no
+ *                       capacity limits, lib/Helpers.py:191,203-245)
  * The caller applies obj_count (Helpers.py:275-279).  Requires mocap_set_cameras + mocap_set_fundamentals. */
 MOCAP_API int mocap_correspond(mocap_ctx_t ctx, const void* pts_dev, long pt_stride_t, long pt_stride_c,
                      const int32_t* counts_dev, long cnt_stride_t, long cnt_stride_c, int pts_f64, int T, int C,
@@ -165,6 +170,27 @@ MOCAP_API int mocap_triangulate_batch(mocap_ctx_t ctx, const double* pts_dev, co
  * ok_dev[n] = 0 where the reference returns None. */
 MOCAP_API int mocap_reproject_batch(mocap_ctx_t ctx, const double* pts_dev, const uint8_t* valid_dev, const double* xyz_dev,
                           int N, int C, int compact_k, double* mse_dev, int32_t* ok_dev, void* stream);
+
+/* The path's one exchange step: with the cameras sharded over GPUs (one process per GPU), every rank
+ * contributes the fixed-size centroid records of its images and receives all ranks' records, in rank order, before
+ * correspondence -- one ncclAllGather (RCCL over xGMI) per batch.  The reference has no counterpart: its camera
+ * threads hand their image points to the `track` thread through queue.Queue (RealtimeTracking_FLIR.py:107-113,
+ * 180-183, 304-312); this is that hand-off across GPUs.  librccl is bound at run time (dlopen), so single-GPU users
+ * do not need it.
+ *   mocap_comm_unique_id  rank 0 obtains MOCAP_COMM_ID_BYTES opaque bytes (ncclGetUniqueId) and hands them to the
+ *                         other ranks by any host-side means (file, socket, MPI, torch.distributed store ...);
+ *   mocap_comm_init       every rank, collectively: creates the context's communicator (ncclCommInitRank) on the
+ *                         context's device; one communicator per context = per stream of batches in flight;
+ *   mocap_allgather_centroids  asynchronous on `stream`: local_records_dev [ints_per_rank] int32 of every rank
+ *                         -> gathered_dev [world][ints_per_rank] on every rank (the records mocap_blob_centroids
+ *                         wrote; mocap_correspond then reads them in place through its strides);
+ *   mocap_comm_destroy    optional; mocap_ctx_destroy does it too. */
+#define MOCAP_COMM_ID_BYTES 128
+MOCAP_API int mocap_comm_unique_id(void* id_out /*[MOCAP_COMM_ID_BYTES]*/);
+MOCAP_API int mocap_comm_init(mocap_ctx_t ctx, const void* id /*[MOCAP_COMM_ID_BYTES]*/, int rank, int world);
+MOCAP_API int mocap_comm_destroy(mocap_ctx_t ctx);
+MOCAP_API int mocap_allgather_centroids(mocap_ctx_t ctx, const int32_t* local_records_dev, int32_t* gathered_dev,
+                                        long ints_per_rank, void* stream);
 
 /* Dark-tile early-out of the filter stage: one streaming kernel sums the excess max(0, p - 63) of every 8x8 cell of the
  * frames; a filter tile whose source region provably cannot produce a set mask bit (bound in DESIGN.md 4.1) is then

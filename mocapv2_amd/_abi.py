@@ -4,7 +4,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmocap_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
+COMM_ID_BYTES = 128  # MOCAP_COMM_ID_BYTES
 
 
 class MocapError(RuntimeError):
@@ -51,6 +52,10 @@ SIGNATURES = {
     "mocap_correspond": [_vp, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, _i, _d, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "mocap_triangulate_batch": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "mocap_reproject_batch": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "mocap_comm_unique_id": [_vp],
+    "mocap_comm_init": [_vp, _vp, _i, _i],
+    "mocap_comm_destroy": [_vp],
+    "mocap_allgather_centroids": [_vp, _vp, _vp, _l, _vp],
     "mocap_tile_stats": [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
     "mocap_profile_enable": [_vp, _i],
     "mocap_profile_read": [_vp, _dp, _ip],

@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 #include <mutex>
+#include <dlfcn.h>
 #include "../../include/mocap_hip.h"
 #include "kernels.h"
 
@@ -58,6 +59,7 @@ struct mocap_ctx {
     void* cwork; size_t cwork_images;      // contour kernel workspace, contour_work_bytes() per image
     CameraTable* cams; int n_cam, n_F;
     double* scratch; size_t scratch_elems;
+    void* comm; int comm_rank, comm_world; // RCCL communicator of mocap_comm_init (ncclComm_t), else null
     bool profiling;
     std::vector<EvPair> ev[5];
     std::mutex mu;
@@ -124,6 +126,49 @@ static bool lds_remap_ok(const mocap_ctx* c, const std::vector<uint2>& sp)
     return true;
 }
 
+// ---- RCCL, bound at run time -----------------------------------------------------------------------------------
+// The path's one exchange is an ncclAllGather of centroid records.  librccl is looked up with dlopen
+// when the first communicator call arrives: a process that already holds RCCL (PyTorch ships its own librccl.so.1)
+// shares that copy, a plain C host gets /opt/rocm/lib's; single-GPU users never load it.
+struct IdBytes { char internal[MOCAP_COMM_ID_BYTES]; }; // layout of ncclUniqueId (rccl.h: 128 opaque bytes, passed by value)
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, IdBytes, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+}
+static Rccl g_rccl;
+static std::mutex g_rccl_mu;
+static int load_rccl()
+{
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.lib) return 0;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(MOCAP_E_UNSUPPORTED, "librccl.so.1 not found: %s", dlerror());
+    Rccl r;
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+    r.AllGather = (decltype(r.AllGather))dlsym(h, "ncclAllGather");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GetErrorString)
+        return fail(MOCAP_E_UNSUPPORTED, "librccl lacks an expected symbol");
+    r.lib = h;
+    g_rccl = r;
+    return 0;
+}
+#define RCCL_TRY(expr)                                                                                        \
+    do {                                                                                                      \
+        int r_ = (expr);                                                                                      \
+        if (r_ != 0) return fail(MOCAP_E_HIP, "%s failed: %s", #expr, g_rccl.GetErrorString(r_));             \
+    } while (0)
+
 extern "C" {
 
 int mocap_abi_version(void) { return MOCAP_ABI_VERSION; }
@@ -142,6 +187,7 @@ int mocap_ctx_create(int device_id, int width, int height, int n_slots, mocap_ct
     c->prm = mocap_blob_params{5, 5, 255 * 0.85, 500.0, 0.5};
     c->maps = nullptr; c->spans = nullptr; c->reach = nullptr; c->cflags = nullptr; c->cells_ext = nullptr; c->cells_ext_images = 0; c->map_flags = nullptr; c->mask = nullptr; c->mask_images = 0; c->cells = nullptr; c->cells_images = 0; c->last_images = 0; c->tile_rows = nullptr; c->patch = nullptr; c->patch_images = 0; c->cwork = nullptr; c->cwork_images = 0;
     c->cams = nullptr; c->n_cam = 0; c->n_F = 0; c->scratch = nullptr; c->scratch_elems = 0; c->profiling = false;
+    c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1;
     c->slot_state.assign(n_slots, 0);
     c->slot_mode.assign(n_slots, 2);
     c->slot_wmax.assign(n_slots, 0);
@@ -162,6 +208,7 @@ int mocap_ctx_destroy(mocap_ctx_t c)
     if (!c) return MOCAP_OK;
     (void)hipSetDevice(c->device);
     for (auto& v : c->ev) for (auto& p : v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    if (c->comm && g_rccl.lib) { (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
     if (c->maps) (void)hipFree(c->maps);
     if (c->spans) (void)hipFree(c->spans);
     if (c->reach) (void)hipFree(c->reach);
@@ -764,6 +811,52 @@ int mocap_demosaic_u8(mocap_ctx_t c, const void* bayer, void* bgr, int H, int W,
     return MOCAP_OK;
 }
 
+// ---- the exchange: one all-gather of centroid records (RCCL over xGMI) -------------------------------------------
+int mocap_comm_unique_id(void* id_out)
+{
+    if (!id_out) return fail(MOCAP_E_INVALID, "null argument");
+    int rc = load_rccl();
+    if (rc) return rc;
+    RCCL_TRY(g_rccl.GetUniqueId(id_out));
+    return MOCAP_OK;
+}
+
+int mocap_comm_init(mocap_ctx_t c, const void* id, int rank, int world)
+{
+    if (!c || !id) return fail(MOCAP_E_INVALID, "null argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(MOCAP_E_INVALID, "rank %d of %d", rank, world);
+    if (c->comm) return fail(MOCAP_E_STATE, "the context already has a communicator");
+    int rc = load_rccl();
+    if (rc) return rc;
+    if (set_device(c)) return MOCAP_E_HIP;
+    IdBytes idb;
+    memcpy(idb.internal, id, sizeof(idb.internal));
+    void* comm = nullptr;
+    RCCL_TRY(g_rccl.CommInitRank(&comm, world, idb, rank));
+    c->comm = comm; c->comm_rank = rank; c->comm_world = world;
+    return MOCAP_OK;
+}
+
+int mocap_comm_destroy(mocap_ctx_t c)
+{
+    if (!c) return fail(MOCAP_E_INVALID, "null context");
+    if (!c->comm) return MOCAP_OK;
+    if (set_device(c)) return MOCAP_E_HIP;
+    RCCL_TRY(g_rccl.CommDestroy(c->comm));
+    c->comm = nullptr; c->comm_world = 1; c->comm_rank = 0;
+    return MOCAP_OK;
+}
+
+int mocap_allgather_centroids(mocap_ctx_t c, const int32_t* local_records, int32_t* gathered, long ints_per_rank, void* stream)
+{
+    if (!c || !local_records || !gathered) return fail(MOCAP_E_INVALID, "null argument");
+    if (ints_per_rank < 1) return fail(MOCAP_E_INVALID, "ints_per_rank = %ld", ints_per_rank);
+    if (!c->comm) return fail(MOCAP_E_STATE, "mocap_comm_init was not called for this context");
+    if (set_device(c)) return MOCAP_E_HIP;
+    RCCL_TRY(g_rccl.AllGather(local_records, gathered, (size_t)ints_per_rank, 2 /* ncclInt32 */, c->comm, (hipStream_t)stream));
+    return MOCAP_OK;
+}
+
 // ---- geometry stage --------------------------------------------------------------------------------------------
 int mocap_correspond(mocap_ctx_t c, const void* pts, long pt_st, long pt_sc, const int32_t* counts, long cnt_st, long cnt_sc,
                      int pts_f64, int T, int C, int P, double cutoff,
@@ -776,10 +869,15 @@ int mocap_correspond(mocap_ctx_t c, const void* pts, long pt_st, long pt_sc, con
     if (T < 1 || C < 1 || C > 32 || P < 1 || P > 255 || max_groups < 1) return fail(MOCAP_E_INVALID, "T=%d C=%d P=%d max_groups=%d", T, C, P, max_groups);
     if (c->n_cam < C) return fail(MOCAP_E_STATE, "mocap_set_cameras: %d cameras set, %d needed", c->n_cam, C);
     if (c->n_F < C - 1) return fail(MOCAP_E_STATE, "mocap_set_fundamentals: %d matrices set, %d needed", c->n_F, C - 1);
-    if (correspond_smem_bytes(P, C) > 64 * 1024)
+    if (correspond_smem_bytes(P, C) + 16 > 64 * 1024) // + the kernel's two static words
         return fail(MOCAP_E_UNSUPPORTED, "P=%d points x C=%d cameras needs %zu bytes of LDS (> 64 KiB)", P, C, correspond_smem_bytes(P, C));
     if (set_device(c)) return MOCAP_E_HIP;
-    size_t need = (size_t)T * P * max_groups;
+    // error scratch: the groups of one time step lie back to back, so a step needs room for its total, not P x max_groups;
+    // a step with more than max(max_groups, 8192) groups in all reports MOCAP_CORR_E_GROUPS
+    size_t budget = (size_t)max_groups > 8192 ? (size_t)max_groups : 8192;
+    if (budget > (size_t)P * max_groups) budget = (size_t)P * max_groups;
+    if (budget > 0x7fffffff) budget = 0x7fffffff;
+    size_t need = (size_t)T * budget;
     if (need > c->scratch_elems) {
         std::lock_guard<std::mutex> lk(c->mu);
         if (c->scratch) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c->scratch)); c->scratch = nullptr; c->scratch_elems = 0; }
@@ -790,7 +888,7 @@ int mocap_correspond(mocap_ctx_t c, const void* pts, long pt_st, long pt_sc, con
     a.cams = c->cams; a.pts = pts; a.counts = counts; a.pts_f64 = pts_f64; a.T = T; a.C = C; a.P = P;
     a.pt_st = pt_st; a.pt_sc = pt_sc; a.cnt_st = cnt_st; a.cnt_sc = cnt_sc;
     a.cutoff = cutoff; a.max_groups = max_groups; a.root_xyz = root_xyz; a.root_err = root_err; a.root_grp = root_grp;
-    a.root_idx = root_idx; a.order = order; a.n_roots = n_roots; a.scratch = c->scratch;
+    a.root_idx = root_idx; a.order = order; a.n_roots = n_roots; a.scratch = c->scratch; a.step_budget = (int)budget;
     EvPair p; bool on;
     prof_begin(c, 2, (hipStream_t)stream, p, on);
     launch_correspond(a, (hipStream_t)stream);

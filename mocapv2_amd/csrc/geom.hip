@@ -222,9 +222,22 @@ __global__ __launch_bounds__(256) void correspond_kernel(CorrArgs a)
     auto cnt = [&](int c) { return a.counts[(size_t)t * a.cnt_st + (size_t)c * a.cnt_sc]; };
     // element offset (in points) of camera c's list; strides are given in scalars, a point is 2 scalars
     auto pbase = [&](int c) { return ((size_t)t * a.pt_st + (size_t)c * a.pt_sc) / 2; };
-    const int n0 = cnt(0) < P ? cnt(0) : P;
     if (tid == 0) { s_err = 0; s_nout = 0; }
     __syncthreads();
+    // A camera whose count does not fit the P points read here, or whose blob stage reported a capacity error (negative
+    // count), fails the time step: the reference has no such limits (lib/Helpers.py:191,203-245), so a shortened list
+    // must never pass for a result.  s_err: 1 = groups, 2 = more than P points, 3 = negative count.
+    if (tid < C) {
+        const int n = cnt(tid);
+        if (n < 0) atomicMax(&s_err, 3);
+        else if (n > P) atomicMax(&s_err, 2);
+    }
+    __syncthreads();
+    if (s_err) {
+        if (tid == 0) a.n_roots[t] = s_err == 3 ? CORR_ERR_BLOB : CORR_ERR_TRUNCATED;
+        return;
+    }
+    const int n0 = cnt(0);
 
     // ---- phase 1: per (root, camera) candidate lists, sorted by distance to the epipolar line -----------
     for (int w = tid; w < n0 * (C - 1); w += blockDim.x) {
@@ -234,7 +247,7 @@ __global__ __launch_bounds__(256) void correspond_kernel(CorrArgs a)
         float line[3];
         epiline(cams->F[i - 1], (float)rx, (float)ry, line);
         double md[MAXM];
-        int mi[MAXM], k = 0, ni = cnt(i) < P ? cnt(i) : P;
+        int mi[MAXM], k = 0, ni = cnt(i);
         bool over = false;
         for (int p = 0; p < ni; p++) {
             double x, y;
@@ -270,6 +283,7 @@ __global__ __launch_bounds__(256) void correspond_kernel(CorrArgs a)
         }
         goff[n0] = acc;
         s_nout = no;
+        if (acc > a.step_budget) s_err = 1; // the time step's groups do not fit its share of the error scratch
     }
     __syncthreads();
     if (s_err) {
@@ -304,7 +318,7 @@ __global__ __launch_bounds__(256) void correspond_kernel(CorrArgs a)
         double e[64];
         for (int i = 0; i < C; i++) reproj_sq(cams->K[i], cams->dist[i], cams->R[i], cams->t[i], Xf, gx[i], gy[i], e[2 * i], e[2 * i + 1]);
         double mse = np_block_sum(e, 2 * C) / (double)(2 * C);
-        a.scratch[((size_t)t * P + j) * a.max_groups + g] = mse;
+        a.scratch[(size_t)t * a.step_budget + goff[j] + g] = mse;
         if (g == 0) {
             int o = slot[j];
             size_t ro = (size_t)t * P + o;
@@ -318,7 +332,7 @@ __global__ __launch_bounds__(256) void correspond_kernel(CorrArgs a)
     // ---- phase 3: per-root mean over its groups (NumPy pairwise order), then argsort ---------------------
     for (int j = tid; j < n0; j += blockDim.x) {
         if (G[j] == 0) continue;
-        const double* e = a.scratch + ((size_t)t * P + j) * a.max_groups;
+        const double* e = a.scratch + (size_t)t * a.step_budget + goff[j];
         a.root_err[(size_t)t * P + slot[j]] = np_pairwise_sum(e, G[j]) / (double)G[j];
     }
     __syncthreads();

@@ -151,7 +151,8 @@ struct CorrArgs {
     int32_t* root_idx;         // [T][P]  camera-0 index of the j-th surviving root
     int32_t* order;            // [T][P]  argsort(root_err)
     int32_t* n_roots;          // [T]  (<0 = error)
-    double* scratch;           // [T][P][max_groups] per-group errors
+    double* scratch;           // [T][step_budget] per-group errors, the groups of a time step back to back in root order
+    int step_budget;           // groups per time step the scratch holds
 };
 
 struct TriArgs {
@@ -174,7 +175,7 @@ struct ReprojArgs {
     int32_t* ok;               // [N]
 };
 
-enum { CORR_ERR_GROUPS = -2 };
+enum { CORR_ERR_GROUPS = -2, CORR_ERR_TRUNCATED = -3, CORR_ERR_BLOB = -4 };
 
 void launch_correspond(const CorrArgs& a, hipStream_t s);
 size_t correspond_smem_bytes(int P, int C);

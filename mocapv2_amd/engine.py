@@ -276,6 +276,25 @@ class MocapContext:
                                                   _ptr(mse), _ptr(ok), _stream()))
         return mse.cpu().numpy(), ok.cpu().numpy()
 
+    # ---- the exchange step (one all-gather of centroid records, RCCL over xGMI) -----------------------------------
+    def comm_init(self, unique_id, rank, world):
+        """Collective over all ranks: create this context's RCCL communicator from the bytes rank 0 got from
+        `comm_unique_id()` (handed around by the host, e.g. through torch.distributed)."""
+        buf = (C.c_char * _abi.COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        _abi.check(self.lib.mocap_comm_init(self._h, C.cast(buf, C.c_void_p), int(rank), int(world)))
+        self.comm_world = int(world)
+
+    def allgather_centroids(self, local, out=None):
+        """local: this rank's centroid records (int32, contiguous, on this GPU) -> [world * len(local), ...] on every
+        rank, in rank order; asynchronous on the current stream."""
+        assert local.is_cuda and local.is_contiguous() and local.dtype == torch.int32
+        world = self.comm_world
+        if out is None:
+            out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=torch.int32, device=local.device)
+        assert out.is_contiguous() and out.numel() == world * local.numel() and out.dtype == torch.int32
+        _abi.check(self.lib.mocap_allgather_centroids(self._h, _ptr(local), _ptr(out), local.numel(), _stream()))
+        return out
+
     # ---- profiling -----------------------------------------------------------------------------------------------
     def tile_stats(self):
         """(tiles, tiles resolved by the dark-tile early-out) of the most recent blob_centroids batch"""
@@ -294,6 +313,13 @@ class MocapContext:
         return {"filter_ms": ms[0], "filter_launches": n[0], "contour_ms": ms[1], "contour_launches": n[1],
                 "corr_ms": ms[2], "corr_launches": n[2], "scan_ms": ms[3], "scan_launches": n[3],
                 "patch_ms": ms[4], "patch_launches": n[4]}
+
+
+def comm_unique_id():
+    """MOCAP_COMM_ID_BYTES opaque bytes (ncclGetUniqueId) for MocapContext.comm_init; call on rank 0 only."""
+    buf = (C.c_char * _abi.COMM_ID_BYTES)()
+    _abi.check(_abi.load().mocap_comm_unique_id(C.cast(buf, C.c_void_p)))
+    return bytes(buf)
 
 
 _contexts = threading.local()

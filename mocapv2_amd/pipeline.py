@@ -32,11 +32,14 @@ def shard_plan(n_cams, steps_per_rank, world, rank):
     return segs
 
 
-def allgather_records(local, world, group=None):
-    """The path's only collective: every rank contributes its [per, REC] centroid records, every rank receives
-    [world * per, REC] in rank order = camera-major order.  `local` may live on the GPU (nccl = RCCL) or on the
-    CPU (gloo, used by the multi-process tests)."""
-    if world == 1:
+def allgather_records(local, world, group=None, force=False):
+    """The path's only collective, host-side form (torch.distributed): every rank contributes its [per, REC] centroid
+    records, every rank receives [world * per, REC] in rank order = camera-major order.  `local` may live on the GPU
+    (nccl = RCCL) or on the CPU (gloo, used by the multi-process tests).  The product's default on GPUs is the same
+    all-gather behind the C-ABI (`MocapContext.allgather_centroids` = mocap_allgather_centroids, RCCL called
+    directly on the batch's HIP stream); this form serves gloo rehearsals / CPU tests and `collective="torch"`.
+    force: run the collective even with one rank (tests)."""
+    if world == 1 and not force:
         return local
     import torch.distributed as dist
     out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
@@ -52,11 +55,39 @@ def allgather_records(local, world, group=None):
     return out
 
 
+# per-time-step status codes of the correspondence kernel (include/mocap_hip.h MOCAP_CORR_E_*)
+CORR_STATUS = {
+    -2: "more candidate groups than the correspondence kernel's capacity (MOCAP_CORR_E_GROUPS)",
+    -3: "a camera holds more image points than the tracker's max_points (MOCAP_CORR_E_TRUNCATED): raise max_points",
+    -4: "a camera's blob stage exceeded an internal capacity (MOCAP_CORR_E_BLOB; its record count holds the MOCAP_BLOB_E_* code)",
+}
+
+
+class CapacityError(RuntimeError):
+    """A time step has no result because a fixed capacity was exceeded.  The reference has no such limits
+    (lib/Helpers.py:191,203-245), so the batched path never passes a shortened point list for a result: it fails."""
+
+    def __init__(self, step, code):
+        super().__init__(f"time step {step}: {CORR_STATUS.get(code, 'status %d' % code)}")
+        self.step, self.code = step, code
+
+
+def check_status(n_roots, first_step=0):
+    """n_roots: host array of the per-time-step root counts of a batch.  Raises CapacityError for the first failed
+    time step."""
+    n_roots = np.asarray(n_roots)
+    bad = np.flatnonzero(n_roots < 0)
+    if len(bad):
+        raise CapacityError(first_step + int(bad[0]), int(n_roots[bad[0]]))
+    return n_roots
+
+
 class _Lane:
     """One set of per-batch buffers (context scratch, centroid records, outputs) and the HIP stream it works on."""
 
     def __init__(self, ctx, records, stream):
         self.ctx, self.records, self.stream, self.out = ctx, records, stream, None
+        self.gathered = None # all ranks' records (collective == "rccl")
         self.staging = None  # device copy of a batch that arrived in host memory
         self.gray = None     # gray frames of a batch that arrived as raw Bayer frames
 
@@ -69,7 +100,14 @@ class BatchTracker:
     the next (the streaming scan).  Results of a batch are complete once its stream (or the device) is synchronised."""
 
     def __init__(self, K, dist, R, t, F, width, height, steps_per_rank, world=1, rank=0, device=0, group=None,
-                 max_points=32, max_groups=4096, depth=1, bayer_pattern=None, gray_shift=14):
+                 max_points=32, max_groups=4096, depth=1, bayer_pattern=None, gray_shift=14, collective="auto",
+                 force_collective=False):
+        """collective: how the centroid records are exchanged when world > 1 --
+             "rccl"  mocap_allgather_centroids: ncclAllGather called by the library on the batch's own HIP stream, one
+                     communicator per batch in flight (its unique id travels through torch.distributed once, at set-up);
+             "torch" torch.distributed (all_gather_into_tensor on nccl = RCCL, or gloo through the host);
+             "auto"  "rccl" when the process group's backend is nccl, else "torch".
+           force_collective: run the exchange even with world == 1 (a one-rank all-gather; tests)."""
         self.n_cam = len(K)
         self.T = int(steps_per_rank)
         self.world, self.rank, self.group = world, rank, group
@@ -102,6 +140,36 @@ class BatchTracker:
             self.lanes.append(_Lane(ctx, records, stream))
         self._k = 0
         self._cur = self.lanes[0]
+        self.force_collective = bool(force_collective)
+        self.collective = None
+        if world > 1 or self.force_collective:
+            self.collective = self._setup_collective(collective)
+
+    def _setup_collective(self, collective):
+        import torch.distributed as dist
+        have_pg = dist.is_available() and dist.is_initialized()
+        if collective == "auto":
+            collective = "rccl" if (not have_pg and self.world == 1) or (have_pg and dist.get_backend(self.group) == "nccl") \
+                else "torch"
+        if collective == "torch":
+            return "torch"
+        assert collective == "rccl", collective
+        from .engine import comm_unique_id
+        from . import _abi
+        dev = self.lanes[0].ctx.device
+        for lane in self.lanes:  # same order on every rank: communicator creation is collective
+            if self.world == 1:
+                uid = comm_unique_id()
+            else:
+                on_gpu = dist.get_backend(self.group) == "nccl"
+                box = torch.zeros(_abi.COMM_ID_BYTES, dtype=torch.uint8, device=dev if on_gpu else "cpu")
+                if self.rank == 0:
+                    box.copy_(torch.frombuffer(bytearray(comm_unique_id()), dtype=torch.uint8))
+                dist.broadcast(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+                uid = bytes(box.cpu().numpy().tobytes())
+            lane.ctx.comm_init(uid, self.rank, self.world)
+            lane.gathered = torch.empty((self.world * self.per, self.rec_ints), dtype=torch.int32, device=dev)
+        return "rccl"
 
     # the buffers of the batch most recently submitted
     @property
@@ -175,6 +243,8 @@ class BatchTracker:
         if lane.stream is None:
             return self._run(self._resident(lane, frames))
         lane.stream.wait_stream(torch.cuda.current_stream())  # the frames were produced on the caller's stream
+        if frames.is_cuda:
+            frames.record_stream(lane.stream)  # the caller may drop them right after this call: keep the memory until the lane is done
         with torch.cuda.stream(lane.stream):
             return self._run(self._resident(lane, frames))
 
@@ -190,7 +260,10 @@ class BatchTracker:
 
     def _run(self, frames):
         records = self.extract(frames)
-        gathered = allgather_records(records, self.world, self.group)  # [C * T_total, REC] camera-major when world > 1
+        if self.collective == "rccl":    # [C * T_total, REC] camera-major when world > 1
+            gathered = self._cur.ctx.allgather_centroids(records, self._cur.gathered)
+        else:
+            gathered = allgather_records(records, self.world, self.group, force=self.force_collective)
         return self.triangulate(gathered)
 
     def synchronize(self):
@@ -198,6 +271,23 @@ class BatchTracker:
         for lane in self.lanes:
             if lane.stream is not None:
                 lane.stream.synchronize()
+            else:
+                torch.cuda.current_stream(lane.ctx.device).synchronize()
+
+    def finish(self, out=None, first_step=0):
+        """Wait for the batch that produced `out` (default: the most recent one) and return its per-time-step root
+        counts as a host array.  Raises CapacityError when a time step failed (more image points in a camera than
+        max_points, a blob-stage capacity error, too many candidate groups): a batch is never answered with shortened
+        point lists."""
+        lane = self._cur
+        if out is not None:
+            lane = next((l for l in self.lanes if l.out is out), lane)
+        out = lane.out
+        if lane.stream is not None:
+            lane.stream.synchronize()
+        else:
+            torch.cuda.current_stream(lane.ctx.device).synchronize()
+        return check_status(out["n"].cpu().numpy(), first_step)
 
     def profile(self, on=True):
         """HIP-event timing of the kernels of every batch in flight (MocapContext.profile)."""

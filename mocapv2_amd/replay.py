@@ -72,15 +72,12 @@ class ReplayTracker:
                 pad = torch.zeros((self.batch - nb,) + tuple(chunk.shape[1:]), dtype=torch.uint8, device=dev)
                 chunk = torch.cat([chunk, pad], dim=0)
             out = self.tracker.step(chunk.reshape(self.batch * self.n_cam, self.height, self.width).contiguous())
-            self.tracker.synchronize()
-            n = out["n"].cpu().numpy()
+            n = self.tracker.finish(out, first_step=b0)  # raises CapacityError: no time step is answered from shortened lists
             xyz = out["xyz"].cpu().numpy()
             grp = out["grp"].cpu().numpy()
             order = out["order"].cpu().numpy()
             for s in range(nb):
                 k = int(n[s])
-                if k < 0:
-                    raise RuntimeError(f"time step {b0 + s}: correspondence capacity exceeded (status {k})")
                 if k == 0:
                     obj, img = np.array([]), np.array([])
                 else:

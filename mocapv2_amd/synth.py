@@ -80,10 +80,11 @@ class Scene:
             out.append(np.floor(px).astype(np.int64))
         return out
 
-    def render(self, rng, markers, cam, radius_range=(16.0, 22.0), noise_max=60, salt=0.0, distorted=True):
-        """uint8[H,W] frame of camera `cam`: discs (core 255, 1.5 px linear edge) over uniform noise."""
+    def render(self, rng, markers, cam, radius_range=(16.0, 22.0), noise_max=60, salt=0.0, distorted=True, noise_min=0):
+        """uint8[H,W] frame of camera `cam`: discs (core 255, 1.5 px linear edge) over uniform noise in
+        [noise_min, noise_max]."""
         H, W = self.height, self.width
-        img = rng.integers(0, noise_max + 1, size=(H, W), dtype=np.uint8)
+        img = rng.integers(noise_min, noise_max + 1, size=(H, W), dtype=np.uint8)
         if salt > 0:
             n = int(salt * H * W)
             img[rng.integers(0, H, n), rng.integers(0, W, n)] = 255

@@ -280,6 +280,56 @@ def test_sharded_pipeline_equals_single_rank():
             assert np.array_equal(out["order"][s, :k], ref_out["order"][sl][s, :k])
 
 
+@pytest.mark.parametrize("collective", ["rccl", "torch"])
+def test_one_rank_collective_through_rccl_equals_no_collective(collective):
+    """As much RCCL as one GPU allows: BatchTracker with three batches in flight and the exchange step forced on with
+    world = 1 -- through mocap_allgather_centroids (ncclCommInitRank + ncclAllGather behind the C-ABI, one communicator
+    per batch in flight, issued on the batch's own HIP stream) and through torch.distributed's nccl backend
+    (all_gather_into_tensor) -- gives bit for bit the results of the path without a collective."""
+    import torch
+    import torch.distributed as dist
+    from mocapv2_amd.pipeline import BatchTracker, scene_arrays
+    C, T, W, H = 3, 4, 640, 360
+    sc = Scene(C, W, H, dist=MILD_DIST)
+    arrays = scene_arrays(sc)
+    batches = [torch.from_numpy(sc.render_batch(seed=70 + b, n_steps=T, n_markers=4, radius_range=(16, 20)).reshape(T * C, H, W)).cuda()
+               for b in range(5)]
+    ref = BatchTracker(*arrays, W, H, T)
+    expected = []
+    for fr in batches:
+        out = ref.step(fr)
+        torch.cuda.synchronize()
+        expected.append({k: v.cpu().numpy().copy() for k, v in out.items()})
+    own_pg = False
+    if collective == "torch" and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        own_pg = True
+    try:
+        trk = BatchTracker(*arrays, W, H, T, depth=3, collective=collective, force_collective=True)
+        assert trk.collective == collective
+        outs = []
+        for fr in batches:
+            out = trk.step(fr)
+            n = trk.finish(out)  # the lane's buffers are reused three batches later: copy the results out now
+            outs.append({k: v.cpu().numpy().copy() for k, v in out.items()})
+            assert (n >= 0).all()
+        if collective == "rccl":
+            for lane in trk.lanes:  # the gathered copy is what correspondence read
+                assert torch.equal(lane.gathered, lane.records)
+    finally:
+        if own_pg:
+            dist.destroy_process_group()
+    assert any((e["n"] > 0).any() for e in expected)
+    for e, o in zip(expected, outs):
+        assert np.array_equal(e["n"], o["n"])
+        for s in range(T):
+            k = e["n"][s]
+            assert np.array_equal(e["xyz"][s, :k], o["xyz"][s, :k]) and np.array_equal(e["grp"][s, :k], o["grp"][s, :k])
+            assert np.array_equal(e["order"][s, :k], o["order"][s, :k])
+
+
 def test_replay_tracker_matches_per_frame_drop_in(helpers):
     """The batched headless tracker gives, per time step, what the reference's loops give for the same frames:
     _find_dot per camera, find_point_correspondance_and_object_points(..., 4), the msgpack message (with the
