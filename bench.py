@@ -203,7 +203,7 @@ def parity_report(results, records, out, n_cam, max_points):
             "oracle": "oracle/ C restatement (geometry half pinned to the reference, blob half parity unpinned: DESIGN.md 2)"}
 
 
-KERNELS = (("scan", "bright_cells_kernel"), ("patch", "undistort_patches_kernel"), ("filter", "filter_mask_kernel"))
+KERNELS = (("scan", "bright_cells_kernel"), ("settle", "settle_tiles_kernel"), ("filter", "box_filter_kernel"))
 
 
 def roofline_of(prof, wl, n_images, n_launch_groups, traffic_key):
@@ -257,7 +257,7 @@ def roofline_of(prof, wl, n_images, n_launch_groups, traffic_key):
 
 def kernel_ms(prof):
     n = prof["steps"]
-    return {"scan": round(prof["scan_ms"] / n, 4), "patches": round(prof["patch_ms"] / n, 4), "filter": round(prof["filter_ms"] / n, 4),
+    return {"scan": round(prof["scan_ms"] / n, 4), "settle": round(prof["settle_ms"] / n, 4), "filter": round(prof["filter_ms"] / n, 4),
             "contours": round(prof["contour_ms"] / n, 4), "correspond": round(prof["corr_ms"] / n, 4)}
 
 

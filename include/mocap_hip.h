@@ -37,7 +37,7 @@ enum {
     MOCAP_BLOB_E_STEPS = -4,      /* a border longer than the step limit */
     MOCAP_BLOB_E_DEPTH = -5,      /* a kept contour nested deeper than 8 levels */
     MOCAP_CORR_E_GROUPS = -2,     /* more than 16 candidates for one (root, camera), > max_groups groups for one root, or
-                                     > max(max_groups, 8192) groups in the whole time step */
+                                     > max(2 * max_groups, 8192) groups in the whole time step */
     MOCAP_CORR_E_TRUNCATED = -3,  /* a camera holds more image points than the P that mocap_correspond was told to read */
     MOCAP_CORR_E_BLOB = -4        /* a camera's point count is negative: its blob stage reported MOCAP_BLOB_E_* */
 };
@@ -200,8 +200,8 @@ MOCAP_API int mocap_allgather_centroids(mocap_ctx_t ctx, const int32_t* local_re
 MOCAP_API int mocap_tile_stats(mocap_ctx_t ctx, uint64_t* tiles, uint64_t* skipped);
 /* HIP-event timing of the kernels launched by mocap_blob_centroids / mocap_filter_mask / mocap_correspond, recorded
  * on their stream.  mocap_profile_read synchronises, returns accumulated milliseconds and launch counts and resets:
- * index 0 = filter_mask_kernel, 1 = contours_kernel, 2 = correspond_kernel, 3 = bright_cells_kernel,
- * 4 = undistort_patches_kernel. */
+ * index 0 = box_filter_kernel (or the general filter_mask_kernel), 1 = contours_kernel, 2 = correspond_kernel,
+ * 3 = bright_cells_kernel, 4 = settle_tiles_kernel. */
 MOCAP_API int mocap_profile_enable(mocap_ctx_t ctx, int on);
 MOCAP_API int mocap_profile_read(mocap_ctx_t ctx, double ms[5], int launches[5]);
 

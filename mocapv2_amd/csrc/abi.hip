@@ -41,21 +41,25 @@ struct EvPair { hipEvent_t a, b; };
 
 struct mocap_ctx {
     int device, W, H, n_slots, wpr;
+    int box_grid;             // workgroups of the box kernel: 8 single-wave workgroups per CU
     mocap_blob_params prm;
-    uint32_t* maps;           // [2][n_slots][H][W]: tap positions, then blend weights
-    uint32_t* map_flags;      // [n_slots] device, followed by the two early-out tile counters
+    uint32_t* maps;           // [2][n_slots][H][W]: tap positions, then blend weights (general form)
+    uint32_t* map4;           // [n_slots][H][W] (+ 4 words): compact table of the box kernel
+    ushort4* srcbox;          // [n_slots][ceil(H/8)][ceil(W/8)]: source box per 8x8 output cell (box kernel)
+    uint32_t* map_flags;      // [n_slots] device
     std::vector<int> slot_state; // 0 unset, 1 identity, 2 remap
+    std::vector<int> slot_compact; // 1 = the slot's displacements fit the compact table (identity: always)
     std::vector<uint32_t> slot_wmax; // largest total blend weight of a source pixel (1024 = identity); 0 = early-out not provable
-    std::vector<int> slot_mode;  // remap kernel variant the slot's table admits: 2 per-pixel, 3 pipelined gather, 4 LDS-staged
-    uint2* spans;             // [n_slots][n_strips][H] source row / column spans per strip row
     uint2* reach;             // [n_slots][ceil(H/8)][ceil(W/8)] per 8x8 source cell: box of the output pixels that read it
     uint8_t* cflags;          // [n_slots][cells] border-cut window flags per source cell (see BrightArgs)
     uint32_t* mask; size_t mask_images;
-    uint32_t* cells; size_t cells_images; // occupancy cells written by the filter kernel for c->mask
+    bool mask_dirty;                       // the general kernel wrote the mask whole: clear it before the box path runs again
+    uint32_t* cells; size_t cells_images; // occupancy cells written by the filter kernels for c->mask
     int last_images;                       // images of the most recent batch that wrote c->cells
-    uint32_t* tile_rows;                   // [mask_images][tiles][2] reachable mask rows per tile, beside cells (see FilterArgs)
-    uint8_t* patch; size_t patch_images;   // undistorted boxes of the marked tiles (see FilterArgs)
-    uint32_t* cells_ext; size_t cells_ext_images; // occupancy words of caller-owned masks (mocap_filter_mask)
+    uint32_t* tile_rows;                   // [mask_images][tiles][4] the scan's box per tile, beside cells (see BoxArgs)
+    uint32_t* cur_box;                     // [mask_images][tiles][4] output region / scan box of the last batch per tile (BoxArgs)
+    BoxItem* items; uint32_t* n_items; uint32_t cap_items; // work list of the box kernel
+    uint32_t* cells_ext; uint32_t* cur_box_ext; size_t cells_ext_images; // the same for caller-owned masks (mocap_filter_mask)
     void* cwork; size_t cwork_images;      // contour kernel workspace, contour_work_bytes() per image
     CameraTable* cams; int n_cam, n_F;
     double* scratch; size_t scratch_elems;
@@ -71,10 +75,9 @@ struct Tiling { int rows, n_cgroups, n_strips; };
 static Tiling tiling(const mocap_ctx* c)
 {
     Tiling t;
-    // Rows per wave.  Must be <= 136 so that a chunk's 8-row groups fit one 32-bit occupancy word.  68 (x4 waves = 272
-    // rows per workgroup): measured within 1 % of 34 / 45 / 136 with the row-range early-out, 4 % better than 24.
+    // Rows per tile.  Must be <= 68: settle_tiles_kernel cuts a tile into at most 4 items of BOX_HCAP quad-rows.
     t.rows = 68;
-    { const char* e = getenv("MOCAP_ROWS"); if (e && atoi(e) >= 16 && atoi(e) <= 136) t.rows = atoi(e); } // A/B switch
+    { const char* e = getenv("MOCAP_ROWS"); if (e && atoi(e) >= 16 && atoi(e) <= 68) t.rows = atoi(e); } // A/B switch
     if (c->H < 4 * 32) t.rows = (c->H + 3) / 4 > 8 ? (c->H + 3) / 4 : 8;
     t.n_cgroups = (c->H + 4 * t.rows - 1) / (4 * t.rows);
     t.n_strips = (c->W + 239) / 240;
@@ -83,48 +86,6 @@ static Tiling tiling(const mocap_ctx* c)
 
 static size_t source_cells(const mocap_ctx* c) { return (size_t)((c->H + 7) / 8) * ((c->W + 7) / 8); }
 static size_t cells_per_image(const mocap_ctx* c) { Tiling t = tiling(c); return (size_t)t.n_cgroups * 4 * t.n_strips; }
-
-// Can the LDS-staged remap kernel serve this slot?  Replays, per (strip, chunk), the kernel's ring schedule on the
-// span table: ring width, rows resident when they are read, at most two new rows per step.
-static bool lds_remap_ok(const mocap_ctx* c, const std::vector<uint2>& sp)
-{
-    if (c->W < 8 || (c->W & 3) || c->H < 2) return false;
-    Tiling t = tiling(c);
-    const int H = c->H, Hm1 = H - 1;
-    auto clampr = [&](int r) { return r < 0 ? 0 : (r > Hm1 ? Hm1 : r); };
-    for (int st = 0; st < t.n_strips; st++) {
-        const uint2* s = sp.data() + (size_t)st * H;
-        auto smin = [&](int r) { return (int)(s[clampr(r)].x & 0xffffu); };
-        auto smax = [&](int r) { return (int)(s[clampr(r)].x >> 16); };
-        for (int ch = 0; ch * t.rows < H; ch++) {
-            int r0 = ch * t.rows, r1 = r0 + t.rows < H ? r0 + t.rows : H;
-            int kfirst = clampr(r0 - 2), ke = r1 + 1 < Hm1 ? r1 + 1 : Hm1;
-            int y0 = kfirst - 2, last = (ke > kfirst ? ke : kfirst) + 2;
-            int xmin = 0x7fff, xmax = 0;
-            for (int r = clampr(y0); r <= clampr(last); r++) {
-                int lo = (int)(s[r].y & 0xffffu), hi = (int)(s[r].y >> 16);
-                xmin = lo < xmin ? lo : xmin; xmax = hi > xmax ? hi : xmax;
-            }
-            if (xmax - (xmin & ~7) + 1 > RING_W) return false;
-            int hi_w = smax(y0);
-            for (int r = y0; r <= y0 + RING_LOOKAHEAD - 1; r++) hi_w = smax(r) > hi_w ? smax(r) : hi_w; // prologue fill
-            if (hi_w - smin(y0) + 1 > RING_H) return false;
-            int loaded = hi_w;
-            for (int r = y0; r <= last + 1; r++) { // r = row whose taps are read; requests run RING_LOOKAHEAD rows ahead
-                int need = smax(r + RING_LOOKAHEAD);
-                if (need - loaded > 2) return false;
-                loaded = need > loaded ? need : loaded;
-                // rows written by the time row r+1 is read: everything requested up to step r-4, i.e. need of rows <= r+1
-                int written = hi_w;
-                for (int q = y0; q <= r + 1; q++) written = smax(q) > written ? smax(q) : written;
-                if (smax(r + 1) > written || smin(r + 1) < written - (RING_H - 1)) return false;
-                // and nothing still needed may be overwritten by what is already requested (<= loaded)
-                if (smin(r + 1) < loaded - (RING_H - 1)) return false;
-            }
-        }
-    }
-    return true;
-}
 
 // ---- RCCL, bound at run time -----------------------------------------------------------------------------------
 // The path's one exchange is an ncclAllGather of centroid records.  librccl is looked up with dlopen
@@ -185,14 +146,24 @@ int mocap_ctx_create(int device_id, int width, int height, int n_slots, mocap_ct
     mocap_ctx* c = new mocap_ctx();
     c->device = device_id; c->W = width; c->H = height; c->n_slots = n_slots; c->wpr = (width + 31) / 32;
     c->prm = mocap_blob_params{5, 5, 255 * 0.85, 500.0, 0.5};
-    c->maps = nullptr; c->spans = nullptr; c->reach = nullptr; c->cflags = nullptr; c->cells_ext = nullptr; c->cells_ext_images = 0; c->map_flags = nullptr; c->mask = nullptr; c->mask_images = 0; c->cells = nullptr; c->cells_images = 0; c->last_images = 0; c->tile_rows = nullptr; c->patch = nullptr; c->patch_images = 0; c->cwork = nullptr; c->cwork_images = 0;
+    c->maps = nullptr; c->map4 = nullptr; c->srcbox = nullptr; c->reach = nullptr; c->cflags = nullptr; c->map_flags = nullptr;
+    c->mask = nullptr; c->mask_images = 0; c->mask_dirty = false; c->cells = nullptr; c->cells_images = 0; c->last_images = 0;
+    c->tile_rows = nullptr; c->cur_box = nullptr; c->items = nullptr; c->n_items = nullptr; c->cap_items = 0;
+    c->cells_ext = nullptr; c->cur_box_ext = nullptr; c->cells_ext_images = 0; c->cwork = nullptr; c->cwork_images = 0;
     c->cams = nullptr; c->n_cam = 0; c->n_F = 0; c->scratch = nullptr; c->scratch_elems = 0; c->profiling = false;
     c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1;
+    {
+        hipDeviceProp_t prop;
+        c->box_grid = 2048;
+        if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->box_grid = 8 * prop.multiProcessorCount;
+    }
     c->slot_state.assign(n_slots, 0);
-    c->slot_mode.assign(n_slots, 2);
+    c->slot_compact.assign(n_slots, 0);
     c->slot_wmax.assign(n_slots, 0);
     hipError_t e = hipMalloc(&c->map_flags, sizeof(uint32_t) * n_slots + 256);
     if (e == hipSuccess) e = hipMemset(c->map_flags, 0, sizeof(uint32_t) * n_slots + 256);
+    if (e == hipSuccess) e = hipMalloc(&c->n_items, 256);
+    if (e == hipSuccess) e = hipMemset(c->n_items, 0, 256);
     if (e == hipSuccess) e = hipMalloc(&c->cams, sizeof(CameraTable));
     if (e == hipSuccess) e = hipMemset(c->cams, 0, sizeof(CameraTable));
     if (e != hipSuccess) {
@@ -210,7 +181,12 @@ int mocap_ctx_destroy(mocap_ctx_t c)
     for (auto& v : c->ev) for (auto& p : v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (c->comm && g_rccl.lib) { (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
     if (c->maps) (void)hipFree(c->maps);
-    if (c->spans) (void)hipFree(c->spans);
+    if (c->map4) (void)hipFree(c->map4);
+    if (c->srcbox) (void)hipFree(c->srcbox);
+    if (c->cur_box) (void)hipFree(c->cur_box);
+    if (c->cur_box_ext) (void)hipFree(c->cur_box_ext);
+    if (c->items) (void)hipFree(c->items);
+    if (c->n_items) (void)hipFree(c->n_items);
     if (c->reach) (void)hipFree(c->reach);
     if (c->cflags) (void)hipFree(c->cflags);
     if (c->cells_ext) (void)hipFree(c->cells_ext);
@@ -218,7 +194,6 @@ int mocap_ctx_destroy(mocap_ctx_t c)
     if (c->mask) (void)hipFree(c->mask);
     if (c->cells) (void)hipFree(c->cells);
     if (c->tile_rows) (void)hipFree(c->tile_rows);
-    if (c->patch) (void)hipFree(c->patch);
     if (c->cwork) (void)hipFree(c->cwork);
     if (c->cams) (void)hipFree(c->cams);
     if (c->scratch) (void)hipFree(c->scratch);
@@ -252,12 +227,16 @@ int mocap_set_undistort(mocap_ctx_t c, int slot, const double K[9], const double
     std::lock_guard<std::mutex> lk(c->mu);
     size_t per = (size_t)c->H * c->W;
     if (!c->maps) HIP_TRY(hipMalloc(&c->maps, sizeof(uint32_t) * per * c->n_slots * 2));
+    if (!c->map4) HIP_TRY(hipMalloc(&c->map4, sizeof(uint32_t) * (per * c->n_slots + 4))); // + 4: a quad load at the last pixel stays inside
+    const int ncx_ = (c->W + 7) / 8, ncy_ = (c->H + 7) / 8;
+    if (!c->srcbox) HIP_TRY(hipMalloc(&c->srcbox, sizeof(ushort4) * (size_t)ncx_ * ncy_ * c->n_slots));
     MapArgs m;
     memcpy(m.K, K, sizeof(m.K));
     memcpy(m.dist, dist, sizeof(m.dist));
     m.H = c->H; m.W = c->W;
     m.map = c->maps + per * slot;
     m.mapw = c->maps + per * (c->n_slots + slot);
+    m.map4 = c->map4 + per * slot;
     m.flags = c->map_flags + slot;
     HIP_TRY(hipMemset(m.flags, 0, sizeof(uint32_t)));
     launch_undistort_map(m, 0);
@@ -265,23 +244,14 @@ int mocap_set_undistort(mocap_ctx_t c, int slot, const double K[9], const double
     uint32_t flags = 0;
     HIP_TRY(hipMemcpy(&flags, m.flags, sizeof(flags), hipMemcpyDeviceToHost));
     c->slot_state[slot] = (flags & 1u) ? 2 : 1;
-    c->slot_mode[slot] = 2;
+    c->slot_compact[slot] = (flags & 2u) ? 0 : 1;
     c->slot_wmax[slot] = c->slot_state[slot] == 1 ? 1024u : 0u; // identity: every source pixel feeds exactly one output pixel
-    Tiling tl = tiling(c);
-    const int ncx_ = (c->W + 7) / 8, ncy_ = (c->H + 7) / 8;
+    launch_srcbox(m.map4, c->srcbox + (size_t)ncx_ * ncy_ * slot, c->H, c->W, 0);
+    HIP_TRY(hipGetLastError());
     std::vector<uint32_t> edge((size_t)ncx_ * ncy_, 0); // source cells read by windows that the image border cuts: bit 0 one axis, bit 1 both
     std::vector<int> reach32((size_t)ncx_ * ncy_ * 4);  // per source cell: x0, x1, y0, y1 of the output pixels that read it
     for (size_t i = 0; i < reach32.size(); i += 2) { reach32[i] = 0x7fffffff; reach32[i + 1] = -0x7fffffff - 1; }
     if (c->slot_state[slot] == 2) {
-        size_t nsp = (size_t)tl.n_strips * c->H;
-        if (!c->spans) HIP_TRY(hipMalloc(&c->spans, sizeof(uint2) * nsp * c->n_slots));
-        SpanArgs sa{m.map, c->spans + nsp * slot, c->H, c->W, tl.n_strips};
-        launch_remap_spans(sa, 0);
-        HIP_TRY(hipGetLastError());
-        std::vector<uint2> sp(nsp);
-        HIP_TRY(hipMemcpy(sp.data(), sa.spans, sizeof(uint2) * nsp, hipMemcpyDeviceToHost));
-        if (lds_remap_ok(c, sp)) c->slot_mode[slot] = 4;
-        else if (c->W >= 4 && (c->W & 3) == 0 && c->H >= 2) c->slot_mode[slot] = 3;
         // statistics for the dark-tile early-out (see blob_filter.hip): total weight per source pixel, tap extents
         uint32_t* tmp = nullptr;
         const size_t edge_words = edge.size();
@@ -433,39 +403,65 @@ static int check_frames(mocap_ctx* c, const void* frames, int n_images, int cam_
 }
 
 
+// Excess base of the scan (BrightArgs::base): pixels count with max(0, p - c).  Exact for any c below the threshold; a
+// higher c ignores brighter backgrounds, a lower c lets a cell hold more bright pixels before it is "hot".
+static int excess_base(int thr_mul)
+{
+    int c = thr_mul - 67; // 150 for the reference's threshold (216.75): backgrounds up to ~150 cost nothing, 4 saturated pixels make a cell hot
+    { const char* e = getenv("MOCAP_EXCESS_BASE"); if (e) c = atoi(e); } // A/B switch
+    if (c > thr_mul - 1) c = thr_mul - 1;
+    if (c > 254) c = 254;
+    return c < 0 ? 0 : c;
+}
+
 // bayer != nullptr: `frames` (= bayer->dst) does not exist yet -- the Bayer -> gray pass that writes it runs first, fused
 // with the streaming scan where the geometry allows (it has the gray bytes in registers anyway)
 static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mod, int slot_base, size_t image_stride,
                       int pitch, uint32_t* mask, uint32_t* cells, hipStream_t s, const BayerArgs* bayer = nullptr)
 {
-    FilterArgs a;
-    a.src = (const uint8_t*)frames; a.image_stride = image_stride; a.pitch = pitch; a.H = c->H; a.W = c->W;
-    a.aligned4 = (((uintptr_t)frames | (uintptr_t)pitch | (uintptr_t)image_stride) & 3) == 0;
-    a.mask = mask; a.words_per_row = c->wpr; a.cam_mod = cam_mod;
-    a.cells = cells;
-    a.map = c->maps ? c->maps + (size_t)slot_base * c->H * c->W : nullptr;
-    a.mapw = c->maps ? c->maps + (size_t)(c->n_slots + slot_base) * c->H * c->W : nullptr;
-    a.n_images = n_images; a.n_steps = (n_images + cam_mod - 1) / cam_mod;
     double ft = floor(c->prm.thresh);
-    a.thr_mul = ft < -1.0 ? 0 : (ft > 255.0 ? 256 : (int)ft + 1);
-    // four waves per workgroup, each sliding over rows_per_chunk rows (+8 halo rows)
+    const int thr_mul = ft < -1.0 ? 0 : (ft > 255.0 ? 256 : (int)ft + 1);
     Tiling tl = tiling(c);
-    a.n_strips = tl.n_strips; a.rows_per_chunk = tl.rows; a.n_cgroups = tl.n_cgroups;
-    bool remap = false;
-    int mode = 4;
+    const bool own_mask = mask == c->mask; // the context's mask keeps "zero outside the recorded regions" from batch to batch
+    bool remap = false, compact = c->W >= 8 && cam_mod <= 64;
+    uint64_t remap_bits = 0;
     for (int sl = slot_base; sl < slot_base + cam_mod; sl++) {
-        remap |= c->slot_state[sl] == 2;
-        // an identity slot inside a remapped batch has no span table: it takes the gather path with its identity table
-        int m = c->slot_state[sl] == 2 ? c->slot_mode[sl] : ((c->W >= 4 && (c->W & 3) == 0 && c->H >= 2) ? 3 : 2);
-        mode = m < mode ? m : mode;
+        if (c->slot_state[sl] == 2) { remap = true; if (sl - slot_base < 64) remap_bits |= 1ull << (sl - slot_base); }
+        if (c->slot_state[sl] == 2 && !c->slot_compact[sl]) compact = false;
     }
-    // Default: the pipelined gather kernel (3).  The LDS-staged kernel (4) is bit-identical but measured slower on
-    // MI355X so far, so it is opt-in: MOCAP_REMAP_MODE=4; 2 or 3 force a simpler variant (tests).
-    { const char* e = getenv("MOCAP_REMAP_MODE"); int cap = e ? atoi(e) : 3; if (cap < 2) cap = 3; if (cap < mode) mode = cap; }
-    a.remap_mode = mode;
-    int allow_cut1 = -1, allow_cut2 = -1;
-    // dark-tile early-out: largest doubled excess sum 2E (E = sum of max(0, p - 63)) per 16x16 block that still proves an
-    // all-zero mask:   2E * Wmax < 1024 * taps_min * (2 * thr_mul - 2 * 64 + 1)     (derivation: blob_filter.hip)
+    { const char* e = getenv("MOCAP_GENERAL_FILTER"); if (e && atoi(e) != 0) compact = false; } // test switch: the general kernel
+    if (cells == c->cells) c->last_images = n_images;
+    EvPair p; bool on;
+    if (!compact) {
+        // general dense kernel (tiny images, tables beyond the compact format): every tile, every mask byte
+        FilterArgs a;
+        a.src = (const uint8_t*)frames; a.image_stride = image_stride; a.pitch = pitch; a.H = c->H; a.W = c->W;
+        a.mask = mask; a.words_per_row = c->wpr; a.cam_mod = cam_mod; a.cells = cells;
+        a.map = c->maps ? c->maps + (size_t)slot_base * c->H * c->W : nullptr;
+        a.mapw = c->maps ? c->maps + (size_t)(c->n_slots + slot_base) * c->H * c->W : nullptr;
+        a.n_images = n_images; a.n_steps = (n_images + cam_mod - 1) / cam_mod;
+        a.thr_mul = thr_mul;
+        a.n_strips = tl.n_strips; a.rows_per_chunk = tl.rows; a.n_cgroups = tl.n_cgroups;
+        if (bayer) { launch_bayer_gray(*bayer, s); HIP_TRY(hipGetLastError()); }
+        if (own_mask) c->mask_dirty = true;
+        prof_begin(c, 0, s, p, on);
+        launch_filter_mask(a, remap, s);
+        prof_end(c, 0, s, p, on);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    if (own_mask && c->mask_dirty) { // the general kernel wrote the whole mask last time: back to "zero outside the regions"
+        HIP_TRY(hipMemsetAsync(c->mask, 0, sizeof(uint32_t) * c->mask_images * c->H * c->wpr, s));
+        std::vector<uint32_t> init(c->mask_images * cells_per_image(c) * 4);
+        for (size_t i = 0; i < init.size(); i += 4) { init[i] = 1u; init[i + 1] = 1u; init[i + 2] = 1u; init[i + 3] = 1u; }
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipMemcpy(c->cur_box, init.data(), sizeof(uint32_t) * init.size(), hipMemcpyHostToDevice));
+        c->mask_dirty = false;
+    }
+    // dark-tile early-out: largest doubled excess sum 2E (E = sum of max(0, p - base)) per 16x16 block that still proves an
+    // all-zero mask:   2E * Wmax < 1024 * taps_min * (2 * thr_mul - 2 * base - 1)     (derivation: blob_filter.hip)
+    const int base = excess_base(thr_mul);
+    int allow = -1, allow_cut1 = -1, allow_cut2 = -1;
     {
         long long wmax = 0;
         bool ok = true;
@@ -475,10 +471,8 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
         }
         auto t5 = [](int n) { return (n - 1 < 2 ? n - 1 : 2) + 1; }; // taps of a window at the border, per axis
         auto t5full = [](int n) { return n < 5 ? n : 5; };
-        const long long per_tap = 1024LL * (2LL * a.thr_mul - 127);
-        int allow = -1;
-        allow_cut1 = allow_cut2 = -1;
-        if (c->W < 8 || !c->tile_rows || !c->reach || !c->cflags) ok = false;
+        const long long per_tap = 1024LL * (2LL * thr_mul - 2LL * base - 1);
+        if (!c->tile_rows || !c->reach || !c->cflags) ok = false;
         if (ok && wmax > 0 && per_tap > 0) {
             allow = (int)((per_tap * t5full(c->W) * t5full(c->H) - 1) / wmax); // windows with all their taps
             const long long taps1 = t5(c->W) * t5full(c->H) < t5full(c->W) * t5(c->H) ? t5(c->W) * t5full(c->H) : t5full(c->W) * t5(c->H);
@@ -486,41 +480,37 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
             allow_cut2 = (int)((per_tap * t5(c->W) * t5(c->H) - 1) / wmax);    // smallest window cut in both
         }
         { const char* e = getenv("MOCAP_SKIP_DARK"); if (e && atoi(e) == 0) allow = -1; }
-        a.skip_allow = allow;
     }
-    if (cells == c->cells) c->last_images = n_images;
-    a.spans = c->spans ? c->spans + (size_t)slot_base * tiling(c).n_strips * c->H : nullptr;
-    const bool own_mask = mask == c->mask; // the context's mask keeps "zero unless filtered" from batch to batch
-    a.tile_rows = c->tile_rows; a.ext_mask = own_mask ? 0 : 1;
-    // Remapped cameras with the early-out: undistort only the boxes hot cells can reach into per-tile patches and run
-    // the plain pipeline on them (MOCAP_PATCH=0: gather in the filter kernel for every filtered row instead).
-    a.patch = nullptr;
-    {
-        bool all_remap = true;
-        for (int sl = slot_base; sl < slot_base + cam_mod; sl++) all_remap &= c->slot_state[sl] == 2 && c->slot_mode[sl] >= 3;
-        const char* e = getenv("MOCAP_PATCH");
-        if (a.skip_allow >= 0 && all_remap && !(e && atoi(e) == 0)) {
-            if ((size_t)n_images > c->patch_images) {
-                std::lock_guard<std::mutex> lk(c->mu);
-                if (c->patch) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c->patch)); c->patch = nullptr; c->patch_images = 0; }
-                if (hipMalloc(&c->patch, (size_t)n_images * cells_per_image(c) * (tl.rows + 8) * 256) == hipSuccess)
-                    c->patch_images = n_images;
-                else { (void)hipGetLastError(); c->patch = nullptr; } // no room for patches: gather in the filter kernel instead
-            }
-            a.patch = c->patch;
-        }
-    }
-    EvPair p; bool on;
-    if (a.skip_allow >= 0) { // one streaming pass over the frames marks the tiles that can hold set pixels
+    BoxArgs a;
+    a.src = (const uint8_t*)frames; a.image_stride = image_stride; a.pitch = pitch; a.H = c->H; a.W = c->W;
+    a.mask = mask; a.words_per_row = c->wpr; a.cells = cells;
+    a.map4 = c->map4 ? c->map4 + (size_t)slot_base * c->H * c->W : nullptr;
+    a.srcbox = c->srcbox ? c->srcbox + (size_t)slot_base * source_cells(c) : nullptr;
+    a.remap_bits = remap_bits;
+    a.cam_mod = cam_mod; a.n_images = n_images; a.n_steps = (n_images + cam_mod - 1) / cam_mod;
+    a.thr_mul = thr_mul;
+    a.rows_per_chunk = tl.rows; a.n_strips = tl.n_strips; a.n_chunks = tl.n_cgroups * 4;
+    a.tile_rows = c->tile_rows;
+    a.cur_box = own_mask ? c->cur_box : c->cur_box_ext;
+    a.items = c->items; a.n_items = c->n_items; a.cap_items = c->cap_items;
+    a.dense = allow < 0;
+    a.stage_bytes = BOX_SCAP;
+    a.prio = 0;
+    { const char* e = getenv("MOCAP_BOX_PRIO"); if (e) a.prio = atoi(e) != 0; } // A/B switch
+    { const char* e = getenv("MOCAP_BOX_STAGE_BYTES"); if (e && atoi(e) >= 0 && atoi(e) < BOX_SCAP) a.stage_bytes = atoi(e); } // test switch
+    a.ext_mask = own_mask ? 0 : 1;
+    if ((size_t)n_images * cells_per_image(c) * 4 > (size_t)c->cap_items) return fail(MOCAP_E_STATE, "work list smaller than the batch");
+    HIP_TRY(hipMemsetAsync(c->n_items, 0, sizeof(uint32_t), s));
+    if (!a.dense) { // one streaming pass over the frames marks the tiles (and their boxes) that can hold set pixels
         // floor(i / ncx) = umulhi(i, ceil(2^32 / ncx)) is exact while i * ncx < 2^32
         uint64_t ncx64 = (uint64_t)((c->W + 7) / 8);
         const uint64_t ncells = ncx64 * (uint64_t)((c->H + 7) / 8);
-        int wide = (c->W % 16 == 0) && (a.pitch % 16 == 0) && (a.image_stride % 16 == 0) && (((uintptr_t)a.src & 15) == 0) && ncx64 >= 4;
+        int wide = (c->W % 16 == 0) && (pitch % 16 == 0) && (image_stride % 16 == 0) && (((uintptr_t)frames & 15) == 0) && ncx64 >= 4;
         if (wide && ncells * (ncx64 / 2) >= (1ull << 32)) wide = 0;
         { const char* e = getenv("MOCAP_SCAN_WIDE"); if (e && atoi(e) == 0) wide = 0; } // A/B switch
         if (wide) ncx64 /= 2; // the wide kernel divides pair indices by the pairs per cell row
         const uint32_t ncx_magic = (ncx64 > 1 && ncells * ncx64 < (1ull << 32)) ? (uint32_t)(((1ull << 32) + ncx64 - 1) / ncx64) : 0u;
-        BrightArgs b{a.src, a.image_stride, a.pitch, a.H, a.W, n_images, cam_mod, ncx_magic, wide, a.skip_allow / 4, allow_cut1 / 4, allow_cut2 / 4,
+        BrightArgs b{(const uint8_t*)frames, image_stride, pitch, c->H, c->W, n_images, cam_mod, ncx_magic, wide, base, allow / 4, allow_cut1 / 4, allow_cut2 / 4,
                      c->reach + (size_t)slot_base * source_cells(c), c->cflags + (size_t)slot_base * source_cells(c),
                      c->tile_rows, tl.n_cgroups * 4, tl.n_strips, (uint32_t)(((1u << 23) + tl.rows - 1) / tl.rows),
                      mask, own_mask ? 0 : (size_t)n_images * c->H * c->wpr, ((uintptr_t)mask & 15) == 0};
@@ -537,14 +527,12 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
         launch_bayer_gray(*bayer, s);
         HIP_TRY(hipGetLastError());
     }
-    if (a.patch) {
-        prof_begin(c, 4, s, p, on);
-        launch_undistort_patches(a, s);
-        prof_end(c, 4, s, p, on);
-        HIP_TRY(hipGetLastError());
-    }
+    prof_begin(c, 4, s, p, on);
+    launch_settle_tiles(a, s);
+    prof_end(c, 4, s, p, on);
+    HIP_TRY(hipGetLastError());
     prof_begin(c, 0, s, p, on);
-    launch_filter_mask(a, remap, s);
+    launch_box_filter(a, c->box_grid, s);
     prof_end(c, 0, s, p, on);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -626,11 +614,21 @@ static int ensure_mask(mocap_ctx* c, int n_images)
     HIP_TRY(hipMemset(c->cells, 0, cbytes));
     c->cells_images = n_images;
     if (c->tile_rows) { HIP_TRY(hipFree(c->tile_rows)); c->tile_rows = nullptr; }
-    {   // every tile starts with the empty range (0xffffffff, 0)
+    if (c->cur_box) { HIP_TRY(hipFree(c->cur_box)); c->cur_box = nullptr; }
+    if (c->items) { HIP_TRY(hipFree(c->items)); c->items = nullptr; c->cap_items = 0; }
+    {   // every tile starts with the empty box (0xffffffff, 0) and an empty recorded region (x0 = 1 > x1 = 0)
         std::vector<uint32_t> init((size_t)n_images * cells_per_image(c) * 4);
         for (size_t i = 0; i < init.size(); i += 2) { init[i] = 0xffffffffu; init[i + 1] = 0u; }
         HIP_TRY(hipMalloc(&c->tile_rows, sizeof(uint32_t) * init.size()));
         HIP_TRY(hipMemcpy(c->tile_rows, init.data(), sizeof(uint32_t) * init.size(), hipMemcpyHostToDevice));
+        for (size_t i = 0; i < init.size(); i++) init[i] = 1u;
+        HIP_TRY(hipMalloc(&c->cur_box, sizeof(uint32_t) * init.size()));
+        HIP_TRY(hipMemcpy(c->cur_box, init.data(), sizeof(uint32_t) * init.size(), hipMemcpyHostToDevice));
+        const size_t cap = (size_t)n_images * cells_per_image(c) * 4; // settle_tiles_kernel cuts a tile into at most 4 items
+        if (cap > 0xffffffffull) return fail(MOCAP_E_UNSUPPORTED, "batch too large for the work list");
+        HIP_TRY(hipMalloc(&c->items, sizeof(BoxItem) * cap));
+        c->cap_items = (uint32_t)cap;
+        c->mask_dirty = false;
     }
     return 0;
 }
@@ -647,6 +645,8 @@ int mocap_filter_mask(mocap_ctx_t c, const void* frames, int n_images, int cam_m
         std::lock_guard<std::mutex> lk(c->mu);
         if (c->cells_ext) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c->cells_ext)); c->cells_ext = nullptr; c->cells_ext_images = 0; }
         HIP_TRY(hipMalloc(&c->cells_ext, sizeof(uint32_t) * (size_t)n_images * cells_per_image(c)));
+        if (c->cur_box_ext) { HIP_TRY(hipFree(c->cur_box_ext)); c->cur_box_ext = nullptr; }
+        HIP_TRY(hipMalloc(&c->cur_box_ext, sizeof(uint32_t) * 4 * (size_t)n_images * cells_per_image(c)));
         c->cells_ext_images = n_images;
     }
     return run_filter(c, frames, n_images, cam_mod, slot_base, image_stride, pitch, mask_dev, c->cells_ext, (hipStream_t)stream);
@@ -736,21 +736,17 @@ int mocap_image_filter_u8(mocap_ctx_t c, const void* src, void* dst, int spitch,
     }
     int rc = ensure_mask(c, 1);
     if (rc) return rc;
-    // the fused kernel with a one-image batch; slot < 0 = no undistortion
+    // the general kernel with a one-image batch; slot < 0 = no undistortion
     FilterArgs a;
     a.src = (const uint8_t*)src; a.image_stride = 0; a.pitch = spitch; a.H = c->H; a.W = c->W;
-    a.aligned4 = (((uintptr_t)src | (uintptr_t)spitch) & 3) == 0;
     a.mask = c->mask; a.words_per_row = c->wpr; a.cam_mod = 1; a.n_images = 1; a.n_steps = 1;
     a.cells = c->cells;
     a.map = slot >= 0 ? c->maps + (size_t)slot * c->H * c->W : nullptr;
     a.mapw = slot >= 0 ? c->maps + (size_t)(c->n_slots + slot) * c->H * c->W : nullptr;
-    a.remap_mode = slot >= 0 ? c->slot_mode[slot] : 0;
-    a.skip_allow = -1; // single-image convenience path: no early-out
-    a.tile_rows = nullptr; a.ext_mask = 1; a.patch = nullptr;
-    a.spans = (slot >= 0 && c->spans) ? c->spans + (size_t)slot * tiling(c).n_strips * c->H : nullptr;
     a.thr_mul = ithresh + 1;
     Tiling tl = tiling(c);
     a.n_strips = tl.n_strips; a.rows_per_chunk = tl.rows; a.n_cgroups = tl.n_cgroups;
+    c->mask_dirty = true; c->last_images = 1;
     launch_filter_mask(a, slot >= 0 && c->slot_state[slot] == 2, s);
     HIP_TRY(hipGetLastError());
     launch_mask_expand(c->mask, c->wpr, (uint8_t*)dst, c->H, c->W, dpitch, s);
@@ -873,8 +869,8 @@ int mocap_correspond(mocap_ctx_t c, const void* pts, long pt_st, long pt_sc, con
         return fail(MOCAP_E_UNSUPPORTED, "P=%d points x C=%d cameras needs %zu bytes of LDS (> 64 KiB)", P, C, correspond_smem_bytes(P, C));
     if (set_device(c)) return MOCAP_E_HIP;
     // error scratch: the groups of one time step lie back to back, so a step needs room for its total, not P x max_groups;
-    // a step with more than max(max_groups, 8192) groups in all reports MOCAP_CORR_E_GROUPS
-    size_t budget = (size_t)max_groups > 8192 ? (size_t)max_groups : 8192;
+    // a step with more than max(2 * max_groups, 8192) groups in all reports MOCAP_CORR_E_GROUPS
+    size_t budget = 2 * (size_t)max_groups > 8192 ? 2 * (size_t)max_groups : 8192;
     if (budget > (size_t)P * max_groups) budget = (size_t)P * max_groups;
     if (budget > 0x7fffffff) budget = 0x7fffffff;
     size_t need = (size_t)T * budget;

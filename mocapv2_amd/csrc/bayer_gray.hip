@@ -254,7 +254,8 @@ __global__ __launch_bounds__(256) void bayer_gray_scan_kernel(BayerArgs a, Brigh
                 if (y == 1) *(uint4*)(dst + x0) = out;
                 if (y == a.H - 2) *(uint4*)(dst + (size_t)(a.H - 1) * a.dpitch + x0) = out;
             }
-            const uint32_t e0 = excess2_row(out.x, out.y), e1 = excess2_row(out.z, out.w);
+            const uint32_t base4 = (uint32_t)b.base * 0x01010101u, c8 = 8u * (uint32_t)b.base;
+            const uint32_t e0 = excess2_row(out.x, out.y, base4, c8), e1 = excess2_row(out.z, out.w, base4, c8);
             acc0 += twice ? 2u * e0 : e0;
             acc1 += twice ? 2u * e1 : e1;
         }

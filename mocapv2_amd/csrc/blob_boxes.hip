@@ -1,0 +1,578 @@
+// blob_boxes.hip -- the sparse half of the filter stage: undistort -> 5x5 in-bounds box sum -> threshold -> 5x5 majority,
+// run only where the streaming scan (bright_cells_kernel, blob_filter.hip) could not prove the mask to be zero.
+//
+// Replaces, for the boxes of one batch of camera images,
+//   cv.undistort (reference lib/ImageOperations.py:38) -> fast_cuda_blur (lib/CudaOperations.py:5-41)
+//   -> cv.threshold (lib/ImageOperations.py:29) -> cv.medianBlur (lib/ImageOperations.py:30).
+//
+// Two kernels per batch, behind the scan:
+//   settle_tiles_kernel  one thread per (tile, image): turns the box the scan left on the tile (reachable mask rows and
+//                        columns) into work items of a bounded size in ONE global list, clears what the previous batch
+//                        left in the mask where this batch will not write, resets the scan's box for the next batch;
+//   box_filter_kernel    a fixed grid of single-wave workgroups consumes the list.  One wave owns one item and keeps
+//                        everything in LDS: the source pixels its undistortion reads (staged with coalesced row loads,
+//                        zero border = cv::remap's BORDER_CONSTANT), the horizontal 5-sums of the undistorted patch, the
+//                        packed window counts of the thresholded rows.  Lanes are dealt (row, 4-pixel quad) pairs
+//                        compactly -- a 72-pixel-wide box keeps 60 of 64 lanes busy with three rows per instruction --
+//                        and horizontal neighbours come from DPP wave shifts.  The undistort table is one 4-byte word per
+//                        pixel (11-bit displacements, 5-bit fractions), read with one 16-byte load per quad.
+// No workgroup barrier anywhere: a wave never waits for another one, the list balances the load.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+#include "kernels.h"
+
+namespace mocap {
+
+namespace {
+
+__device__ __forceinline__ uint32_t from_prev(uint32_t v)
+{ // lane L receives lane L-1's value, lane 0 receives 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
+}
+__device__ __forceinline__ uint32_t from_next(uint32_t v)
+{ // lane L receives lane L+1's value, lane 63 receives 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /*wave_shl:1*/, 0xf, 0xf, true);
+}
+__device__ __forceinline__ uint32_t dot4(uint32_t a, uint32_t sel, uint32_t acc) { return __builtin_amdgcn_udot4(a, sel, acc, false); }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int taps5(int v, int n)
+{ // number of in-image taps of a 5-wide window centred on v
+    int lo = v - 2 < 0 ? 0 : v - 2, hi = v + 2 > n - 1 ? n - 1 : v + 2;
+    return hi - lo + 1;
+}
+// floor(n / d) for 0 <= n < 4096, 1 <= d <= 4096 (float reciprocal, +0.5 keeps every quotient away from an integer)
+__device__ __forceinline__ int small_div(int n, float rcp_d) { return (int)(((float)n + 0.5f) * rcp_d); }
+
+} // namespace
+
+// ---- set-up: per 8x8 output cell, the box of source pixels its undistortion reads ------------------------------------
+__global__ void srcbox_kernel(const uint32_t* __restrict__ map4, ushort4* __restrict__ srcbox, int H, int W)
+{
+    const int ncx = (W + 7) >> 3, ncy = (H + 7) >> 3;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncx * ncy) return;
+    const int cy = c / ncx, cx = c - cy * ncx;
+    int x0 = 0x7fff, x1 = -0x8000, y0 = 0x7fff, y1 = -0x8000;
+    for (int y = 8 * cy; y < 8 * cy + 8 && y < H; y++)
+        for (int x = 8 * cx; x < 8 * cx + 8 && x < W; x++) {
+            const uint32_t w = map4[(size_t)y * W + x];
+            const int sx = x + ((int)(w << 21) >> 21), sy = y + ((int)(w << 10) >> 21);
+            x0 = imin(x0, sx); x1 = imax(x1, sx + 1); y0 = imin(y0, sy); y1 = imax(y1, sy + 1);
+        }
+    // tap coordinates lie in [-2, W + 1] x [-2, H + 1]; stored + 2
+    srcbox[c] = make_ushort4((unsigned short)(x0 + 2), (unsigned short)(x1 + 2), (unsigned short)(y0 + 2), (unsigned short)(y1 + 2));
+}
+
+void launch_srcbox(const uint32_t* map4, ushort4* srcbox, int H, int W, hipStream_t s)
+{
+    const int n = ((W + 7) >> 3) * ((H + 7) >> 3);
+    hipLaunchKernelGGL(srcbox_kernel, dim3((n + 63) / 64), dim3(64), 0, s, map4, srcbox, H, W);
+}
+
+// ---- settle: boxes -> work items ----------------------------------------------------------------------------------------
+// How a tile's output region (nb mask bytes wide, h rows) is cut into items: nx x ny parts (nx * ny <= 4) such that a
+// part's patch -- (bytes * 2 + 2) quads x (rows + 8) -- fits BOX_HCAP quad-rows, minimising the wave instructions
+// ("trips": rows per instruction = 64 / quads) plus a fixed cost per item.
+__device__ __forceinline__ void choose_split(int nb, int h, int& nx, int& ny)
+{
+    int best = 0x7fffffff;
+    nx = 1; ny = 1;
+    for (int cx = 1; cx <= 4; cx++) {
+        const int pb = (nb + cx - 1) / cx, Q = 2 * pb + 2;
+        if (Q > 64) continue;
+        const int rpw = 64 / Q, mr = BOX_HCAP / Q - 8;
+        if (mr < 1) continue;
+        const int cy = (h + mr - 1) / mr;
+        if (cx * cy > 4) continue;
+        const int ph = (h + cy - 1) / cy;
+        const int cost = cx * cy * ((ph + 8 + rpw - 1) / rpw + 8);
+        if (cost < best) { best = cost; nx = cx; ny = cy; }
+    }
+}
+
+__global__ __launch_bounds__(256) void settle_tiles_kernel(BoxArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int tiles = a.n_chunks * a.n_strips;
+    const long long total = (long long)tiles * a.cam_mod * a.n_steps;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    // thread -> (tile, slot, time step), time fastest: the items of one tile of one camera lie together in the list, so
+    // the waves that work at the same time share undistort-table lines (matters when every tile is filtered)
+    int image = 0, chunk = 0, strip = 0;
+    bool valid = i < total;
+    if (valid) {
+        const int t = (int)(i % a.n_steps);
+        const long long rest = i / a.n_steps;
+        const int slot = (int)(rest % a.cam_mod), tile = (int)(rest / a.cam_mod);
+        image = t * a.cam_mod + slot;
+        chunk = tile / a.n_strips; strip = tile - chunk * a.n_strips;
+        valid = image < a.n_images && chunk * a.rows_per_chunk < a.H;
+    }
+    const size_t idx = ((size_t)image * a.n_chunks + chunk) * a.n_strips + strip;
+    const int tile_r0 = chunk * a.rows_per_chunk, tile_r1 = imin(tile_r0 + a.rows_per_chunk, a.H) - 1;
+    const int tile_x0 = 240 * strip, tile_x1 = imin(tile_x0 + 239, a.W - 1);
+    int bx0 = 0, bx1 = a.W - 1, by0 = 0, by1 = a.H - 1; // the scan's box: where exact pixels are needed / bits can be set
+    bool marked = valid;
+    if (valid && !a.dense) {
+        const uint4 r = *(const uint4*)(a.tile_rows + 4 * idx);
+        marked = r.x <= r.y;
+        if (marked) {
+            by0 = (int)r.x; by1 = (int)r.y; bx0 = (int)r.z; bx1 = (int)r.w;
+            *(uint4*)(a.tile_rows + 4 * idx) = make_uint4(0xffffffffu, 0u, 0xffffffffu, 0u); // ready for the next batch
+        }
+    }
+    // output region of the tile: the box clipped to the tile, whole mask bytes
+    int ox0 = imax(bx0, tile_x0) & ~7, ox1 = imin(imin(bx1, tile_x1) | 7, tile_x1);
+    int oy0 = imax(by0, tile_r0), oy1 = imin(by1, tile_r1);
+    if (marked && (ox0 > ox1 || oy0 > oy1)) marked = false;
+    if (!marked) { ox0 = 1; ox1 = 0; oy0 = 1; oy1 = 0; }
+    const uint32_t nout_x = (uint32_t)ox0 | ((uint32_t)ox1 << 16), nout_y = (uint32_t)oy0 | ((uint32_t)oy1 << 16);
+
+    // What the previous batch wrote in this tile of the context's own mask and this batch will not overwrite is
+    // cleared here (the mask keeps "zero outside the recorded regions" from batch to batch; a caller-owned mask was
+    // cleared by the scan kernel instead, or is written whole when every tile is filtered).
+    bool need_clear = false;
+    uint32_t pout_x = 1u, pout_y = 1u; // empty
+    if (valid) {
+        uint4* cb = (uint4*)(a.cur_box + 4 * idx);
+        if (!a.ext_mask) {
+            const uint4 prev = *cb;
+            pout_x = prev.x; pout_y = prev.y;
+            const int px0 = (int)(prev.x & 0xffffu), px1 = (int)(prev.x >> 16), py0 = (int)(prev.y & 0xffffu), py1 = (int)(prev.y >> 16);
+            if (px0 <= px1) need_clear = !(marked && ox0 <= px0 && px1 <= ox1 && oy0 <= py0 && py1 <= oy1);
+            if (prev.x != nout_x || prev.y != nout_y || marked)
+                *cb = make_uint4(nout_x, nout_y, (uint32_t)bx0 | ((uint32_t)bx1 << 16), (uint32_t)by0 | ((uint32_t)by1 << 16));
+            if (a.cells[idx] != 0u) a.cells[idx] = 0u;
+        } else {
+            *cb = make_uint4(nout_x, nout_y, (uint32_t)bx0 | ((uint32_t)bx1 << 16), (uint32_t)by0 | ((uint32_t)by1 << 16));
+            a.cells[idx] = 0u;
+        }
+    }
+    for (uint64_t todo = __ballot(need_clear); todo; todo &= todo - 1) { // the whole wave clears one region: lane = row
+        const int src = __ffsll((long long)todo) - 1;
+        const uint32_t cx = (uint32_t)__builtin_amdgcn_readlane((int)pout_x, src), cy = (uint32_t)__builtin_amdgcn_readlane((int)pout_y, src);
+        const int cimage = __builtin_amdgcn_readlane(image, src);
+        const int x0 = (int)(cx & 0xffffu), x1 = (int)(cx >> 16), y0 = (int)(cy & 0xffffu), y1 = (int)(cy >> 16);
+        uint8_t* m = (uint8_t*)(a.mask + (size_t)cimage * a.H * a.words_per_row);
+        const int b0 = x0 >> 3, b1 = x1 >> 3, rb = a.words_per_row * 4;
+        for (int y = y0 + lane; y <= y1; y += 64)
+            for (int b = b0; b <= b1; b++) m[(size_t)y * rb + b] = 0;
+    }
+
+    // items
+    int nx = 0, ny = 0, nb = 0, h = 0;
+    if (marked) {
+        nb = (ox1 - ox0 + 8) >> 3; h = oy1 - oy0 + 1;
+        choose_split(nb, h, nx, ny);
+    }
+    const int cnt = nx * ny;
+    int incl = cnt; // inclusive prefix sum over the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    const int wave_total = __builtin_amdgcn_readlane(incl, 63);
+    if (wave_total == 0) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(a.n_items, (uint32_t)wave_total);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    uint32_t o = base + (uint32_t)(incl - cnt);
+    if (cnt) {
+        const int pb = (nb + nx - 1) / nx, ph = (h + ny - 1) / ny;
+        for (int jy = 0; jy < ny; jy++)
+            for (int jx = 0; jx < nx; jx++, o++) {
+                const int x0 = ox0 + 8 * pb * jx, x1 = imin(x0 + 8 * pb - 1, ox1);
+                const int y0 = oy0 + ph * jy, y1 = imin(y0 + ph - 1, oy1);
+                if (o >= a.cap_items) continue; // cannot happen: nx * ny <= 4 per tile and the list holds 4 per tile
+                uint4 it;
+                it.x = (uint32_t)image;
+                it.y = (uint32_t)(chunk * a.n_strips + strip);
+                it.z = (uint32_t)x0 | ((uint32_t)x1 << 16);
+                it.w = (uint32_t)y0 | ((uint32_t)y1 << 16);
+                if (x0 > x1 || y0 > y1) it.z = 1u; // an empty part (rounding of the split): the consumer skips it
+                ((uint4*)a.items)[2 * o] = it;
+                ((uint4*)a.items)[2 * o + 1] = make_uint4((uint32_t)bx0 | ((uint32_t)bx1 << 16), (uint32_t)by0 | ((uint32_t)by1 << 16), 0u, 0u);
+            }
+    }
+}
+
+// ---- the consumer ---------------------------------------------------------------------------------------------------------
+// Geometry of one item (all wave-uniform):
+//   output region   columns [ox0, ox1] (ox0 a multiple of 8), rows [oy0, oy1]
+//   threshold rows  [ty0, ty1] = [oy0 - 2, oy1 + 2] clipped to the image (the median replicates the border rows)
+//   patch           columns [px0, px0 + 4 Q) with px0 = ox0 - 4, Q = 2 * bytes + 2 quads; rows [hy0, hy1] = [ty0 - 2, ty1 + 2]
+//   exact region    the patch pixels inside the scan's box and the image; every other patch pixel counts as 0, which is
+//                   exact for the mask (blob_filter.hip, "dark-tile early-out")
+// Lane -> (rsub, q): q = lane % Q the quad, rsub = lane / Q the row of the trip; trip k handles rows k * rpw + rsub.
+// Global memory latency is taken out of the item loop: the next item's header and the box of source pixels it will read
+// are fetched while the current item is filtered, all staging loads of an item are in flight together, and the table
+// words of the next group of trips are requested before the current group is blended.
+constexpr int BOX_GROUP = 6; // trips whose table / frame loads are issued together
+
+struct BoxGeom { // derived from an item header, wave-uniform
+    int image, tile, slot, remap;
+    int ox0, ox1, oy0, oy1, Q, px0, ty0, ty1, hy0, hy1, PR, ey0, ey1, eq0, eq1;
+    bool valid, exact;
+};
+__device__ __forceinline__ BoxGeom box_geometry(int H, int W, int cam_mod, uint64_t remap_bits, uint4 h0, uint4 h1)
+{
+    BoxGeom g;
+    g.image = uni((int)h0.x); g.tile = uni((int)h0.y);
+    g.ox0 = uni((int)(h0.z & 0xffffu)); g.ox1 = uni((int)(h0.z >> 16)); g.oy0 = uni((int)(h0.w & 0xffffu)); g.oy1 = uni((int)(h0.w >> 16));
+    const int bx0 = uni((int)(h1.x & 0xffffu)), bx1 = uni((int)(h1.x >> 16)), by0 = uni((int)(h1.y & 0xffffu)), by1 = uni((int)(h1.y >> 16));
+    g.valid = g.ox0 <= g.ox1 && g.oy0 <= g.oy1;
+    g.slot = g.image % cam_mod;
+    g.remap = (int)((remap_bits >> g.slot) & 1ull);
+    const int nb = (g.ox1 - g.ox0 + 8) >> 3;
+    g.Q = 2 * nb + 2; g.px0 = g.ox0 - 4;
+    g.ty0 = imax(g.oy0 - 2, 0); g.ty1 = imin(g.oy1 + 2, H - 1);
+    g.hy0 = g.ty0 - 2; g.hy1 = g.ty1 + 2; g.PR = g.hy1 - g.hy0 + 1;
+    g.ey0 = imax(imax(by0, g.hy0), 0); g.ey1 = imin(imin(by1, g.hy1), H - 1);
+    g.eq0 = imax((imax(bx0, 0) - g.px0) >> 2, 0); g.eq1 = imin((imin(bx1, W - 1) - g.px0) >> 2, g.Q - 1);
+    g.exact = g.valid && g.ey0 <= g.ey1 && g.eq0 <= g.eq1;
+    return g;
+}
+// per-lane partial of the box of source pixels the exact region of `g` reads (union of the per-cell boxes); the caller
+// reduces it over the wave when it needs it, so that the loads stay in flight meanwhile
+struct SrcBounds { int xa, xb, ya, yb; };
+__device__ __forceinline__ SrcBounds source_bounds_partial(const ushort4* __restrict__ srcbox, int H, int W, const BoxGeom& g, int lane)
+{
+    SrcBounds b{0x7fff, -0x8000, 0x7fff, -0x8000};
+    if (!g.exact || !g.remap) return b;
+    const int ncx8 = (W + 7) >> 3;
+    const ushort4* __restrict__ sbx = srcbox + (size_t)g.slot * ncx8 * ((H + 7) >> 3);
+    const int cx0 = imax(g.px0 + 4 * g.eq0, 0) >> 3, cx1 = imin(g.px0 + 4 * g.eq1 + 3, W - 1) >> 3, cy0 = g.ey0 >> 3, cy1 = g.ey1 >> 3;
+    const int ncw = cx1 - cx0 + 1, ncells = ncw * (cy1 - cy0 + 1);
+    const float rcpw = __builtin_amdgcn_rcpf((float)ncw);
+    for (int c0 = 0; c0 < ncells; c0 += 64) {
+        const int c = imin(c0 + lane, ncells - 1);
+        const int cyi = small_div(c, rcpw), cxi = c - cyi * ncw;
+        const ushort4 sb = sbx[(cy0 + cyi) * ncx8 + cx0 + cxi];
+        b.xa = imin(b.xa, (int)sb.x - 2); b.xb = imax(b.xb, (int)sb.y - 2); b.ya = imin(b.ya, (int)sb.z - 2); b.yb = imax(b.yb, (int)sb.w - 2);
+    }
+    return b;
+}
+
+__global__ __launch_bounds__(64) void box_filter_kernel(BoxArgs a)
+{
+    __shared__ uint32_t lut[256];
+    __shared__ uint2 Hs[BOX_HCAP + 64];                              // + 64: where lanes without a row park their store
+    __shared__ __attribute__((aligned(16))) uint8_t Sbuf[BOX_SCAP];   // staged source pixels; afterwards the window counts
+    uint32_t* const Cs = (uint32_t*)Sbuf;
+    static_assert((BOX_HCAP + 64) * 4 <= BOX_SCAP, "counts alias the source buffer");
+
+    const int lane = threadIdx.x;
+    // kernel arguments as plain scalars (a struct captured by the lambdas below would be kept in scratch memory)
+    const uint8_t* __restrict__ const a_src = a.src;
+    const size_t a_image_stride = a.image_stride;
+    const int a_pitch = a.pitch, a_stage_bytes = a.stage_bytes, a_thr_mul = a.thr_mul, a_words_per_row = a.words_per_row;
+    const int a_n_chunks = a.n_chunks, a_n_strips = a.n_strips, a_rows_per_chunk = a.rows_per_chunk;
+    const uint32_t* __restrict__ const a_map4 = a.map4;
+    uint32_t* __restrict__ const a_mask = a.mask;
+    uint32_t* __restrict__ const a_cells = a.cells;
+    const uint32_t a_cap_items = a.cap_items;
+    const uint32_t* const a_n_items = a.n_items;
+    if (a.prio) __builtin_amdgcn_s_setprio(2); // A/B switch: these waves compute, the scan's waves of the next batch wait on HBM
+    // lut[w]: byte k = number of set bits among bits k..k+4 of the 8-bit window w
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        uint32_t i = (uint32_t)(lane + 64 * e), v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) v |= (uint32_t)__popc((i >> k) & 0x1fu) << (8 * k);
+        lut[i] = v;
+    }
+    uint32_t n_items = *a_n_items;
+    n_items = n_items < a_cap_items ? n_items : a_cap_items;
+    const int G = gridDim.x;
+    // blocks b and b + 8 share an XCD: give each XCD runs of consecutive items (they share table lines, see settle)
+    const uint32_t first = (G & 7) == 0 ? (uint32_t)((blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3)) : blockIdx.x;
+    const int H = a.H, W = a.W, Hm1 = H - 1;
+    const int row_bytes = a_words_per_row * 4;
+    const int cam_mod = a.cam_mod;
+    const uint64_t remap_bits = a.remap_bits;
+    const ushort4* __restrict__ srcbox = a.srcbox;
+    const uint4* __restrict__ items = (const uint4*)a.items;
+    if (first >= n_items) return;
+
+    uint4 h0 = items[2 * first], h1 = items[2 * first + 1];
+    BoxGeom g = box_geometry(H, W, cam_mod, remap_bits, h0, h1);
+    SrcBounds sbp = source_bounds_partial(srcbox, H, W, g, lane);
+
+    for (uint32_t item = first; item < n_items; item += (uint32_t)G) {
+        // header of the next item: requested now, looked at when this item's patch is done
+        const uint32_t nxt = item + (uint32_t)G < n_items ? item + (uint32_t)G : item;
+        const uint4 n0 = items[2 * nxt], n1 = items[2 * nxt + 1];
+        if (!g.valid) { // an empty part of a split
+            g = box_geometry(H, W, cam_mod, remap_bits, n0, n1);
+            sbp = source_bounds_partial(srcbox, H, W, g, lane);
+            continue;
+        }
+        const int image = g.image, tile = g.tile, slot = g.slot;
+        const int ox0 = g.ox0, oy0 = g.oy0, oy1 = g.oy1, Q = g.Q, px0 = g.px0, ty0 = g.ty0, ty1 = g.ty1, hy0 = g.hy0, PR = g.PR;
+        const int ey0 = g.ey0, ey1 = g.ey1, eq0 = g.eq0, eq1 = g.eq1;
+        const size_t idx = (size_t)image * a_n_chunks * a_n_strips + tile;
+        const float rcpQ = __builtin_amdgcn_rcpf((float)Q);
+        const int rpw = small_div(64, rcpQ);
+        const int rsub = small_div(lane, rcpQ), q = lane - rsub * Q;
+        const bool lane_on = rsub < rpw;
+        const int x = px0 + 4 * q;
+        uint32_t bytemask = 0, colmask = 0; // columns of this lane's quad inside the image
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if ((unsigned)(x + k) < (unsigned)W) { bytemask |= 0xffu << (8 * k); colmask |= 1u << k; }
+        const bool q_exact = q >= eq0 && q <= eq1;
+        const int qc = q < eq0 ? eq0 : (q > eq1 ? eq1 : q);
+        const int xc = imax(px0 + 4 * qc, 0); // column of a quad of the exact region (loads of other lanes go there and are discarded)
+        const uint8_t* __restrict__ img = a_src + (size_t)image * a_image_stride;
+        const int ntrip_a = (PR + rpw - 1) / rpw, ngroup_a = (ntrip_a + BOX_GROUP - 1) / BOX_GROUP;
+        __syncthreads(); // (single wave) the previous item's LDS reads are done
+
+        // ---- pass A: undistorted patch -> horizontal 5-sums of every patch row, in LDS -----------------------------------
+        // hsum of one patch row's quad B (4 bytes): packed 16-bit sums of the 5 columns around each pixel
+        auto store_h = [&](uint32_t B, int r) __attribute__((always_inline)) {
+            const uint32_t A = from_prev(B), C = from_next(B);
+            const uint32_t sB = dot4(B, 0x01010101u, 0u);
+            const uint32_t h0_ = dot4(A, 0x01010000u, dot4(B, 0x00010101u, 0u));
+            const uint32_t h1_ = dot4(A, 0x01000000u, sB);
+            const uint32_t h2_ = dot4(C, 0x00000001u, sB);
+            const uint32_t h3_ = dot4(C, 0x00000101u, dot4(B, 0x01010100u, 0u));
+            const int at = (lane_on && r < PR) ? __mul24(r, Q) + q : BOX_HCAP + lane;
+            Hs[at] = make_uint2(h0_ | (h1_ << 16), h2_ | (h3_ << 16));
+        };
+        if (!g.exact) {
+            for (int k = 0; k < ntrip_a; k++) store_h(0u, k * rpw + rsub);
+        } else if (!g.remap) {
+            // identity map: the patch is the frame
+            const int ax = xc > W - 4 ? W - 4 : xc; // W >= 4
+            const uint32_t sh = (uint32_t)((xc - ax) * 8);
+            auto load_rows = [&](uint32_t (&raw)[BOX_GROUP], int gi) __attribute__((always_inline)) {
+#pragma unroll
+                for (int u = 0; u < BOX_GROUP; u++) {
+                    const int y = hy0 + (gi * BOX_GROUP + u) * rpw + rsub, yc = y < ey0 ? ey0 : (y > ey1 ? ey1 : y);
+                    __builtin_memcpy(&raw[u], img + ((uint32_t)yc * (uint32_t)a_pitch + (uint32_t)ax), 4);
+                }
+            };
+            auto use_rows = [&](const uint32_t (&raw)[BOX_GROUP], int gi) __attribute__((always_inline)) {
+#pragma unroll
+                for (int u = 0; u < BOX_GROUP; u++) {
+                    const int r = (gi * BOX_GROUP + u) * rpw + rsub, y = hy0 + r;
+                    const bool ok = q_exact && y >= ey0 && y <= ey1;
+                    store_h(ok ? ((raw[u] >> sh) & bytemask) : 0u, r);
+                }
+            };
+            uint32_t ra[BOX_GROUP], rb[BOX_GROUP];
+            load_rows(ra, 0);
+            for (int gi = 0; gi < ngroup_a; gi += 2) {
+                load_rows(rb, gi + 1);
+                use_rows(ra, gi);
+                if (gi + 1 < ngroup_a) {
+                    load_rows(ra, gi + 2);
+                    use_rows(rb, gi + 1);
+                }
+            }
+        } else {
+            // 1. source pixels the exact region reads (their loads were issued during the previous item)
+            int sxa = sbp.xa, sxb = sbp.xb, sya = sbp.ya, syb = sbp.yb;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                sxa = imin(sxa, __shfl_xor(sxa, d)); sxb = imax(sxb, __shfl_xor(sxb, d));
+                sya = imin(sya, __shfl_xor(sya, d)); syb = imax(syb, __shfl_xor(syb, d));
+            }
+            sxa = uni(sxa) & ~3; sxb = uni(sxb); sya = uni(sya); syb = uni(syb);
+            const int SP = (sxb - sxa + 4) & ~3, SR = syb - sya + 1, dpr = SP >> 2;
+            const bool staged = SP * SR <= a_stage_bytes && dpr <= 64;
+            const uint32_t* __restrict__ map4 = a_map4 + (size_t)slot * H * W;
+            auto load_table = [&](uint4 (&tw)[BOX_GROUP], int gi) __attribute__((always_inline)) {
+#pragma unroll
+                for (int u = 0; u < BOX_GROUP; u++) {
+                    const int y = hy0 + (gi * BOX_GROUP + u) * rpw + rsub, yc = y < ey0 ? ey0 : (y > ey1 ? ey1 : y);
+                    __builtin_memcpy(&tw[u], map4 + ((uint32_t)yc * (uint32_t)W + (uint32_t)xc), 16);
+                }
+            };
+            uint4 ta[BOX_GROUP], tb[BOX_GROUP];
+            if (staged) {
+                // 2. stage them: coalesced dword loads, zeros outside the image (cv::remap's BORDER_CONSTANT).  Lane -> (row of
+                // the round, dword of the row); all rounds' loads are in flight together.
+                const float rcpd = __builtin_amdgcn_rcpf((float)dpr);
+                const int rpi = small_div(64, rcpd), srs = small_div(lane, rcpd), sc = lane - srs * dpr;
+                const bool s_on = srs < rpi;
+                const int gx = sxa + 4 * sc, ax = gx < 0 ? 0 : (gx > W - 4 ? W - 4 : gx);
+                const int sb = (gx - ax) * 8; // > 0 only at the right edge of the image
+                uint32_t keep = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if ((unsigned)(gx + k) < (unsigned)W) keep |= 0xffu << (8 * k);
+                if (sb >= 32 || sb < 0) keep = 0;
+                const uint32_t shs = (uint32_t)(sb < 0 || sb > 31 ? 0 : sb);
+                constexpr int SU = 14;
+                const int nround = (SR + rpi - 1) / rpi;
+                for (int r0 = 0; r0 < nround; r0 += 2 * SU) {
+                    uint32_t v[2 * SU];
+#pragma unroll
+                    for (int u = 0; u < 2 * SU; u++) {
+                        const int gy = sya + (r0 + u) * rpi + srs, gyc = gy < 0 ? 0 : (gy > Hm1 ? Hm1 : gy);
+                        __builtin_memcpy(&v[u], img + ((uint32_t)gyc * (uint32_t)a_pitch + (uint32_t)ax), 4);
+                    }
+                    if (r0 == 0) load_table(ta, 0);
+#pragma unroll
+                    for (int u = 0; u < 2 * SU; u++) {
+                        const int r = (r0 + u) * rpi + srs, gy = sya + r;
+                        const uint32_t val = ((unsigned)gy < (unsigned)H) ? ((v[u] >> shs) & keep) : 0u;
+                        if (s_on && r < SR) ((uint32_t*)Sbuf)[r * dpr + sc] = val;
+                    }
+                }
+                __syncthreads();
+            } else {
+                load_table(ta, 0);
+            }
+            // 3. table words (one 16-byte load per quad), taps from LDS, blend exactly as cv::remap's fixed point does
+            auto blend_rows = [&](auto staged_c, const uint4 (&tw)[BOX_GROUP], int gi) __attribute__((always_inline)) {
+                constexpr bool STAGED = decltype(staged_c)::value;
+#pragma unroll
+                for (int u = 0; u < BOX_GROUP; u++) {
+                    const int r = (gi * BOX_GROUP + u) * rpw + rsub, y = hy0 + r;
+                    const int yc = y < ey0 ? ey0 : (y > ey1 ? ey1 : y);
+                    const bool ok = q_exact && y >= ey0 && y <= ey1;
+                    const uint32_t ww[4] = {tw[u].x, tw[u].y, tw[u].z, tw[u].w};
+                    const int rowbase = __mul24(yc - sya, SP) + (xc - sxa); // LDS offset of (xc, yc)
+                    uint32_t B = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t w = ww[k];
+                        const int dx = (int)(w << 21) >> 21, dy = (int)(w << 10) >> 21;
+                        const uint32_t fa = (w >> 22) & 31u, fb = w >> 27;
+                        uint32_t p00, p01, p10, p11;
+                        if (STAGED) {
+                            const int A0 = __mul24(dy, SP) + (rowbase + k) + dx;
+                            p00 = Sbuf[A0]; p01 = Sbuf[A0 + 1]; p10 = Sbuf[A0 + SP]; p11 = Sbuf[A0 + SP + 1];
+                        } else { // source region too large for the LDS buffer (strong local distortion): taps from memory,
+                                 // loaded from the nearest in-image position and zeroed by select (no branch around loads)
+                            const int sx = xc + k + dx, sy = yc + dy;
+                            const int sx0 = sx < 0 ? 0 : (sx > W - 1 ? W - 1 : sx), sx1 = sx + 1 < 0 ? 0 : (sx + 1 > W - 1 ? W - 1 : sx + 1);
+                            const int sy0 = sy < 0 ? 0 : (sy > Hm1 ? Hm1 : sy), sy1 = sy + 1 < 0 ? 0 : (sy + 1 > Hm1 ? Hm1 : sy + 1);
+                            const uint32_t o0 = (uint32_t)sy0 * (uint32_t)a_pitch, o1 = (uint32_t)sy1 * (uint32_t)a_pitch;
+                            const uint32_t t00 = img[o0 + (uint32_t)sx0], t01 = img[o0 + (uint32_t)sx1], t10 = img[o1 + (uint32_t)sx0], t11 = img[o1 + (uint32_t)sx1];
+                            const bool c0 = sx0 == sx, c1 = sx1 == sx + 1, r0 = sy0 == sy, r1 = sy1 == sy + 1;
+                            p00 = (c0 && r0) ? t00 : 0u; p01 = (c1 && r0) ? t01 : 0u; p10 = (c0 && r1) ? t10 : 0u; p11 = (c1 && r1) ? t11 : 0u;
+                        }
+                        const uint32_t wa = 32u - fa, wb = 32u - fb;
+                        const uint32_t top = __umul24(p00, wa) + __umul24(p01, fa), bot = __umul24(p10, wa) + __umul24(p11, fa);
+                        const uint32_t rr = (__umul24(top, wb) + __umul24(bot, fb) + 512u) >> 10; // == (sum of 32*w*p + 2^14) >> 15
+                        B |= rr << (8 * k);
+                    }
+                    store_h(ok ? (B & bytemask) : 0u, r);
+                }
+            };
+            auto remap_rows = [&](auto staged_c) __attribute__((always_inline)) {
+                for (int gi = 0; gi < ngroup_a; gi += 2) {
+                    load_table(tb, gi + 1);
+                    blend_rows(staged_c, ta, gi);
+                    if (gi + 1 < ngroup_a) {
+                        load_table(ta, gi + 2);
+                        blend_rows(staged_c, tb, gi + 1);
+                    }
+                }
+            };
+            if (staged) remap_rows(std::true_type{});
+            else remap_rows(std::false_type{});
+        }
+        __syncthreads();
+        // the next item: its geometry, and the loads of its source box (in flight during passes B and C)
+        const BoxGeom gn = box_geometry(H, W, cam_mod, remap_bits, n0, n1);
+        const SrcBounds sbn = source_bounds_partial(srcbox, H, W, gn, lane);
+
+        // ---- pass B: vertical 5-sums -> threshold -> horizontal window counts of the threshold bits --------------------
+        const int c0t = taps5(x, W), c1t = taps5(x + 1, W), c2t = taps5(x + 2, W), c3t = taps5(x + 3, W);
+        const uint32_t cx01 = (uint32_t)(c0t & 0xffff) | ((uint32_t)c1t << 16), cx23 = (uint32_t)(c2t & 0xffff) | ((uint32_t)c3t << 16);
+        const bool left_edge = px0 < 0, right_edge = px0 + 4 * Q > W; // the patch sticks out of the image
+        const int qe = (W - 1 - px0) >> 2, be = (W - 1 - px0) & 3;    // quad / bit of column W - 1
+        const int ntrip_b = (ty1 - ty0 + 1 + rpw - 1) / rpw;
+        const int hstep = Q;                                          // Hs entries per patch row
+        for (int k = 0; k < ntrip_b; k++) {
+            const int y = ty0 + k * rpw + rsub, yb = imin(y, ty1), rh = yb - hy0; // H row of the threshold row (>= 2)
+            const uint2* hp = Hs + (__mul24(rh - 2, hstep) + q);
+            const uint2 v0 = hp[0], v1 = hp[hstep], v2 = hp[2 * hstep], v3 = hp[3 * hstep], v4 = hp[4 * hstep];
+            const uint32_t V01 = v0.x + v1.x + v2.x + v3.x + v4.x, V23 = v0.y + v1.y + v2.y + v3.y + v4.y;
+            const uint32_t m = (uint32_t)__mul24(a_thr_mul, taps5(yb, H));
+            const uint32_t T01 = __umul24(cx01, m), T23 = __umul24(cx23, m);
+            const uint32_t d01 = (V01 | 0x80008000u) - T01, d23 = (V23 | 0x80008000u) - T23;
+            const uint32_t t = (d01 >> 15) & 0x10001u, u = (d23 >> 15) & 0x10001u;
+            const uint32_t wv = t | (u << 2);
+            uint32_t nib = (wv | (wv >> 15)) & 0xfu;
+            // medianBlur replicates the border: columns outside the image take the edge column's bit
+            if (left_edge) { // quad 0 = columns -4..-1, quad 1 starts at column 0
+                const uint32_t e = from_next(nib) & 1u;
+                if (q == 0) nib = e ? 0xfu : 0u;
+            }
+            if (right_edge) {
+                const uint32_t ne = (uint32_t)__shfl((int)nib, lane - q + qe);
+                const uint32_t e = (ne >> be) & 1u, keep = (2u << be) - 1u;
+                if (q > qe) nib = e ? 0xfu : 0u;
+                else if (q == qe) nib = (nib & keep) | (e ? (0xfu & ~keep) : 0u);
+            }
+            const uint32_t nl = from_prev(nib), nr = from_next(nib);
+            const uint32_t win = (nl >> 2) | (nib << 2) | ((nr & 3u) << 6);
+            const uint32_t c = lut[win & 0xffu];
+            const int at = (lane_on && y <= ty1) ? __mul24(y - ty0, Q) + q : BOX_HCAP + lane;
+            Cs[at] = c;
+        }
+        __syncthreads();
+
+        // ---- pass C: majority (>= 13 of 25) of every output row, two quads -> one byte of the bit mask -----------------
+        const int tile_r0 = (tile / a_n_strips) * a_rows_per_chunk;
+        uint8_t* __restrict__ mrow = (uint8_t*)(a_mask + (size_t)image * H * a_words_per_row);
+        const int out_byte = (ox0 >> 3) + ((q - 1) >> 1);
+        const bool stores = lane_on && (q & 1) && q <= Q - 3 && out_byte < ((W + 7) >> 3) && out_byte < row_bytes;
+        uint32_t lacc = 0; // bit g: rows 8g..8g+7 of the tile's chunk hold set pixels in this lane's columns
+        const int ntrip_c = (oy1 - oy0 + 1 + rpw - 1) / rpw;
+        const bool inner = oy0 >= 2 && oy1 + 2 <= Hm1; // no row of the item's windows is replicated
+        for (int k = 0; k < ntrip_c; k++) {
+            const int y = oy0 + k * rpw + rsub, yy = imin(y, oy1);
+            uint32_t Cv = 0;
+            if (inner) {
+                const uint32_t* cp = Cs + (__mul24(yy - 2 - ty0, hstep) + q);
+                Cv = cp[0] + cp[hstep] + cp[2 * hstep] + cp[3 * hstep] + cp[4 * hstep];
+            } else {
+#pragma unroll
+                for (int d = -2; d <= 2; d++) {
+                    const int yr = yy + d < 0 ? 0 : (yy + d > Hm1 ? Hm1 : yy + d); // BORDER_REPLICATE in y
+                    Cv += Cs[__mul24(yr - ty0, Q) + q];
+                }
+            }
+            const uint32_t mm = ((Cv + 0x73737373u) >> 7) & 0x01010101u;
+            const uint32_t t1 = mm | (mm >> 7);
+            const uint32_t mn = (t1 | (t1 >> 14)) & colmask & 0xfu;
+            const uint32_t odd = from_next(mn);
+            const uint32_t byte = mn | ((odd & 0xfu) << 4);
+            if (stores && y <= oy1) {
+                mrow[(size_t)y * row_bytes + out_byte] = (uint8_t)byte;
+                lacc |= (byte != 0u ? 1u : 0u) << ((y - tile_r0) >> 3);
+            }
+        }
+        {   // occupancy word of the tile (read by the contour kernel): OR of every lane's row groups; bit 31 = filtered
+            uint32_t cellmask = 0;
+            const int g0 = (oy0 - tile_r0) >> 3, g1 = (oy1 - tile_r0) >> 3;
+            for (int gg = g0; gg <= g1; gg++)
+                if (__ballot((lacc >> gg) & 1u) != 0ull) cellmask |= 1u << gg;
+            if (lane == 0) atomicOr(&a_cells[idx], cellmask | 0x80000000u);
+        }
+        g = gn; sbp = sbn;
+    }
+}
+
+void launch_settle_tiles(const BoxArgs& a, hipStream_t s)
+{
+    const long long total = (long long)a.n_chunks * a.n_strips * a.cam_mod * a.n_steps;
+    hipLaunchKernelGGL(settle_tiles_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+}
+
+void launch_box_filter(const BoxArgs& a, int grid, hipStream_t s)
+{
+    hipLaunchKernelGGL(box_filter_kernel, dim3(grid), dim3(64), 0, s, a);
+}
+
+} // namespace mocap

@@ -5,41 +5,66 @@
 
 namespace mocap {
 
+// The general (any geometry, any lens model) dense filter kernel: every tile of every image, per-pixel gather for
+// remapped cameras.  Off the hot path: used for images narrower than 8 pixels, for undistort tables whose displacements
+// do not fit the compact table of the box kernel, and by the single-image convenience entry points.
 struct FilterArgs {
     const uint8_t* src;   // images, image_stride bytes apart, rows `pitch` bytes apart
     size_t image_stride;
     int pitch, H, W;
-    int aligned4;         // src base, pitch and image_stride are multiples of 4
     uint32_t* mask;       // [n_images][H][words_per_row], bit b of word k = pixel 32k+b
     int words_per_row;
     uint32_t* cells;      // [n_images][n_cgroups*4][n_strips]: bit g = rows 8g..8g+7 of the chunk have set pixels in the strip; bit 31 = tile ran the full filter
     // undistort tables of the first slot used (remap variant only), each [cam_mod][H][W]:
     const uint32_t* map;  //   tap position: (sx - x) | (sy - y) << 16, the 2x2 tap window clamped into the image
     const uint32_t* mapw; //   blend weights 32*(wx0 | wx1<<8 | wy1<<16 | wy0<<24)/32, taps outside the image weigh 0
-    const uint2* spans;   //   per (slot, strip, row): x = smin | smax<<16, y = xmin | xmax<<16 (source rows / columns the
-                          //   strip's pixels of that row read); used by the LDS-staged remap variant
-    int remap_mode;       // 0 plain / 2 per-pixel gather, 3 pipelined gather, 4 LDS-staged
-    int skip_allow;       // dark-tile early-out: a tile whose source region has no 16x16 block (2x2 cells of 8x8 px)
-                          //   whose doubled excess sum, 2 * sum of max(0, p - 63), exceeds this provably yields an all-zero mask; -1 = off
-    uint32_t* tile_rows;  // [n_images][n_cgroups*4][n_strips][4] (indexed like cells): first / last mask row and first / last
-                          //   column that hot cells of the tile's source region can reach, (0xffffffff, 0) = none; written by
-                          //   bright_cells_kernel, read and reset by the filter kernel; used if skip_allow >= 0
-    uint8_t* patch;       // optional [n_images][tiles][rows_per_chunk + 8][256]: undistorted boxes (undistort_patches_kernel);
-                          //   non-null selects the patch path (all cameras of the batch remapped, early-out on, W % 4 == 0)
-    int ext_mask;         // 1 = caller-owned mask (with the early-out: cleared by bright_cells_kernel, occupancy words of dark
-                          //   tiles always written); 0 = the context's own mask (cleared on demand, see the filter kernel)
     int cam_mod;          // undistort slot of image n = n % cam_mod (map already points at the first slot)
     int n_images, n_steps; // n_steps = ceil(n_images / cam_mod)
     int thr_mul;          // floor(thresh)+1: blurred > thresh  <=>  S >= thr_mul * taps
     int rows_per_chunk, n_strips, n_cgroups;
 };
 
+// The sparse half of the filter stage (blob_boxes.hip): tiles, boxes, work items.
+// A tile = 240 mask columns x rows_per_chunk rows.  The scan kernel leaves per tile the box of mask rows / columns that
+// hot cells can reach (tile_rows); settle_tiles_kernel turns the boxes into items; box_filter_kernel consumes them.
+constexpr int BOX_HCAP = 1536; // quad-rows (4 pixels x 1 row) of one item's patch
+constexpr int BOX_SCAP = 6656; // bytes of source pixels staged in LDS per item
+struct BoxItem { uint32_t image, tile, x01, y01, bx01, by01, pad0, pad1; }; // output region: columns x0 | x1 << 16, rows y0 | y1 << 16
+                                                                        //   (x0 > x1: skip); the scan's box of the tile (not clipped to it)
+struct BoxArgs {
+    const uint8_t* src; size_t image_stride; int pitch, H, W;
+    uint32_t* mask; int words_per_row;
+    uint32_t* cells;            // occupancy words [n_images][n_chunks][n_strips] (see FilterArgs)
+    const uint32_t* map4;       // compact undistort table of the first slot used, [cam_mod][H][W]: dx (11 bits, signed) |
+                                //   dy (11, signed) << 11 | x fraction (5) << 22 | y fraction (5) << 27; the 2x2 taps start at
+                                //   (x + dx, y + dy), clamped into [-2, W] x [-2, H] (taps outside the image read 0)
+    const ushort4* srcbox;      // [cam_mod][ceil(H/8)][ceil(W/8)]: box of the tap coordinates of an 8x8 output cell, + 2
+    uint64_t remap_bits;        // bit s: slot s (relative to the first) is remapped (else the identity)
+    int cam_mod, n_images, n_steps;
+    int thr_mul;
+    int rows_per_chunk, n_strips, n_chunks;
+    uint32_t* tile_rows;        // [n_images][n_chunks][n_strips][4]: the scan's boxes (first / last row, first / last column;
+                                //   (0xffffffff, 0) = none), reset by settle
+    uint32_t* cur_box;          // [n_images][n_chunks][n_strips][4]: words 0-1 the tile's output region of this batch
+                                //   (x0 | x1 << 16, y0 | y1 << 16; x0 > x1 = none) = what the mask may hold there; words 2-3 the
+                                //   scan's box (not clipped to the tile)
+    BoxItem* items; uint32_t* n_items; uint32_t cap_items;
+    int prio;                   // 1 = raise the wave priority of the box kernel (A/B switch)
+    int stage_bytes;            // LDS bytes the source staging may use (BOX_SCAP; smaller values are a test switch)
+    int dense;                  // 1 = no early-out: every tile is filtered whole
+    int ext_mask;               // 1 = caller-owned mask (cleared by the scan kernel, or written whole when dense)
+};
+void launch_settle_tiles(const BoxArgs& a, hipStream_t s);
+void launch_box_filter(const BoxArgs& a, int grid, hipStream_t s);
+void launch_srcbox(const uint32_t* map4, ushort4* srcbox, int H, int W, hipStream_t s);
+
 struct MapArgs {
     double K[9], dist[5];
     int H, W;
     uint32_t* map;   // [H][W] tap positions (see FilterArgs)
     uint32_t* mapw;  // [H][W] blend weights
-    uint32_t* flags; // bit0: the table is not the identity
+    uint32_t* map4;  // [H][W] compact table (see BoxArgs)
+    uint32_t* flags; // bit0: the table is not the identity; bit1: a displacement does not fit the compact table
 };
 
 // one border found by the contour kernel (also the debug record compared with the oracle in tests)
@@ -78,13 +103,13 @@ struct ContourArgs {
 enum { BLOB_ERR_CANDIDATES = -2, BLOB_ERR_CONTOURS = -3, BLOB_ERR_STEPS = -4, BLOB_ERR_DEPTH = -5 };
 
 void launch_filter_mask(const FilterArgs& a, bool remap, hipStream_t s);
-void launch_undistort_patches(const FilterArgs& a, hipStream_t s); // needs a.patch; before launch_filter_mask
 struct BrightArgs {
     const uint8_t* src; size_t image_stride; int pitch, H, W, n_images; // W >= 8
     int cam_mod;                  // undistort slot of image n = n % cam_mod (the tables already point at the first slot)
     uint32_t ncx_magic;           // ceil(2^32 / d), d = ceil(W/8) (wide: d / 2), if that divides every index exactly by multiply-high, else 0
     int wide;                     // 1 = 16-byte loads (W, pitch, image stride, base all multiples of 16; ncx_magic != 0)
-    int hot, hot_edge, hot_corner; // a cell whose doubled excess sum (2 * sum of max(0, p - 63)) exceeds this is hot (4 * hot <= skip_allow); _edge /
+    int base;                     // excess base c: a pixel p counts with max(0, p - c)
+    int hot, hot_edge, hot_corner; // a cell whose doubled excess sum (2 * sum of max(0, p - c)) exceeds this is hot (4 * hot <= allow); _edge /
                                   //   _corner for cells feeding windows the image border cuts in one axis / in both
     const uint2* reach;           // [cam_mod][cells]: box of the output pixels that read the 8x8 source cell, x0 | x1 << 16, y0 | y1 << 16
     const uint8_t* cflags;        // [cam_mod][cells]: 1 / 2 = the cell feeds windows the image border cuts in one axis / in both
@@ -93,7 +118,6 @@ struct BrightArgs {
     uint32_t* mask; size_t mask_words; int mask_aligned16; // caller-owned bit masks to clear on the side (mask_words = 0: none)
 };
 void launch_bright_cells(const BrightArgs& a, hipStream_t s);
-struct SpanArgs { const uint32_t* map; uint2* spans; int H, W, n_strips; };
 // set-up statistics of an undistort table, for the dark-tile bound: stats[0] = largest total blend weight any source
 // pixel carries over all output pixels (1024 = one full pixel), stats[1] / stats[2] = largest x / y extent (in source
 // pixels) of the taps feeding one 5x5 output window.  acc: H*W zero-initialised scratch words.  edge: zero-initialised
@@ -102,8 +126,6 @@ struct SpanArgs { const uint32_t* map; uint2* spans; int H, W, n_strips; };
 // bounding box of the output pixels that read the cell with a nonzero weight.
 struct StatArgs { const uint32_t* map; const uint32_t* mapw; uint32_t* acc; uint32_t* stats; int H, W; uint32_t* edge; int* reach; };
 void launch_remap_stats(const StatArgs& a, hipStream_t s);
-void launch_remap_spans(const SpanArgs& a, hipStream_t s);
-constexpr int RING_H = 32, RING_W = 288, RING_LOOKAHEAD = 5; // LDS source-row ring of the staged remap (per wave)
 void launch_undistort_map(const MapArgs& m, hipStream_t s);
 void launch_contours(const ContourArgs& a, hipStream_t s);
 size_t contour_work_bytes();

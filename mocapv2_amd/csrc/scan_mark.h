@@ -8,13 +8,14 @@
 
 namespace mocap {
 
-__device__ __forceinline__ uint32_t excess2_row(uint32_t lo, uint32_t hi)
-{ // sum over the 8 bytes of |p - 63| + p - 63 = 2 * max(0, p - 63); a zero byte adds nothing
-    uint32_t s = __builtin_amdgcn_sad_u8(lo, 0x3f3f3f3fu, 0u);
+// base4 = the excess base c in every byte (c * 0x01010101), c8 = 8 * c
+__device__ __forceinline__ uint32_t excess2_row(uint32_t lo, uint32_t hi, uint32_t base4, uint32_t c8)
+{ // sum over the 8 bytes of |p - c| + p - c = 2 * max(0, p - c)   (|p - c| + |p - 0| = 2 max(0, p - c) + c per byte)
+    uint32_t s = __builtin_amdgcn_sad_u8(lo, base4, 0u);
     s = __builtin_amdgcn_sad_u8(lo, 0u, s);
-    s = __builtin_amdgcn_sad_u8(hi, 0x3f3f3f3fu, s);
+    s = __builtin_amdgcn_sad_u8(hi, base4, s);
     s = __builtin_amdgcn_sad_u8(hi, 0u, s);
-    return s - 8u * 63u;
+    return s - c8;
 }
 
 // A cell whose doubled excess sum `acc` exceeds its threshold widens, for every filter tile its reach (+ 4 pixels of blur
@@ -40,6 +41,10 @@ __device__ __forceinline__ void mark_hot_cell(const BrightArgs& a, const uint2* 
             for (int ch = ch0; ch <= ch1; ch++)
                 for (int st = st0; st <= st1; st++) {
                     const int t = ch * a.n_strips + st;
+                    // a box that already holds the rectangle needs no atomics (boxes only grow inside a launch, so a stale
+                    // value read here errs on the safe side): keeps a frame that is hot everywhere from serialising on them
+                    const uint4 cur = *(const uint4*)(rows + 4 * t);
+                    if (cur.x <= (uint32_t)ya && cur.y >= (uint32_t)yb && cur.z <= (uint32_t)xa && cur.w >= (uint32_t)xb) continue;
                     atomicMin(&rows[4 * t], (uint32_t)ya);
                     atomicMax(&rows[4 * t + 1], (uint32_t)yb);
                     atomicMin(&rows[4 * t + 2], (uint32_t)xa);

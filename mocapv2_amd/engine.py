@@ -312,7 +312,7 @@ class MocapContext:
         _abi.check(self.lib.mocap_profile_read(self._h, ms, n))
         return {"filter_ms": ms[0], "filter_launches": n[0], "contour_ms": ms[1], "contour_launches": n[1],
                 "corr_ms": ms[2], "corr_launches": n[2], "scan_ms": ms[3], "scan_launches": n[3],
-                "patch_ms": ms[4], "patch_launches": n[4]}
+                "settle_ms": ms[4], "settle_launches": n[4]}
 
 
 def comm_unique_id():

@@ -47,15 +47,20 @@ def test_4k_frame_64_markers_matches_oracle():
 
 def test_batch_invariance_and_remap_variants_agree_at_1080p(monkeypatch):
     """Size-independent properties: an image's result does not depend on the batch it travels in, nor on which of the
-    three remap kernels produced it."""
+    remap variants (general dense kernel, box kernel staged / unstaged) produced it."""
     import torch
     from mocapv2_amd.engine import MocapContext
     sc = Scene(6, 1920, 1080, dist=MILD_DIST)
     frames = sc.render_batch(seed=3000, n_steps=4, n_markers=8, radius_range=(16, 22), salt=0.001)
     dev = torch.from_numpy(frames).cuda()
     results = []
-    for mode in ["2", "3", "4"]:
-        monkeypatch.setenv("MOCAP_REMAP_MODE", mode)
+    for mode in ["general", "3", "box_unstaged"]:  # "3" = the product path (box kernel, staged source)
+        monkeypatch.delenv("MOCAP_GENERAL_FILTER", raising=False)
+        monkeypatch.delenv("MOCAP_BOX_STAGE_BYTES", raising=False)
+        if mode == "general":
+            monkeypatch.setenv("MOCAP_GENERAL_FILTER", "1")
+        if mode == "box_unstaged":
+            monkeypatch.setenv("MOCAP_BOX_STAGE_BYTES", "0")
         ctx = MocapContext(1920, 1080, n_slots=6)
         for s in range(6):
             ctx.set_undistort(s, sc.K, sc.dist)
