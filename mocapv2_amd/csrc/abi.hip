@@ -41,7 +41,7 @@ struct EvPair { hipEvent_t a, b; };
 
 struct mocap_ctx {
     int device, W, H, n_slots, wpr;
-    int box_grid;             // workgroups of the box kernel: 8 single-wave workgroups per CU
+    int box_grid;             // workgroups of the box kernel: the resident ones (box_filter_blocks_per_cu() per CU)
     mocap_blob_params prm;
     uint32_t* maps;           // [2][n_slots][H][W]: tap positions, then blend weights (general form)
     uint32_t* map4;           // [n_slots][H][W] (+ 4 words): compact table of the box kernel
@@ -155,15 +155,18 @@ int mocap_ctx_create(int device_id, int width, int height, int n_slots, mocap_ct
     {
         hipDeviceProp_t prop;
         c->box_grid = 2048;
-        if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->box_grid = 8 * prop.multiProcessorCount;
+        if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) {
+            c->box_grid = box_filter_blocks_per_cu() * prop.multiProcessorCount;
+            { const char* e = getenv("MOCAP_BOX_BLOCKS_PER_CU"); if (e && atoi(e) >= 1 && atoi(e) <= 32) c->box_grid = atoi(e) * prop.multiProcessorCount; } // A/B switch
+        }
     }
     c->slot_state.assign(n_slots, 0);
     c->slot_compact.assign(n_slots, 0);
     c->slot_wmax.assign(n_slots, 0);
     hipError_t e = hipMalloc(&c->map_flags, sizeof(uint32_t) * n_slots + 256);
     if (e == hipSuccess) e = hipMemset(c->map_flags, 0, sizeof(uint32_t) * n_slots + 256);
-    if (e == hipSuccess) e = hipMalloc(&c->n_items, 256);
-    if (e == hipSuccess) e = hipMemset(c->n_items, 0, 256);
+    if (e == hipSuccess) e = hipMalloc(&c->n_items, 1024); // item count + the 8 head words of the box kernel's runs
+    if (e == hipSuccess) e = hipMemset(c->n_items, 0, 1024);
     if (e == hipSuccess) e = hipMalloc(&c->cams, sizeof(CameraTable));
     if (e == hipSuccess) e = hipMemset(c->cams, 0, sizeof(CameraTable));
     if (e != hipSuccess) {
@@ -432,32 +435,6 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
     { const char* e = getenv("MOCAP_GENERAL_FILTER"); if (e && atoi(e) != 0) compact = false; } // test switch: the general kernel
     if (cells == c->cells) c->last_images = n_images;
     EvPair p; bool on;
-    if (!compact) {
-        // general dense kernel (tiny images, tables beyond the compact format): every tile, every mask byte
-        FilterArgs a;
-        a.src = (const uint8_t*)frames; a.image_stride = image_stride; a.pitch = pitch; a.H = c->H; a.W = c->W;
-        a.mask = mask; a.words_per_row = c->wpr; a.cam_mod = cam_mod; a.cells = cells;
-        a.map = c->maps ? c->maps + (size_t)slot_base * c->H * c->W : nullptr;
-        a.mapw = c->maps ? c->maps + (size_t)(c->n_slots + slot_base) * c->H * c->W : nullptr;
-        a.n_images = n_images; a.n_steps = (n_images + cam_mod - 1) / cam_mod;
-        a.thr_mul = thr_mul;
-        a.n_strips = tl.n_strips; a.rows_per_chunk = tl.rows; a.n_cgroups = tl.n_cgroups;
-        if (bayer) { launch_bayer_gray(*bayer, s); HIP_TRY(hipGetLastError()); }
-        if (own_mask) c->mask_dirty = true;
-        prof_begin(c, 0, s, p, on);
-        launch_filter_mask(a, remap, s);
-        prof_end(c, 0, s, p, on);
-        HIP_TRY(hipGetLastError());
-        return 0;
-    }
-    if (own_mask && c->mask_dirty) { // the general kernel wrote the whole mask last time: back to "zero outside the regions"
-        HIP_TRY(hipMemsetAsync(c->mask, 0, sizeof(uint32_t) * c->mask_images * c->H * c->wpr, s));
-        std::vector<uint32_t> init(c->mask_images * cells_per_image(c) * 4);
-        for (size_t i = 0; i < init.size(); i += 4) { init[i] = 1u; init[i + 1] = 1u; init[i + 2] = 1u; init[i + 3] = 1u; }
-        HIP_TRY(hipStreamSynchronize(s));
-        HIP_TRY(hipMemcpy(c->cur_box, init.data(), sizeof(uint32_t) * init.size(), hipMemcpyHostToDevice));
-        c->mask_dirty = false;
-    }
     // dark-tile early-out: largest doubled excess sum 2E (E = sum of max(0, p - base)) per 16x16 block that still proves an
     // all-zero mask:   2E * Wmax < 1024 * taps_min * (2 * thr_mul - 2 * base - 1)     (derivation: blob_filter.hip)
     const int base = excess_base(thr_mul);
@@ -481,6 +458,37 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
         }
         { const char* e = getenv("MOCAP_SKIP_DARK"); if (e && atoi(e) == 0) allow = -1; }
     }
+    // every tile has to be filtered anyway: the dense kernel's sliding row pipeline does that with less work per pixel
+    // than the box kernel (MOCAP_DENSE_BOXES=1: the box kernel on whole tiles, a test switch)
+    { const char* e = getenv("MOCAP_DENSE_BOXES"); if (allow < 0 && !(e && atoi(e) != 0)) compact = false; }
+    if (!compact) {
+        // general dense kernel (tiny images, tables beyond the compact format): every tile, every mask byte
+        FilterArgs a;
+        a.src = (const uint8_t*)frames; a.image_stride = image_stride; a.pitch = pitch; a.H = c->H; a.W = c->W;
+        a.mask = mask; a.words_per_row = c->wpr; a.cam_mod = cam_mod; a.cells = cells;
+        a.map = c->maps ? c->maps + (size_t)slot_base * c->H * c->W : nullptr;
+        a.mapw = c->maps ? c->maps + (size_t)(c->n_slots + slot_base) * c->H * c->W : nullptr;
+        a.n_images = n_images; a.n_steps = (n_images + cam_mod - 1) / cam_mod;
+        a.thr_mul = thr_mul;
+        a.n_strips = tl.n_strips; a.rows_per_chunk = tl.rows; a.n_cgroups = tl.n_cgroups;
+        a.pipelined = c->W >= 4 && (c->W & 3) == 0 && c->H >= 2;
+        { const char* e = getenv("MOCAP_REMAP_PIPELINE"); if (e && atoi(e) == 0) a.pipelined = 0; } // test switch: the per-pixel gather
+        if (bayer) { launch_bayer_gray(*bayer, s); HIP_TRY(hipGetLastError()); }
+        if (own_mask) c->mask_dirty = true;
+        prof_begin(c, 0, s, p, on);
+        launch_filter_mask(a, remap, s);
+        prof_end(c, 0, s, p, on);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    if (own_mask && c->mask_dirty) { // the general kernel wrote the whole mask last time: back to "zero outside the regions"
+        HIP_TRY(hipMemsetAsync(c->mask, 0, sizeof(uint32_t) * c->mask_images * c->H * c->wpr, s));
+        std::vector<uint32_t> init(c->mask_images * cells_per_image(c) * 4);
+        for (size_t i = 0; i < init.size(); i += 4) { init[i] = 1u; init[i + 1] = 1u; init[i + 2] = 1u; init[i + 3] = 1u; }
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipMemcpy(c->cur_box, init.data(), sizeof(uint32_t) * init.size(), hipMemcpyHostToDevice));
+        c->mask_dirty = false;
+    }
     BoxArgs a;
     a.src = (const uint8_t*)frames; a.image_stride = image_stride; a.pitch = pitch; a.H = c->H; a.W = c->W;
     a.mask = mask; a.words_per_row = c->wpr; a.cells = cells;
@@ -499,8 +507,8 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
     { const char* e = getenv("MOCAP_BOX_PRIO"); if (e) a.prio = atoi(e) != 0; } // A/B switch
     { const char* e = getenv("MOCAP_BOX_STAGE_BYTES"); if (e && atoi(e) >= 0 && atoi(e) < BOX_SCAP) a.stage_bytes = atoi(e); } // test switch
     a.ext_mask = own_mask ? 0 : 1;
-    if ((size_t)n_images * cells_per_image(c) * 4 > (size_t)c->cap_items) return fail(MOCAP_E_STATE, "work list smaller than the batch");
-    HIP_TRY(hipMemsetAsync(c->n_items, 0, sizeof(uint32_t), s));
+    if ((size_t)n_images * cells_per_image(c) * BOX_MAX_PARTS > (size_t)c->cap_items) return fail(MOCAP_E_STATE, "work list smaller than the batch");
+    HIP_TRY(hipMemsetAsync(c->n_items, 0, 1024, s));
     if (!a.dense) { // one streaming pass over the frames marks the tiles (and their boxes) that can hold set pixels
         // floor(i / ncx) = umulhi(i, ceil(2^32 / ncx)) is exact while i * ncx < 2^32
         uint64_t ncx64 = (uint64_t)((c->W + 7) / 8);
@@ -531,10 +539,31 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
     launch_settle_tiles(a, s);
     prof_end(c, 4, s, p, on);
     HIP_TRY(hipGetLastError());
+    a.timing = nullptr;
+    static const bool box_timing = getenv("MOCAP_BOX_TIMING") && atoi(getenv("MOCAP_BOX_TIMING")) != 0;
+    if (box_timing) { // debugging aid: synchronous, prints the mean duration of the box kernel's phases
+        HIP_TRY(hipMalloc(&a.timing, sizeof(uint64_t) * 6 * c->box_grid));
+        HIP_TRY(hipMemsetAsync(a.timing, 0, sizeof(uint64_t) * 6 * c->box_grid, s));
+    }
     prof_begin(c, 0, s, p, on);
     launch_box_filter(a, c->box_grid, s);
     prof_end(c, 0, s, p, on);
     HIP_TRY(hipGetLastError());
+    if (box_timing) {
+        std::vector<uint64_t> t((size_t)6 * c->box_grid);
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipMemcpy(t.data(), a.timing, sizeof(uint64_t) * t.size(), hipMemcpyDeviceToHost));
+        (void)hipFree(a.timing);
+        double sum[6] = {0, 0, 0, 0, 0, 0}, mx = 0;
+        for (int b = 0; b < c->box_grid; b++) {
+            double tot = 0;
+            for (int i = 0; i < 6; i++) { sum[i] += (double)t[6 * b + i]; if (i < 5) tot += (double)t[6 * b + i]; }
+            mx = tot > mx ? tot : mx;
+        }
+        const double n = sum[5] > 0 ? sum[5] : 1;
+        fprintf(stderr, "[box] items %.0f (%.1f per wave) | cycles per item: header+wait %.0f, stage %.0f, patch %.0f, threshold %.0f, majority+next %.0f | busiest wave %.0f cycles\n",
+                sum[5], sum[5] / c->box_grid, sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n, mx);
+    }
     return 0;
 }
 
@@ -624,7 +653,7 @@ static int ensure_mask(mocap_ctx* c, int n_images)
         for (size_t i = 0; i < init.size(); i++) init[i] = 1u;
         HIP_TRY(hipMalloc(&c->cur_box, sizeof(uint32_t) * init.size()));
         HIP_TRY(hipMemcpy(c->cur_box, init.data(), sizeof(uint32_t) * init.size(), hipMemcpyHostToDevice));
-        const size_t cap = (size_t)n_images * cells_per_image(c) * 4; // settle_tiles_kernel cuts a tile into at most 4 items
+        const size_t cap = (size_t)n_images * cells_per_image(c) * BOX_MAX_PARTS; // settle_tiles_kernel cuts a tile into at most that many items
         if (cap > 0xffffffffull) return fail(MOCAP_E_UNSUPPORTED, "batch too large for the work list");
         HIP_TRY(hipMalloc(&c->items, sizeof(BoxItem) * cap));
         c->cap_items = (uint32_t)cap;
@@ -746,6 +775,7 @@ int mocap_image_filter_u8(mocap_ctx_t c, const void* src, void* dst, int spitch,
     a.thr_mul = ithresh + 1;
     Tiling tl = tiling(c);
     a.n_strips = tl.n_strips; a.rows_per_chunk = tl.rows; a.n_cgroups = tl.n_cgroups;
+    a.pipelined = c->W >= 4 && (c->W & 3) == 0 && c->H >= 2;
     c->mask_dirty = true; c->last_images = 1;
     launch_filter_mask(a, slot >= 0 && c->slot_state[slot] == 2, s);
     HIP_TRY(hipGetLastError());

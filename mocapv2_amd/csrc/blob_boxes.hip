@@ -73,7 +73,7 @@ void launch_srcbox(const uint32_t* map4, ushort4* srcbox, int H, int W, hipStrea
 }
 
 // ---- settle: boxes -> work items ----------------------------------------------------------------------------------------
-// How a tile's output region (nb mask bytes wide, h rows) is cut into items: nx x ny parts (nx * ny <= 4) such that a
+// How a tile's output region (nb mask bytes wide, h rows) is cut into items: nx x ny parts (nx * ny <= BOX_MAX_PARTS) such that a
 // part's patch -- (bytes * 2 + 2) quads x (rows + 8) -- fits BOX_HCAP quad-rows, minimising the wave instructions
 // ("trips": rows per instruction = 64 / quads) plus a fixed cost per item.
 __device__ __forceinline__ void choose_split(int nb, int h, int& nx, int& ny)
@@ -86,7 +86,7 @@ __device__ __forceinline__ void choose_split(int nb, int h, int& nx, int& ny)
         const int rpw = 64 / Q, mr = BOX_HCAP / Q - 8;
         if (mr < 1) continue;
         const int cy = (h + mr - 1) / mr;
-        if (cx * cy > 4) continue;
+        if (cx * cy > BOX_MAX_PARTS) continue;
         const int ph = (h + cy - 1) / cy;
         const int cost = cx * cy * ((ph + 8 + rpw - 1) / rpw + 8);
         if (cost < best) { best = cost; nx = cx; ny = cy; }
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void settle_tiles_kernel(BoxArgs a)
             for (int jx = 0; jx < nx; jx++, o++) {
                 const int x0 = ox0 + 8 * pb * jx, x1 = imin(x0 + 8 * pb - 1, ox1);
                 const int y0 = oy0 + ph * jy, y1 = imin(y0 + ph - 1, oy1);
-                if (o >= a.cap_items) continue; // cannot happen: nx * ny <= 4 per tile and the list holds 4 per tile
+                if (o >= a.cap_items) continue; // cannot happen: the list holds BOX_MAX_PARTS items per tile
                 uint4 it;
                 it.x = (uint32_t)image;
                 it.y = (uint32_t)(chunk * a.n_strips + strip);
@@ -276,6 +276,7 @@ __global__ __launch_bounds__(64) void box_filter_kernel(BoxArgs a)
     uint32_t* __restrict__ const a_cells = a.cells;
     const uint32_t a_cap_items = a.cap_items;
     const uint32_t* const a_n_items = a.n_items;
+    uint64_t* const a_timing = a.timing;
     if (a.prio) __builtin_amdgcn_s_setprio(2); // A/B switch: these waves compute, the scan's waves of the next batch wait on HBM
     // lut[w]: byte k = number of set bits among bits k..k+4 of the 8-bit window w
 #pragma unroll
@@ -287,28 +288,65 @@ __global__ __launch_bounds__(64) void box_filter_kernel(BoxArgs a)
     }
     uint32_t n_items = *a_n_items;
     n_items = n_items < a_cap_items ? n_items : a_cap_items;
-    const int G = gridDim.x;
-    // blocks b and b + 8 share an XCD: give each XCD runs of consecutive items (they share table lines, see settle)
-    const uint32_t first = (G & 7) == 0 ? (uint32_t)((blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3)) : blockIdx.x;
+    // The list is cut into 8 runs of consecutive items, one per XCD (blocks b and b + 8 share an XCD; consecutive items share
+    // undistort-table lines, see settle).  A wave takes the next item of its run with one atomic add on the run's head word
+    // -- requested an item ahead, so its latency hides behind the filtering -- and moves on to the next run when its own is
+    // exhausted: items differ in cost, a fixed deal left the busiest wave with 1.4x the mean.
+    uint32_t* const heads = a.n_items + 16; // 8 head words, 64 bytes apart
+    int shard = blockIdx.x & 7, tries = 0;
+    auto take = [&]() __attribute__((always_inline)) -> uint32_t { // index of the next item, or 0xffffffff when the list is exhausted
+        for (;;) {
+            const uint32_t lo = (uint32_t)(((uint64_t)n_items * (uint32_t)shard) >> 3), hi = (uint32_t)(((uint64_t)n_items * (uint32_t)(shard + 1)) >> 3);
+            uint32_t i = 0;
+            if (lane == 0) i = atomicAdd(heads + 16 * shard, 1u);
+            i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+            if (i < hi - lo) return lo + i;
+            if (++tries >= 8) return 0xffffffffu;
+            shard = (shard + 1) & 7;
+        }
+    };
     const int H = a.H, W = a.W, Hm1 = H - 1;
     const int row_bytes = a_words_per_row * 4;
     const int cam_mod = a.cam_mod;
     const uint64_t remap_bits = a.remap_bits;
     const ushort4* __restrict__ srcbox = a.srcbox;
     const uint4* __restrict__ items = (const uint4*)a.items;
-    if (first >= n_items) return;
+    // the same in two halves, so that the atomic's round trip hides behind an item's work: request now, look later
+    auto take_request = [&]() __attribute__((always_inline)) -> uint32_t {
+        uint32_t i = 0;
+        if (lane == 0 && tries < 8) i = atomicAdd(heads + 16 * shard, 1u);
+        return i;
+    };
+    auto take_resolve = [&](uint32_t i) __attribute__((always_inline)) -> uint32_t {
+        if (tries >= 8) return 0xffffffffu;
+        const uint32_t lo = (uint32_t)(((uint64_t)n_items * (uint32_t)shard) >> 3), hi = (uint32_t)(((uint64_t)n_items * (uint32_t)(shard + 1)) >> 3);
+        i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+        if (i < hi - lo) return lo + i;
+        if (++tries >= 8) return 0xffffffffu;
+        shard = (shard + 1) & 7;
+        return take(); // this run is exhausted: the next ones, synchronously (the tail of the kernel only)
+    };
+    uint32_t item = take();
+    if (item == 0xffffffffu) return;
+    uint32_t nitem = take();
 
-    uint4 h0 = items[2 * first], h1 = items[2 * first + 1];
+    uint64_t tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = a.timing ? __builtin_readcyclecounter() : 0; // phase clock (debugging aid)
+    auto tick = [&](int i) __attribute__((always_inline)) { if (a_timing) { const uint64_t now = __builtin_readcyclecounter(); tacc[i] += now - tlast; tlast = now; } };
+    uint4 h0 = items[2 * item], h1 = items[2 * item + 1];
     BoxGeom g = box_geometry(H, W, cam_mod, remap_bits, h0, h1);
     SrcBounds sbp = source_bounds_partial(srcbox, H, W, g, lane);
 
-    for (uint32_t item = first; item < n_items; item += (uint32_t)G) {
-        // header of the next item: requested now, looked at when this item's patch is done
-        const uint32_t nxt = item + (uint32_t)G < n_items ? item + (uint32_t)G : item;
+    while (item != 0xffffffffu) {
+        // the next item's header and the index of the one after it: requested now, looked at when this item's patch is done /
+        // at the end of the iteration
+        const uint32_t nxt = nitem != 0xffffffffu ? nitem : item;
         const uint4 n0 = items[2 * nxt], n1 = items[2 * nxt + 1];
+        const uint32_t nn_raw = take_request();
         if (!g.valid) { // an empty part of a split
             g = box_geometry(H, W, cam_mod, remap_bits, n0, n1);
             sbp = source_bounds_partial(srcbox, H, W, g, lane);
+            item = nitem;
+            nitem = take_resolve(nn_raw);
             continue;
         }
         const int image = g.image, tile = g.tile, slot = g.slot;
@@ -330,6 +368,7 @@ __global__ __launch_bounds__(64) void box_filter_kernel(BoxArgs a)
         const uint8_t* __restrict__ img = a_src + (size_t)image * a_image_stride;
         const int ntrip_a = (PR + rpw - 1) / rpw, ngroup_a = (ntrip_a + BOX_GROUP - 1) / BOX_GROUP;
         __syncthreads(); // (single wave) the previous item's LDS reads are done
+        tick(0);
 
         // ---- pass A: undistorted patch -> horizontal 5-sums of every patch row, in LDS -----------------------------------
         // hsum of one patch row's quad B (4 bytes): packed 16-bit sums of the 5 columns around each pixel
@@ -343,8 +382,16 @@ __global__ __launch_bounds__(64) void box_filter_kernel(BoxArgs a)
             const int at = (lane_on && r < PR) ? __mul24(r, Q) + q : BOX_HCAP + lane;
             Hs[at] = make_uint2(h0_ | (h1_ << 16), h2_ | (h3_ << 16));
         };
+        // patch rows outside the exact region are zeros: trips [0, ka0) and [ka1, ntrip_a) hold none of its rows
+        const int ka0 = g.exact ? (ey0 - hy0) / rpw : ntrip_a, ka1 = g.exact ? (ey1 - hy0) / rpw + 1 : ntrip_a;
+        for (int k = 0; k < ntrip_a; k++) {
+            if (k == ka0) k = ka1;
+            if (k >= ntrip_a) break;
+            const int r = k * rpw + rsub;
+            Hs[(lane_on && r < PR) ? __mul24(r, Q) + q : BOX_HCAP + lane] = make_uint2(0u, 0u);
+        }
+        const int ngroup_e = (ka1 - ka0 + BOX_GROUP - 1) / BOX_GROUP; // groups of trips of the exact region
         if (!g.exact) {
-            for (int k = 0; k < ntrip_a; k++) store_h(0u, k * rpw + rsub);
         } else if (!g.remap) {
             // identity map: the patch is the frame
             const int ax = xc > W - 4 ? W - 4 : xc; // W >= 4
@@ -352,24 +399,24 @@ __global__ __launch_bounds__(64) void box_filter_kernel(BoxArgs a)
             auto load_rows = [&](uint32_t (&raw)[BOX_GROUP], int gi) __attribute__((always_inline)) {
 #pragma unroll
                 for (int u = 0; u < BOX_GROUP; u++) {
-                    const int y = hy0 + (gi * BOX_GROUP + u) * rpw + rsub, yc = y < ey0 ? ey0 : (y > ey1 ? ey1 : y);
+                    const int y = hy0 + (ka0 + gi * BOX_GROUP + u) * rpw + rsub, yc = y < ey0 ? ey0 : (y > ey1 ? ey1 : y);
                     __builtin_memcpy(&raw[u], img + ((uint32_t)yc * (uint32_t)a_pitch + (uint32_t)ax), 4);
                 }
             };
             auto use_rows = [&](const uint32_t (&raw)[BOX_GROUP], int gi) __attribute__((always_inline)) {
 #pragma unroll
                 for (int u = 0; u < BOX_GROUP; u++) {
-                    const int r = (gi * BOX_GROUP + u) * rpw + rsub, y = hy0 + r;
+                    const int kt = ka0 + gi * BOX_GROUP + u, r = kt * rpw + rsub, y = hy0 + r;
                     const bool ok = q_exact && y >= ey0 && y <= ey1;
-                    store_h(ok ? ((raw[u] >> sh) & bytemask) : 0u, r);
+                    store_h(ok ? ((raw[u] >> sh) & bytemask) : 0u, kt < ka1 ? r : PR);
                 }
             };
             uint32_t ra[BOX_GROUP], rb[BOX_GROUP];
             load_rows(ra, 0);
-            for (int gi = 0; gi < ngroup_a; gi += 2) {
+            for (int gi = 0; gi < ngroup_e; gi += 2) {
                 load_rows(rb, gi + 1);
                 use_rows(ra, gi);
-                if (gi + 1 < ngroup_a) {
+                if (gi + 1 < ngroup_e) {
                     load_rows(ra, gi + 2);
                     use_rows(rb, gi + 1);
                 }
@@ -389,7 +436,7 @@ __global__ __launch_bounds__(64) void box_filter_kernel(BoxArgs a)
             auto load_table = [&](uint4 (&tw)[BOX_GROUP], int gi) __attribute__((always_inline)) {
 #pragma unroll
                 for (int u = 0; u < BOX_GROUP; u++) {
-                    const int y = hy0 + (gi * BOX_GROUP + u) * rpw + rsub, yc = y < ey0 ? ey0 : (y > ey1 ? ey1 : y);
+                    const int y = hy0 + (ka0 + gi * BOX_GROUP + u) * rpw + rsub, yc = y < ey0 ? ey0 : (y > ey1 ? ey1 : y);
                     __builtin_memcpy(&tw[u], map4 + ((uint32_t)yc * (uint32_t)W + (uint32_t)xc), 16);
                 }
             };
@@ -426,6 +473,7 @@ __global__ __launch_bounds__(64) void box_filter_kernel(BoxArgs a)
                     }
                 }
                 __syncthreads();
+                tick(1);
             } else {
                 load_table(ta, 0);
             }
@@ -434,11 +482,15 @@ __global__ __launch_bounds__(64) void box_filter_kernel(BoxArgs a)
                 constexpr bool STAGED = decltype(staged_c)::value;
 #pragma unroll
                 for (int u = 0; u < BOX_GROUP; u++) {
-                    const int r = (gi * BOX_GROUP + u) * rpw + rsub, y = hy0 + r;
+                    const int kt = ka0 + gi * BOX_GROUP + u, r = kt * rpw + rsub, y = hy0 + r;
                     const int yc = y < ey0 ? ey0 : (y > ey1 ? ey1 : y);
-                    const bool ok = q_exact && y >= ey0 && y <= ey1;
+                    // lanes outside the exact region blend a pixel of it (clamped row / quad) and drop the result: no branch,
+                    // so that the trips of a group overlap their LDS reads
+                    uint32_t okm = (q_exact && y >= ey0 && y <= ey1) ? bytemask : 0u;
+                    asm volatile("" : "+v"(okm));
                     const uint32_t ww[4] = {tw[u].x, tw[u].y, tw[u].z, tw[u].w};
-                    const int rowbase = __mul24(yc - sya, SP) + (xc - sxa); // LDS offset of (xc, yc)
+                    int rowbase = __mul24(yc - sya, SP) + (xc - sxa); // LDS offset of (xc, yc)
+                    asm volatile("" : "+v"(rowbase)); // (keeps dy * SP a 24-bit multiply-add of its own)
                     uint32_t B = 0;
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
@@ -464,14 +516,14 @@ __global__ __launch_bounds__(64) void box_filter_kernel(BoxArgs a)
                         const uint32_t rr = (__umul24(top, wb) + __umul24(bot, fb) + 512u) >> 10; // == (sum of 32*w*p + 2^14) >> 15
                         B |= rr << (8 * k);
                     }
-                    store_h(ok ? (B & bytemask) : 0u, r);
+                    store_h(B & okm, kt < ka1 ? r : PR);
                 }
             };
             auto remap_rows = [&](auto staged_c) __attribute__((always_inline)) {
-                for (int gi = 0; gi < ngroup_a; gi += 2) {
+                for (int gi = 0; gi < ngroup_e; gi += 2) {
                     load_table(tb, gi + 1);
                     blend_rows(staged_c, ta, gi);
-                    if (gi + 1 < ngroup_a) {
+                    if (gi + 1 < ngroup_e) {
                         load_table(ta, gi + 2);
                         blend_rows(staged_c, tb, gi + 1);
                     }
@@ -481,6 +533,7 @@ __global__ __launch_bounds__(64) void box_filter_kernel(BoxArgs a)
             else remap_rows(std::false_type{});
         }
         __syncthreads();
+        tick(2);
         // the next item: its geometry, and the loads of its source box (in flight during passes B and C)
         const BoxGeom gn = box_geometry(H, W, cam_mod, remap_bits, n0, n1);
         const SrcBounds sbn = source_bounds_partial(srcbox, H, W, gn, lane);
@@ -492,35 +545,44 @@ __global__ __launch_bounds__(64) void box_filter_kernel(BoxArgs a)
         const int qe = (W - 1 - px0) >> 2, be = (W - 1 - px0) & 3;    // quad / bit of column W - 1
         const int ntrip_b = (ty1 - ty0 + 1 + rpw - 1) / rpw;
         const int hstep = Q;                                          // Hs entries per patch row
-        for (int k = 0; k < ntrip_b; k++) {
-            const int y = ty0 + k * rpw + rsub, yb = imin(y, ty1), rh = yb - hy0; // H row of the threshold row (>= 2)
-            const uint2* hp = Hs + (__mul24(rh - 2, hstep) + q);
-            const uint2 v0 = hp[0], v1 = hp[hstep], v2 = hp[2 * hstep], v3 = hp[3 * hstep], v4 = hp[4 * hstep];
-            const uint32_t V01 = v0.x + v1.x + v2.x + v3.x + v4.x, V23 = v0.y + v1.y + v2.y + v3.y + v4.y;
-            const uint32_t m = (uint32_t)__mul24(a_thr_mul, taps5(yb, H));
-            const uint32_t T01 = __umul24(cx01, m), T23 = __umul24(cx23, m);
-            const uint32_t d01 = (V01 | 0x80008000u) - T01, d23 = (V23 | 0x80008000u) - T23;
-            const uint32_t t = (d01 >> 15) & 0x10001u, u = (d23 >> 15) & 0x10001u;
-            const uint32_t wv = t | (u << 2);
-            uint32_t nib = (wv | (wv >> 15)) & 0xfu;
-            // medianBlur replicates the border: columns outside the image take the edge column's bit
-            if (left_edge) { // quad 0 = columns -4..-1, quad 1 starts at column 0
-                const uint32_t e = from_next(nib) & 1u;
-                if (q == 0) nib = e ? 0xfu : 0u;
+        auto pass_b = [&](auto edge_c) __attribute__((always_inline)) {
+            constexpr bool EDGE = decltype(edge_c)::value; // the patch sticks out of the image on the left or right
+#pragma unroll 2
+            for (int k = 0; k < ntrip_b; k++) {
+                const int y = ty0 + k * rpw + rsub, yb = imin(y, ty1), rh = yb - hy0; // H row of the threshold row (>= 2)
+                const uint2* hp = Hs + (__mul24(rh - 2, hstep) + q);
+                const uint2 v0 = hp[0], v1 = hp[hstep], v2 = hp[2 * hstep], v3 = hp[3 * hstep], v4 = hp[4 * hstep];
+                const uint32_t V01 = v0.x + v1.x + v2.x + v3.x + v4.x, V23 = v0.y + v1.y + v2.y + v3.y + v4.y;
+                const uint32_t m = (uint32_t)__mul24(a_thr_mul, taps5(yb, H));
+                const uint32_t T01 = __umul24(cx01, m), T23 = __umul24(cx23, m);
+                const uint32_t d01 = (V01 | 0x80008000u) - T01, d23 = (V23 | 0x80008000u) - T23;
+                const uint32_t t = (d01 >> 15) & 0x10001u, u = (d23 >> 15) & 0x10001u;
+                const uint32_t wv = t | (u << 2);
+                uint32_t nib = (wv | (wv >> 15)) & 0xfu;
+                if (EDGE) {
+                    // medianBlur replicates the border: columns outside the image take the edge column's bit
+                    if (left_edge) { // quad 0 = columns -4..-1, quad 1 starts at column 0
+                        const uint32_t e = from_next(nib) & 1u;
+                        if (q == 0) nib = e ? 0xfu : 0u;
+                    }
+                    if (right_edge) {
+                        const uint32_t ne = (uint32_t)__shfl((int)nib, lane - q + qe);
+                        const uint32_t e = (ne >> be) & 1u, keep = (2u << be) - 1u;
+                        if (q > qe) nib = e ? 0xfu : 0u;
+                        else if (q == qe) nib = (nib & keep) | (e ? (0xfu & ~keep) : 0u);
+                    }
+                }
+                const uint32_t nl = from_prev(nib), nr = from_next(nib);
+                const uint32_t win = (nl >> 2) | (nib << 2) | ((nr & 3u) << 6);
+                const uint32_t c = lut[win & 0xffu];
+                const int at = (lane_on && y <= ty1) ? __mul24(y - ty0, Q) + q : BOX_HCAP + lane;
+                Cs[at] = c;
             }
-            if (right_edge) {
-                const uint32_t ne = (uint32_t)__shfl((int)nib, lane - q + qe);
-                const uint32_t e = (ne >> be) & 1u, keep = (2u << be) - 1u;
-                if (q > qe) nib = e ? 0xfu : 0u;
-                else if (q == qe) nib = (nib & keep) | (e ? (0xfu & ~keep) : 0u);
-            }
-            const uint32_t nl = from_prev(nib), nr = from_next(nib);
-            const uint32_t win = (nl >> 2) | (nib << 2) | ((nr & 3u) << 6);
-            const uint32_t c = lut[win & 0xffu];
-            const int at = (lane_on && y <= ty1) ? __mul24(y - ty0, Q) + q : BOX_HCAP + lane;
-            Cs[at] = c;
-        }
+        };
+        if (left_edge || right_edge) pass_b(std::true_type{});
+        else pass_b(std::false_type{});
         __syncthreads();
+        tick(3);
 
         // ---- pass C: majority (>= 13 of 25) of every output row, two quads -> one byte of the bit mask -----------------
         const int tile_r0 = (tile / a_n_strips) * a_rows_per_chunk;
@@ -530,29 +592,34 @@ __global__ __launch_bounds__(64) void box_filter_kernel(BoxArgs a)
         uint32_t lacc = 0; // bit g: rows 8g..8g+7 of the tile's chunk hold set pixels in this lane's columns
         const int ntrip_c = (oy1 - oy0 + 1 + rpw - 1) / rpw;
         const bool inner = oy0 >= 2 && oy1 + 2 <= Hm1; // no row of the item's windows is replicated
-        for (int k = 0; k < ntrip_c; k++) {
-            const int y = oy0 + k * rpw + rsub, yy = imin(y, oy1);
-            uint32_t Cv = 0;
-            if (inner) {
-                const uint32_t* cp = Cs + (__mul24(yy - 2 - ty0, hstep) + q);
-                Cv = cp[0] + cp[hstep] + cp[2 * hstep] + cp[3 * hstep] + cp[4 * hstep];
-            } else {
+        auto pass_c = [&](auto inner_c) __attribute__((always_inline)) {
+            constexpr bool INNER = decltype(inner_c)::value; // no row of the item's windows is replicated
+#pragma unroll 2
+            for (int k = 0; k < ntrip_c; k++) {
+                const int y = oy0 + k * rpw + rsub, yy = imin(y, oy1);
+                uint32_t Cv = 0;
+                if (INNER) {
+                    const uint32_t* cp = Cs + (__mul24(yy - 2 - ty0, hstep) + q);
+                    Cv = cp[0] + cp[hstep] + cp[2 * hstep] + cp[3 * hstep] + cp[4 * hstep];
+                } else {
 #pragma unroll
-                for (int d = -2; d <= 2; d++) {
-                    const int yr = yy + d < 0 ? 0 : (yy + d > Hm1 ? Hm1 : yy + d); // BORDER_REPLICATE in y
-                    Cv += Cs[__mul24(yr - ty0, Q) + q];
+                    for (int d = -2; d <= 2; d++) {
+                        const int yr = yy + d < 0 ? 0 : (yy + d > Hm1 ? Hm1 : yy + d); // BORDER_REPLICATE in y
+                        Cv += Cs[__mul24(yr - ty0, Q) + q];
+                    }
                 }
+                const uint32_t mm = ((Cv + 0x73737373u) >> 7) & 0x01010101u;
+                const uint32_t t1 = mm | (mm >> 7);
+                const uint32_t mn = (t1 | (t1 >> 14)) & colmask & 0xfu;
+                const uint32_t odd = from_next(mn);
+                const uint32_t byte = mn | ((odd & 0xfu) << 4);
+                const bool st = stores && y <= oy1;
+                if (st) mrow[(size_t)y * row_bytes + out_byte] = (uint8_t)byte;
+                lacc |= ((st && byte != 0u) ? 1u : 0u) << ((yy - tile_r0) >> 3);
             }
-            const uint32_t mm = ((Cv + 0x73737373u) >> 7) & 0x01010101u;
-            const uint32_t t1 = mm | (mm >> 7);
-            const uint32_t mn = (t1 | (t1 >> 14)) & colmask & 0xfu;
-            const uint32_t odd = from_next(mn);
-            const uint32_t byte = mn | ((odd & 0xfu) << 4);
-            if (stores && y <= oy1) {
-                mrow[(size_t)y * row_bytes + out_byte] = (uint8_t)byte;
-                lacc |= (byte != 0u ? 1u : 0u) << ((y - tile_r0) >> 3);
-            }
-        }
+        };
+        if (inner) pass_c(std::true_type{});
+        else pass_c(std::false_type{});
         {   // occupancy word of the tile (read by the contour kernel): OR of every lane's row groups; bit 31 = filtered
             uint32_t cellmask = 0;
             const int g0 = (oy0 - tile_r0) >> 3, g1 = (oy1 - tile_r0) >> 3;
@@ -560,14 +627,27 @@ __global__ __launch_bounds__(64) void box_filter_kernel(BoxArgs a)
                 if (__ballot((lacc >> gg) & 1u) != 0ull) cellmask |= 1u << gg;
             if (lane == 0) atomicOr(&a_cells[idx], cellmask | 0x80000000u);
         }
-        g = gn; sbp = sbn;
+        g = gn; sbp = sbn; item = nitem;
+        nitem = take_resolve(nn_raw);
+        tick(4);
+        tacc[5] += 1;
     }
+    if (a_timing && lane == 0)
+        for (int i = 0; i < 6; i++) a_timing[(size_t)blockIdx.x * 6 + i] = tacc[i];
 }
 
 void launch_settle_tiles(const BoxArgs& a, hipStream_t s)
 {
     const long long total = (long long)a.n_chunks * a.n_strips * a.cam_mod * a.n_steps;
     hipLaunchKernelGGL(settle_tiles_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+}
+
+// resident workgroups of the box kernel per CU (the list is dealt to a grid of exactly the resident workgroups)
+int box_filter_blocks_per_cu()
+{
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, box_filter_kernel, 64, 0) != hipSuccess || n < 1) n = 8;
+    return n;
 }
 
 void launch_box_filter(const BoxArgs& a, int grid, hipStream_t s)

@@ -9,7 +9,7 @@
 //   bright_cells_kernel  streams every frame byte once (the algorithmic HBM traffic of the stage) and records, per
 //                        filter tile, which mask rows and columns can possibly hold a set pixel -- an exact bound, see
 //                        "dark-tile early-out" below.  The boxes it leaves are filtered by blob_boxes.hip;
-//   filter_mask_kernel   the general dense form of the filter (every tile, any image size, any lens model; one wave owns
+//   filter_mask_kernel   the dense form of the filter (every tile, any image size, any lens model; one wave owns
 //                        a strip of 256 source columns and slides down its rows, everything in registers: horizontal
 //                        neighbours from DPP wave shifts, byte sums from v_dot4_u32_u8, vertical 5-row windows as
 //                        running sums whose history sits in a per-wave LDS ring).  Off the hot path: tiny images, tables
@@ -124,6 +124,57 @@ __device__ __forceinline__ uint32_t finish_src4(uint32_t raw, bool row_ok, const
     if (REMAP) return raw;
     uint32_t v = TINY ? raw : ((raw >> lc.shift) & lc.bytemask);
     return row_ok ? v : 0u;
+}
+
+// ---- software-pipelined remap (three stages, each one source row apart in time) -----------------------------
+//   A: issue the load of the row's four packed map words          (8 rows ahead of use)
+//   B: decode them, issue the 2x2 tap loads and the weight load    (4 rows ahead of use)
+//   C: blend the taps                                             (at use)
+// so that neither memory latency is exposed.  Border handling lives in the tables (tap window clamped into the
+// image, weights of outside taps zero), so the stages contain no image-edge logic at all.
+struct MapSlot { uint4 m; };
+struct TapSlot { uint32_t t0[4], t1[4], w[4]; };
+
+__device__ __forceinline__ void remap_issue_map(MapSlot& ms, const uint32_t* __restrict__ map, int row, int H, int W,
+                                                const LaneCols& lc)
+{
+    int rc = row < 0 ? 0 : (row > H - 1 ? H - 1 : row);
+    __builtin_memcpy(&ms.m, map + ((uint32_t)rc * (uint32_t)W + (uint32_t)lc.addr_x), 16);
+}
+
+__device__ __forceinline__ void remap_issue_taps(TapSlot& ts, const MapSlot& ms, const uint8_t* __restrict__ img,
+                                                 const uint32_t* __restrict__ mapw, int pitch, int H, int W, int row,
+                                                 const int xq[4], const LaneCols& lc)
+{
+    // Rows outside the image contribute zeros; their loads are simply those of the nearest row (no branch around
+    // loads: the compiler's in-flight counts stay exact) and next_row() discards the result.
+    row = row < 0 ? 0 : (row > H - 1 ? H - 1 : row);
+    const uint32_t mm[4] = {ms.m.x, ms.m.y, ms.m.z, ms.m.w};
+    uint4 wv4;
+    __builtin_memcpy(&wv4, mapw + ((uint32_t)row * (uint32_t)W + (uint32_t)lc.addr_x), 16);
+    ts.w[0] = wv4.x; ts.w[1] = wv4.y; ts.w[2] = wv4.z; ts.w[3] = wv4.w;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t m = mm[k];
+        int sx = xq[k] + (int)(int16_t)(m & 0xffffu), sy = row + ((int)m >> 16); // inside the image by construction
+        uint32_t off0 = __umul24((uint32_t)sy, (uint32_t)pitch) + (uint32_t)sx, off1 = off0 + (uint32_t)pitch;
+        ts.t0[k] = load_u16(img + off0);
+        ts.t1[k] = load_u16(img + off1);
+    }
+}
+
+__device__ __forceinline__ uint32_t remap_combine(const TapSlot& ts, const LaneCols& lc)
+{
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t w = ts.w[k];
+        uint32_t top = dot4(ts.t0[k], w, 0u), bot = dot4(ts.t1[k], w, 0u); // tap bytes 2,3 are zero
+        uint32_t r = __umul24(top, w >> 24) + 512u;
+        r += __umul24(bot, (w >> 16) & 0xffu);
+        out |= (r >> 10) << (8 * k);
+    }
+    return out & lc.bytemask; // columns outside the image do not exist
 }
 
 // ---- dark-tile early-out ---------------------------------------------------------------------------------------
@@ -265,7 +316,7 @@ __device__ __forceinline__ TileId decode_tile(const FilterArgs& a, int b)
     return t;
 }
 
-template <bool REMAP, bool TINY>
+template <bool REMAP, bool TINY, bool PIPE>
 __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
 {
     __shared__ uint32_t lut[256];
@@ -310,6 +361,7 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
 
         const uint8_t* __restrict__ img = a.src + (size_t)image * a.image_stride;
         const uint32_t* __restrict__ map = REMAP ? a.map + (size_t)slot * a.H * a.W : nullptr;
+        const uint32_t* __restrict__ mapw = REMAP ? a.mapw + (size_t)slot * a.H * a.W : nullptr;
         uint8_t* __restrict__ mrow_base = (uint8_t*)(a.mask + (size_t)image * a.H * a.words_per_row);
         const int row_bytes = a.words_per_row * 4;
 
@@ -340,12 +392,43 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
         // source-row queue, 8 deep.  q[3] holds the first row so that the five set-up slides consume q[3..7] and the
         // steady loop starts at q[0] / ring slot 0 with all indices static.
         uint32_t q[8];
-        const int y0 = kfirst - 2;
+        MapSlot mq[4];
+        TapSlot tq[4];
+        int xq[4];
     #pragma unroll
-        for (int j = 0; j < 8; j++) q[j] = fetch_src4<REMAP, TINY>(a, img, map, y0 + ((j + 5) & 7), xl, lc);
-        // next source row (row index `row`, queue slot J): its four pixels, and the refill of the queue behind it
+        // columns the lane's four table words belong to (lanes outside the image read the nearest in-image group:
+        // their taps stay inside the image, their result is masked out)
+        for (int k = 0; k < 4; k++) xq[k] = lc.addr_x + k;
+        const int y0 = kfirst - 2;
+        if (PIPE) {
+            // slot of source row rho = (rho - (y0 + 5)) & 3, so that the steady loop starts at slot 0
+            remap_issue_map(mq[3], map, y0, a.H, a.W, lc);
+            remap_issue_map(mq[0], map, y0 + 1, a.H, a.W, lc);
+            remap_issue_map(mq[1], map, y0 + 2, a.H, a.W, lc);
+            remap_issue_map(mq[2], map, y0 + 3, a.H, a.W, lc);
+            remap_issue_taps(tq[3], mq[3], img, mapw, a.pitch, a.H, a.W, y0, xq, lc);
+            remap_issue_map(mq[3], map, y0 + 4, a.H, a.W, lc);
+            remap_issue_taps(tq[0], mq[0], img, mapw, a.pitch, a.H, a.W, y0 + 1, xq, lc);
+            remap_issue_map(mq[0], map, y0 + 5, a.H, a.W, lc);
+            remap_issue_taps(tq[1], mq[1], img, mapw, a.pitch, a.H, a.W, y0 + 2, xq, lc);
+            remap_issue_map(mq[1], map, y0 + 6, a.H, a.W, lc);
+            remap_issue_taps(tq[2], mq[2], img, mapw, a.pitch, a.H, a.W, y0 + 3, xq, lc);
+            remap_issue_map(mq[2], map, y0 + 7, a.H, a.W, lc);
+        } else {
+    #pragma unroll
+            for (int j = 0; j < 8; j++) q[j] = fetch_src4<REMAP, TINY>(a, img, map, y0 + ((j + 5) & 7), xl, lc);
+        }
+        // next source row (row index `row`, queue slot J): its four pixels, and the refill of the pipeline behind it
         auto next_row = [&](auto Jc, int row) -> uint32_t {
             constexpr int J = decltype(Jc)::value;
+            if (PIPE) {
+                constexpr int S = J & 3;
+                uint32_t B = remap_combine(tq[S], lc);
+                if ((unsigned)row >= (unsigned)a.H) B = 0u; // wave-uniform select: rows outside the image are zero
+                remap_issue_taps(tq[S], mq[S], img, mapw, a.pitch, a.H, a.W, row + 4, xq, lc);
+                remap_issue_map(mq[S], map, row + 8, a.H, a.W, lc);
+                return B;
+            }
             uint32_t B = finish_src4<REMAP, TINY>(q[J], (unsigned)row < (unsigned)a.H, lc);
             // refill 8 rows ahead, unconditionally (rows past the chunk are clamped into the image and simply
             // unused: a branch here would make the compiler drain the whole queue at the join)
@@ -696,12 +779,14 @@ void launch_remap_stats(const StatArgs& a, hipStream_t s)
 void launch_filter_mask(const FilterArgs& a, bool remap, hipStream_t s)
 {
     const int blocks = a.cam_mod * a.n_cgroups * a.n_steps;
-    if (remap)
-        hipLaunchKernelGGL((filter_mask_kernel<true, false>), dim3(blocks), dim3(256), 0, s, a);
+    if (remap && a.pipelined)
+        hipLaunchKernelGGL((filter_mask_kernel<true, false, true>), dim3(blocks), dim3(256), 0, s, a);
+    else if (remap)
+        hipLaunchKernelGGL((filter_mask_kernel<true, false, false>), dim3(blocks), dim3(256), 0, s, a);
     else if (a.W >= 4)
-        hipLaunchKernelGGL((filter_mask_kernel<false, false>), dim3(blocks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((filter_mask_kernel<false, false, false>), dim3(blocks), dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL((filter_mask_kernel<false, true>), dim3(blocks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((filter_mask_kernel<false, true, false>), dim3(blocks), dim3(256), 0, s, a);
 }
 void launch_bright_cells(const BrightArgs& a, hipStream_t s)
 {

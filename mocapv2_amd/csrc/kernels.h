@@ -5,9 +5,10 @@
 
 namespace mocap {
 
-// The general (any geometry, any lens model) dense filter kernel: every tile of every image, per-pixel gather for
-// remapped cameras.  Off the hot path: used for images narrower than 8 pixels, for undistort tables whose displacements
-// do not fit the compact table of the box kernel, and by the single-image convenience entry points.
+// The dense filter kernel (any geometry, any lens model): every tile of every image, the undistortion as a gather in the
+// row pipeline.  Used when every tile has to be filtered anyway (early-out off or not provable), for images narrower than
+// 8 pixels, for undistort tables whose displacements do not fit the compact table of the box kernel, and by the
+// single-image convenience entry points.
 struct FilterArgs {
     const uint8_t* src;   // images, image_stride bytes apart, rows `pitch` bytes apart
     size_t image_stride;
@@ -18,6 +19,7 @@ struct FilterArgs {
     // undistort tables of the first slot used (remap variant only), each [cam_mod][H][W]:
     const uint32_t* map;  //   tap position: (sx - x) | (sy - y) << 16, the 2x2 tap window clamped into the image
     const uint32_t* mapw; //   blend weights 32*(wx0 | wx1<<8 | wy1<<16 | wy0<<24)/32, taps outside the image weigh 0
+    int pipelined;        // 1 = software-pipelined gather (table words 8 rows ahead, taps 4 rows ahead; W % 4 == 0, H >= 2), 0 = per-pixel gather
     int cam_mod;          // undistort slot of image n = n % cam_mod (map already points at the first slot)
     int n_images, n_steps; // n_steps = ceil(n_images / cam_mod)
     int thr_mul;          // floor(thresh)+1: blurred > thresh  <=>  S >= thr_mul * taps
@@ -27,8 +29,9 @@ struct FilterArgs {
 // The sparse half of the filter stage (blob_boxes.hip): tiles, boxes, work items.
 // A tile = 240 mask columns x rows_per_chunk rows.  The scan kernel leaves per tile the box of mask rows / columns that
 // hot cells can reach (tile_rows); settle_tiles_kernel turns the boxes into items; box_filter_kernel consumes them.
-constexpr int BOX_HCAP = 1536; // quad-rows (4 pixels x 1 row) of one item's patch
-constexpr int BOX_SCAP = 6656; // bytes of source pixels staged in LDS per item
+constexpr int BOX_HCAP = 1536; // quad-rows (4 pixels x 1 row) of one item's patch (halving it for twice the waves per CU: 0.63 against 0.53 ms)
+constexpr int BOX_SCAP = 6656; // bytes of source pixels staged in LDS per item (>= (BOX_HCAP + 64) * 4: the counts alias it)
+constexpr int BOX_MAX_PARTS = 4;  // items a tile is cut into at most (a whole 240 x 68 tile: 2 x 2)
 struct BoxItem { uint32_t image, tile, x01, y01, bx01, by01, pad0, pad1; }; // output region: columns x0 | x1 << 16, rows y0 | y1 << 16
                                                                         //   (x0 > x1: skip); the scan's box of the tile (not clipped to it)
 struct BoxArgs {
@@ -48,7 +51,8 @@ struct BoxArgs {
     uint32_t* cur_box;          // [n_images][n_chunks][n_strips][4]: words 0-1 the tile's output region of this batch
                                 //   (x0 | x1 << 16, y0 | y1 << 16; x0 > x1 = none) = what the mask may hold there; words 2-3 the
                                 //   scan's box (not clipped to the tile)
-    BoxItem* items; uint32_t* n_items; uint32_t cap_items;
+    BoxItem* items; uint32_t* n_items; uint32_t cap_items; // n_items[0] = items in the list; n_items[16 + 16 x] = head of run x (box kernel)
+    uint64_t* timing;           // optional [grid][6] phase clock of the box kernel (MOCAP_BOX_TIMING=1, a debugging aid), else null
     int prio;                   // 1 = raise the wave priority of the box kernel (A/B switch)
     int stage_bytes;            // LDS bytes the source staging may use (BOX_SCAP; smaller values are a test switch)
     int dense;                  // 1 = no early-out: every tile is filtered whole
@@ -56,6 +60,7 @@ struct BoxArgs {
 };
 void launch_settle_tiles(const BoxArgs& a, hipStream_t s);
 void launch_box_filter(const BoxArgs& a, int grid, hipStream_t s);
+int box_filter_blocks_per_cu();
 void launch_srcbox(const uint32_t* map4, ushort4* srcbox, int H, int W, hipStream_t s);
 
 struct MapArgs {

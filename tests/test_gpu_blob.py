@@ -58,18 +58,23 @@ def test_filter_mask_identity(torch_cuda, W, H):
 
 @pytest.mark.parametrize("W,H", [(64, 48), (250, 130), (251, 77), (500, 300), (960, 540)])
 @pytest.mark.parametrize("scale", [1.0, 4.0, -3.0])
-@pytest.mark.parametrize("mode", ["box", "box_unstaged", "general"])
+@pytest.mark.parametrize("mode", ["box", "box_unstaged", "dense", "dense_gather", "dense_boxes"])
 def test_filter_mask_remap(torch_cuda, monkeypatch, W, H, scale, mode):
     """The remap variants -- the box kernel with its source pixels staged in LDS (the product path), the same with the
-    taps taken from memory (what it does when a box's source region outgrows the LDS buffer), and the general dense
-    kernel (tables beyond the compact format) -- against cv.undistort + filter as restated by the oracle; barrel, strong
-    barrel, pincushion."""
+    taps taken from memory (what it does when a box's source region outgrows the LDS buffer), the dense kernel with its
+    pipelined and its per-pixel gather (early-out off, tables beyond the compact format), and the box kernel on whole
+    tiles -- against cv.undistort + filter as restated by the oracle; barrel, strong barrel, pincushion."""
     from gpu_util import unpack_mask
     torch = torch_cuda
     if mode == "box_unstaged":
         monkeypatch.setenv("MOCAP_BOX_STAGE_BYTES", "0")
-    if mode == "general":
+    if mode in ("dense", "dense_gather"):
         monkeypatch.setenv("MOCAP_GENERAL_FILTER", "1")
+    if mode == "dense_gather":
+        monkeypatch.setenv("MOCAP_REMAP_PIPELINE", "0")
+    if mode == "dense_boxes":
+        monkeypatch.setenv("MOCAP_SKIP_DARK", "0")
+        monkeypatch.setenv("MOCAP_DENSE_BOXES", "1")
     rng = np.random.default_rng(W + H)
     frames = rand_frames(rng, 2, H, W, bright=0.2, blobs=6)
     dist = np.array(MILD_DIST) * scale
