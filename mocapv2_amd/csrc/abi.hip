@@ -59,6 +59,9 @@ struct mocap_ctx {
     uint32_t* tile_rows;                   // [mask_images][tiles][4] the scan's box per tile, beside cells (see BoxArgs)
     uint32_t* cur_box;                     // [mask_images][tiles][4] output region / scan box of the last batch per tile (BoxArgs)
     BoxItem* items; uint32_t* n_items; uint32_t cap_items; // work list of the box kernel
+    // excess base of the scan, adapted between batches: two candidates (tight / tolerant of bright backgrounds), the current
+    // one, and a probe now and then that counts the hot cells both would leave (BrightArgs::probe)
+    int base_sel; int probe_age; bool probe_pending; uint32_t* probe_dev; uint32_t* probe_host; hipEvent_t probe_ev;
     uint32_t* cells_ext; uint32_t* cur_box_ext; size_t cells_ext_images; // the same for caller-owned masks (mocap_filter_mask)
     void* cwork; size_t cwork_images;      // contour kernel workspace, contour_work_bytes() per image
     CameraTable* cams; int n_cam, n_F;
@@ -152,6 +155,7 @@ int mocap_ctx_create(int device_id, int width, int height, int n_slots, mocap_ct
     c->cells_ext = nullptr; c->cur_box_ext = nullptr; c->cells_ext_images = 0; c->cwork = nullptr; c->cwork_images = 0;
     c->cams = nullptr; c->n_cam = 0; c->n_F = 0; c->scratch = nullptr; c->scratch_elems = 0; c->profiling = false;
     c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1;
+    c->base_sel = 1; { const char* e = getenv("MOCAP_BASE_SEL"); if (e) c->base_sel = atoi(e) != 0; } c->probe_age = 0; c->probe_pending = false; c->probe_dev = nullptr; c->probe_host = nullptr; c->probe_ev = nullptr;
     {
         hipDeviceProp_t prop;
         c->box_grid = 2048;
@@ -167,6 +171,9 @@ int mocap_ctx_create(int device_id, int width, int height, int n_slots, mocap_ct
     if (e == hipSuccess) e = hipMemset(c->map_flags, 0, sizeof(uint32_t) * n_slots + 256);
     if (e == hipSuccess) e = hipMalloc(&c->n_items, 1024); // item count + the 8 head words of the box kernel's runs
     if (e == hipSuccess) e = hipMemset(c->n_items, 0, 1024);
+    if (e == hipSuccess) e = hipMalloc(&c->probe_dev, 1024);
+    if (e == hipSuccess) e = hipHostMalloc(&c->probe_host, 1024);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->probe_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(&c->cams, sizeof(CameraTable));
     if (e == hipSuccess) e = hipMemset(c->cams, 0, sizeof(CameraTable));
     if (e != hipSuccess) {
@@ -183,6 +190,9 @@ int mocap_ctx_destroy(mocap_ctx_t c)
     (void)hipSetDevice(c->device);
     for (auto& v : c->ev) for (auto& p : v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (c->comm && g_rccl.lib) { (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
+    if (c->probe_ev) { (void)hipEventSynchronize(c->probe_ev); (void)hipEventDestroy(c->probe_ev); }
+    if (c->probe_dev) (void)hipFree(c->probe_dev);
+    if (c->probe_host) (void)hipHostFree(c->probe_host);
     if (c->maps) (void)hipFree(c->maps);
     if (c->map4) (void)hipFree(c->map4);
     if (c->srcbox) (void)hipFree(c->srcbox);
@@ -407,11 +417,15 @@ static int check_frames(mocap_ctx* c, const void* frames, int n_images, int cam_
 
 
 // Excess base of the scan (BrightArgs::base): pixels count with max(0, p - c).  Exact for any c below the threshold; a
-// higher c ignores brighter backgrounds, a lower c lets a cell hold more bright pixels before it is "hot".
-static int excess_base(int thr_mul)
+// higher c ignores brighter backgrounds, a lower c lets a cell hold more bright pixels before it is "hot" (tighter boxes
+// around the markers).  Two candidates derived from the threshold -- for the reference's 216.75: 63 (tight; a dark IR
+// frame) and 150 (backgrounds up to ~150 cost nothing) -- between which the context switches by itself: on its first batch
+// and every 32nd one after it the scan also counts the cells that are hot under the other base (on every 16th image); the
+// tight one is used whenever it does not leave noticeably more hot cells.  A context starts with the tolerant base (a
+// bright scene filtered with the tight one would cost a dense pass).  MOCAP_EXCESS_BASE=c pins the base (A/B switch).
+static int excess_base(int thr_mul, int sel)
 {
-    int c = thr_mul - 67; // 150 for the reference's threshold (216.75): backgrounds up to ~150 cost nothing, 4 saturated pixels make a cell hot
-    { const char* e = getenv("MOCAP_EXCESS_BASE"); if (e) c = atoi(e); } // A/B switch
+    int c = sel ? thr_mul - 67 : thr_mul - 154;
     if (c > thr_mul - 1) c = thr_mul - 1;
     if (c > 254) c = 254;
     return c < 0 ? 0 : c;
@@ -437,8 +451,23 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
     EvPair p; bool on;
     // dark-tile early-out: largest doubled excess sum 2E (E = sum of max(0, p - base)) per 16x16 block that still proves an
     // all-zero mask:   2E * Wmax < 1024 * taps_min * (2 * thr_mul - 2 * base - 1)     (derivation: blob_filter.hip)
-    const int base = excess_base(thr_mul);
-    int allow = -1, allow_cut1 = -1, allow_cut2 = -1;
+    int fixed_base = -1;
+    { const char* e = getenv("MOCAP_EXCESS_BASE"); if (e) { fixed_base = atoi(e); if (fixed_base > thr_mul - 1) fixed_base = thr_mul - 1; if (fixed_base > 254) fixed_base = 254; if (fixed_base < 0) fixed_base = 0; } }
+    if (c->probe_pending && hipEventQuery(c->probe_ev) == hipSuccess) { // the last probe's counts have arrived
+        unsigned long long n_cur = 0, n_alt = 0;
+        for (int i = 0; i < 128; i++) { n_cur += c->probe_host[2 * i]; n_alt += c->probe_host[2 * i + 1]; }
+        static const bool dbg = getenv("MOCAP_PROBE_DEBUG") != nullptr;
+        if (dbg) fprintf(stderr, "[probe] base %d: %llu hot cells, alternative %d: %llu\n", excess_base(thr_mul, c->base_sel), n_cur, excess_base(thr_mul, c->base_sel ^ 1), n_alt);
+        // The tight base (sel 0) leaves tighter boxes around the markers for the same number of hot cells (measured: 33k against
+        // 45k marked tiles per 3072 images of the benchmark scene), so it is preferred unless the background makes its hot cells
+        // explode: use it iff it leaves at most 1.25x the hot cells of the tolerant base.
+        const unsigned long long n_lo = c->base_sel == 0 ? n_cur : n_alt, n_hi = c->base_sel == 0 ? n_alt : n_cur;
+        c->base_sel = (n_lo * 4 <= n_hi * 5) ? 0 : 1;
+        c->probe_pending = false;
+    }
+    const int base = fixed_base >= 0 ? fixed_base : excess_base(thr_mul, c->base_sel);
+    const int base_alt = excess_base(thr_mul, c->base_sel ^ 1);
+    int allow = -1, allow_cut1 = -1, allow_cut2 = -1, allow_alt = -1;
     {
         long long wmax = 0;
         bool ok = true;
@@ -448,13 +477,14 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
         }
         auto t5 = [](int n) { return (n - 1 < 2 ? n - 1 : 2) + 1; }; // taps of a window at the border, per axis
         auto t5full = [](int n) { return n < 5 ? n : 5; };
-        const long long per_tap = 1024LL * (2LL * thr_mul - 2LL * base - 1);
+        const long long per_tap = 1024LL * (2LL * thr_mul - 2LL * base - 1), per_tap_alt = 1024LL * (2LL * thr_mul - 2LL * base_alt - 1);
         if (!c->tile_rows || !c->reach || !c->cflags) ok = false;
         if (ok && wmax > 0 && per_tap > 0) {
             allow = (int)((per_tap * t5full(c->W) * t5full(c->H) - 1) / wmax); // windows with all their taps
             const long long taps1 = t5(c->W) * t5full(c->H) < t5full(c->W) * t5(c->H) ? t5(c->W) * t5full(c->H) : t5full(c->W) * t5(c->H);
             allow_cut1 = (int)((per_tap * taps1 - 1) / wmax);                  // smallest window cut in one axis
             allow_cut2 = (int)((per_tap * t5(c->W) * t5(c->H) - 1) / wmax);    // smallest window cut in both
+            if (per_tap_alt > 0) allow_alt = (int)((per_tap_alt * t5full(c->W) * t5full(c->H) - 1) / wmax);
         }
         { const char* e = getenv("MOCAP_SKIP_DARK"); if (e && atoi(e) == 0) allow = -1; }
     }
@@ -521,7 +551,14 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
         BrightArgs b{(const uint8_t*)frames, image_stride, pitch, c->H, c->W, n_images, cam_mod, ncx_magic, wide, base, allow / 4, allow_cut1 / 4, allow_cut2 / 4,
                      c->reach + (size_t)slot_base * source_cells(c), c->cflags + (size_t)slot_base * source_cells(c),
                      c->tile_rows, tl.n_cgroups * 4, tl.n_strips, (uint32_t)(((1u << 23) + tl.rows - 1) / tl.rows),
-                     mask, own_mask ? 0 : (size_t)n_images * c->H * c->wpr, ((uintptr_t)mask & 15) == 0};
+                     mask, own_mask ? 0 : (size_t)n_images * c->H * c->wpr, ((uintptr_t)mask & 15) == 0, nullptr, base_alt, allow_alt / 4};
+        const bool probe = fixed_base < 0 && !c->probe_pending && allow_alt >= 0 && base_alt != base && !bayer &&
+                           (c->probe_age == 0 || c->probe_age >= 32);
+        if (probe) {
+            HIP_TRY(hipMemsetAsync(c->probe_dev, 0, 1024, s));
+            b.probe = c->probe_dev;
+        }
+        c->probe_age = probe ? 1 : c->probe_age + 1;
         prof_begin(c, 3, s, p, on);
         if (bayer && own_mask && bayer_scan_fusable(*bayer)) launch_bayer_gray_scan(*bayer, b, s);
         else {
@@ -530,6 +567,11 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
         }
         prof_end(c, 3, s, p, on);
         HIP_TRY(hipGetLastError());
+        if (probe) {
+            HIP_TRY(hipMemcpyAsync(c->probe_host, c->probe_dev, 1024, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipEventRecord(c->probe_ev, s));
+            c->probe_pending = true;
+        }
     }
     else if (bayer) { // no early-out (not provable for this table, or MOCAP_SKIP_DARK=0): the plain gray pass
         launch_bayer_gray(*bayer, s);

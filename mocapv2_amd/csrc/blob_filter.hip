@@ -276,6 +276,21 @@ __global__ __launch_bounds__(256) void bright_cells_kernel(BrightArgs a)
             }
         }
         mark_hot_cell(a, reach, cflags, rows, ci[u], acc);
+        if (a.probe && (image & 15) == 0) { // wave-uniform, rare: which base would leave fewer hot cells?
+            const uint32_t alt4 = (uint32_t)a.base_alt * 0x01010101u, alt8 = 8u * (uint32_t)a.base_alt;
+            uint32_t acc2 = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint64_t vv = WIDE ? (((uint64_t)v[u][j].y << 32) | v[u][j].x) : ((((uint64_t)v[u][j].y << 32) | v[u][j].x) >> sh[u]);
+                const uint32_t e2 = excess2_row((uint32_t)vv, (uint32_t)(vv >> 32), alt4, alt8);
+                if (FULL || 8 * cr[u] + j < a.H) acc2 += e2;
+            }
+            const int n_cur = __popcll(__ballot((int)acc > a.hot)), n_alt = __popcll(__ballot((int)acc2 > a.hot_alt));
+            if ((threadIdx.x & 63) == 0) {
+                atomicAdd(&a.probe[2 * (blockIdx.x & 127)], (uint32_t)n_cur);
+                atomicAdd(&a.probe[2 * (blockIdx.x & 127) + 1], (uint32_t)n_alt);
+            }
+        }
     }
     if (a.mask_words) {
         // caller-owned masks: clear them on the side (16 bytes per thread and round), the filter kernel then only

@@ -121,6 +121,9 @@ struct BrightArgs {
     uint32_t* tile_rows; int n_chunks, n_strips; uint32_t rows_magic; // reachable mask rows / columns per tile, see FilterArgs;
                                   //   rows_magic = ceil(2^23 / rows per chunk)
     uint32_t* mask; size_t mask_words; int mask_aligned16; // caller-owned bit masks to clear on the side (mask_words = 0: none)
+    // probe (optional): on every 16th image also count the cells that are hot under the current base and under the alternative
+    // base `base_alt` / threshold `hot_alt`, into probe[2 * (block & 127) + 0 / 1]: the host compares the sums and switches
+    uint32_t* probe; int base_alt, hot_alt;
 };
 void launch_bright_cells(const BrightArgs& a, hipStream_t s);
 // set-up statistics of an undistort table, for the dark-tile bound: stats[0] = largest total blend weight any source
