@@ -152,7 +152,8 @@ def cpu_baseline(wl, arrays, frames, n_steps):
     oracle.lib()
     T = frames.shape[0]
     pool = ThreadPoolExecutor(C)
-    gray = (lambda im: oracle.bayer_gray(im, 3, 14)) if wl.bayer else (lambda im: im)
+    from mocapv2_amd.engine import GRAY_SHIFT
+    gray = (lambda im: oracle.bayer_gray(im, 3, GRAY_SHIFT)) if wl.bayer else (lambda im: im)
     results = []
     t0 = time.perf_counter()
     for i in range(n_steps):
@@ -358,6 +359,51 @@ def main():
                 "kernel_ms_per_step": kernel_ms(prof), "status_ok": ok, "points_per_frame": float(np.maximum(n_roots, 0).mean()),
                 "dark_tile_early_out": {"tiles_per_step": prof["tiles"], "tiles_resolved_without_filtering": prof["tiles_skipped"]}}
 
+    def ba_residual_section(n_eval=50):
+        """The residual evaluation part of BASELINE.json configs[4]: 16 cameras x 64 markers, one bundle-adjustment residual
+        vector = triangulate every point from its 16 views + reproject into all of them + per-point MSE (reference
+        lib/Helpers.py:161-167), through the drop-in lib.Helpers surface (host lists in, host array out: the H2D / D2H
+        copies and the packing are inside the figure), with the oracle's C restatement timed beside it."""
+        import oracle
+        import mocapv2_amd.lib.Helpers as Hh
+        from mocapv2_amd.synth import MILD_DIST, Scene
+        from scipy.spatial.transform import Rotation
+        C, M = 16, 64
+        sc = Scene(C, 3840, 2160, dist=MILD_DIST, radius=4.0)
+        rng = np.random.default_rng(5)
+        cents = sc.centroids(sc.markers(rng, M, extent=1.2), rng, jitter=0.3)
+        groups = np.stack([np.stack([cents[c][m] for c in range(C)]) for m in range(M)]).astype(float)  # [M, C, 2]
+        K, dd = np.stack([sc.K] * C), np.stack([sc.dist] * C)
+        R, tt = np.stack([p["R"] for p in sc.poses]), np.stack([p["t"] for p in sc.poses])
+        params = []
+        for c in range(1, C):
+            Rrel = R[c] @ R[0].T
+            params += list(Rotation.from_matrix(Rrel).as_rotvec()) + list(tt[c] - Rrel @ tt[0])
+        params = np.array(params)
+        Hh.camera_params = np.array([{"intrinsic_matrix": K[i].tolist(), "distortion_coef": dd[i].tolist()} for i in range(C)])
+        glist = groups.tolist()
+
+        def one():
+            poses = Hh.params_to_camera_poses(params, C)
+            obj = Hh.triangulate_points(glist, poses)
+            return Hh.calculate_reprojection_errors(glist, obj, poses).astype(np.float32)
+        got = one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_eval):
+            got = one()
+        dt = (time.perf_counter() - t0) / n_eval
+        valid = np.ones(groups.shape[:2], np.uint8)
+        t0 = time.perf_counter()
+        for _ in range(n_eval):
+            exp = oracle.ba_residuals(params, C, groups, valid, K, dd)
+        dt_cpu = (time.perf_counter() - t0) / n_eval
+        return {"workload": "bundle-adjustment residual vector, 16 cameras x 64 markers (BASELINE.json configs[4], residual part)",
+                "ms_per_evaluation": round(1e3 * dt, 4), "evaluations_per_s": round(1 / dt, 1), "points_per_s": round(M / dt, 1),
+                "includes": "drop-in lib.Helpers call surface: list packing, H2D, triangulate + reproject kernels, D2H",
+                "matches_oracle": bool(got.shape == exp.shape and np.allclose(got, exp, rtol=1e-5, atol=1e-6)),
+                "cpu_oracle_ms_per_evaluation": round(1e3 * dt_cpu, 4)}
+
     T_STEPS = args.time_steps or main_wl.default_time_steps()
     m = measure(main_wl, T_STEPS, args.steps, args.warmup)
     tracker, out, elapsed, prof = m["tracker"], m["out"], m["elapsed"], m["prof"]
@@ -445,6 +491,7 @@ def main():
                 extra[key] = section(wl, mx, args.steps)
                 mx.clear()
                 torch.cuda.empty_cache()
+            extra["ba_residual_eval_configs4"] = ba_residual_section()
             line["extra"] = extra
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -59,6 +59,7 @@ struct mocap_ctx {
     uint32_t* tile_rows;                   // [mask_images][tiles][4] the scan's box per tile, beside cells (see BoxArgs)
     uint32_t* cur_box;                     // [mask_images][tiles][4] output region / scan box of the last batch per tile (BoxArgs)
     BoxItem* items; uint32_t* n_items; uint32_t cap_items; // work list of the box kernel
+    uint4* wide_tiles; uint32_t cap_wide;                  // list of the tiles with wide boxes (filter_mask_kernel, list form)
     // excess base of the scan, adapted between batches: two candidates (tight / tolerant of bright backgrounds), the current
     // one, and a probe now and then that counts the hot cells both would leave (BrightArgs::probe)
     int base_sel; int probe_age; bool probe_pending; uint32_t* probe_dev; uint32_t* probe_host; hipEvent_t probe_ev;
@@ -151,7 +152,7 @@ int mocap_ctx_create(int device_id, int width, int height, int n_slots, mocap_ct
     c->prm = mocap_blob_params{5, 5, 255 * 0.85, 500.0, 0.5};
     c->maps = nullptr; c->map4 = nullptr; c->srcbox = nullptr; c->reach = nullptr; c->cflags = nullptr; c->map_flags = nullptr;
     c->mask = nullptr; c->mask_images = 0; c->mask_dirty = false; c->cells = nullptr; c->cells_images = 0; c->last_images = 0;
-    c->tile_rows = nullptr; c->cur_box = nullptr; c->items = nullptr; c->n_items = nullptr; c->cap_items = 0;
+    c->tile_rows = nullptr; c->cur_box = nullptr; c->items = nullptr; c->n_items = nullptr; c->cap_items = 0; c->wide_tiles = nullptr; c->cap_wide = 0;
     c->cells_ext = nullptr; c->cur_box_ext = nullptr; c->cells_ext_images = 0; c->cwork = nullptr; c->cwork_images = 0;
     c->cams = nullptr; c->n_cam = 0; c->n_F = 0; c->scratch = nullptr; c->scratch_elems = 0; c->profiling = false;
     c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1;
@@ -199,6 +200,7 @@ int mocap_ctx_destroy(mocap_ctx_t c)
     if (c->cur_box) (void)hipFree(c->cur_box);
     if (c->cur_box_ext) (void)hipFree(c->cur_box_ext);
     if (c->items) (void)hipFree(c->items);
+    if (c->wide_tiles) (void)hipFree(c->wide_tiles);
     if (c->n_items) (void)hipFree(c->n_items);
     if (c->reach) (void)hipFree(c->reach);
     if (c->cflags) (void)hipFree(c->cflags);
@@ -532,6 +534,14 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
     a.cur_box = own_mask ? c->cur_box : c->cur_box_ext;
     a.items = c->items; a.n_items = c->n_items; a.cap_items = c->cap_items;
     a.dense = allow < 0;
+    // Boxes wider than this many patch quads go through the sliding row pipeline instead (whole tile width, the box's rows):
+    // the box kernel's cost grows with the patch area (~30 cycles per quad-row), the row pipeline's with the rows only
+    // (~850 cycles per row with the gather).  Measured optimum on the benchmark scenes (8 and 32 markers, both lens models):
+    // 38-46 quads; without the routing the 32-marker scene's filter takes 1.77 ms instead of 1.25, the 8-marker scene's
+    // 0.53 instead of 0.49.  MOCAP_WIDE_QUADS="remap,identity" overrides (A/B switch; 1000 = never).
+    a.wide_tiles = c->wide_tiles; a.cap_wide = c->cap_wide; a.wide_quads_remap = 40; a.wide_quads_identity = 40;
+    { const char* e = getenv("MOCAP_WIDE_QUADS"); int r_ = 0, i_ = 0; if (e && sscanf(e, "%d,%d", &r_, &i_) == 2) { a.wide_quads_remap = r_; a.wide_quads_identity = i_; } }
+    if (c->W < 4) a.wide_tiles = nullptr;
     a.stage_bytes = BOX_SCAP;
     a.prio = 0;
     { const char* e = getenv("MOCAP_BOX_PRIO"); if (e) a.prio = atoi(e) != 0; } // A/B switch
@@ -589,8 +599,21 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
     }
     prof_begin(c, 0, s, p, on);
     launch_box_filter(a, c->box_grid, s);
-    prof_end(c, 0, s, p, on);
     HIP_TRY(hipGetLastError());
+    if (a.wide_tiles) { // the tiles with wide boxes: the row pipeline over their list
+        FilterArgs f;
+        f.src = a.src; f.image_stride = image_stride; f.pitch = pitch; f.H = c->H; f.W = c->W;
+        f.mask = mask; f.words_per_row = c->wpr; f.cam_mod = cam_mod; f.cells = cells;
+        f.map = c->maps ? c->maps + (size_t)slot_base * c->H * c->W : nullptr;
+        f.mapw = c->maps ? c->maps + (size_t)(c->n_slots + slot_base) * c->H * c->W : nullptr;
+        f.n_images = n_images; f.n_steps = a.n_steps; f.thr_mul = thr_mul;
+        f.n_strips = tl.n_strips; f.rows_per_chunk = tl.rows; f.n_cgroups = tl.n_cgroups;
+        f.tiles = c->wide_tiles; f.n_tiles = c->n_items + 8; f.cap_tiles = c->cap_wide;
+        f.pipelined = (c->W & 3) == 0 && c->H >= 2;
+        launch_filter_tiles(f, remap, c->box_grid / 4 > 0 ? c->box_grid / 4 : 1, s);
+        HIP_TRY(hipGetLastError());
+    }
+    prof_end(c, 0, s, p, on);
     if (box_timing) {
         std::vector<uint64_t> t((size_t)6 * c->box_grid);
         HIP_TRY(hipStreamSynchronize(s));
@@ -687,6 +710,7 @@ static int ensure_mask(mocap_ctx* c, int n_images)
     if (c->tile_rows) { HIP_TRY(hipFree(c->tile_rows)); c->tile_rows = nullptr; }
     if (c->cur_box) { HIP_TRY(hipFree(c->cur_box)); c->cur_box = nullptr; }
     if (c->items) { HIP_TRY(hipFree(c->items)); c->items = nullptr; c->cap_items = 0; }
+    if (c->wide_tiles) { HIP_TRY(hipFree(c->wide_tiles)); c->wide_tiles = nullptr; c->cap_wide = 0; }
     {   // every tile starts with the empty box (0xffffffff, 0) and an empty recorded region (x0 = 1 > x1 = 0)
         std::vector<uint32_t> init((size_t)n_images * cells_per_image(c) * 4);
         for (size_t i = 0; i < init.size(); i += 2) { init[i] = 0xffffffffu; init[i + 1] = 0u; }
@@ -699,6 +723,8 @@ static int ensure_mask(mocap_ctx* c, int n_images)
         if (cap > 0xffffffffull) return fail(MOCAP_E_UNSUPPORTED, "batch too large for the work list");
         HIP_TRY(hipMalloc(&c->items, sizeof(BoxItem) * cap));
         c->cap_items = (uint32_t)cap;
+        HIP_TRY(hipMalloc(&c->wide_tiles, sizeof(uint4) * (size_t)n_images * cells_per_image(c)));
+        c->cap_wide = (uint32_t)((size_t)n_images * cells_per_image(c));
         c->mask_dirty = false;
     }
     return 0;

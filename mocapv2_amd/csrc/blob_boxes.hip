@@ -129,6 +129,18 @@ __global__ __launch_bounds__(256) void settle_tiles_kernel(BoxArgs a)
     int oy0 = imax(by0, tile_r0), oy1 = imin(by1, tile_r1);
     if (marked && (ox0 > ox1 || oy0 > oy1)) marked = false;
     if (!marked) { ox0 = 1; ox1 = 0; oy0 = 1; oy1 = 0; }
+    // how the tile is filtered: cut into items for the box kernel, or -- a wide box -- as the tile's rows through the
+    // sliding row pipeline, which then writes the whole width of the tile
+    int nx = 0, ny = 0, nb = 0, h = 0;
+    bool wide = false;
+    if (marked) {
+        nb = (ox1 - ox0 + 8) >> 3; h = oy1 - oy0 + 1;
+        choose_split(nb, h, nx, ny);
+        const int slot_ = image % a.cam_mod;
+        const int limit = ((a.remap_bits >> slot_) & 1ull) ? a.wide_quads_remap : a.wide_quads_identity;
+        wide = a.wide_tiles != nullptr && 2 * nb + 2 * nx >= limit;
+        if (wide) { ox0 = tile_x0; ox1 = tile_x1; }
+    }
     const uint32_t nout_x = (uint32_t)ox0 | ((uint32_t)ox1 << 16), nout_y = (uint32_t)oy0 | ((uint32_t)oy1 << 16);
 
     // What the previous batch wrote in this tile of the context's own mask and this batch will not overwrite is
@@ -162,13 +174,15 @@ __global__ __launch_bounds__(256) void settle_tiles_kernel(BoxArgs a)
             for (int b = b0; b <= b1; b++) m[(size_t)y * rb + b] = 0;
     }
 
-    // items
-    int nx = 0, ny = 0, nb = 0, h = 0;
-    if (marked) {
-        nb = (ox1 - ox0 + 8) >> 3; h = oy1 - oy0 + 1;
-        choose_split(nb, h, nx, ny);
+    if (uint64_t wb = __ballot(wide)) { // the wide tiles of this wave: one slot each in their list
+        uint32_t base_w = 0;
+        if (lane == 0) base_w = atomicAdd(a.n_items + 8, (uint32_t)__popcll(wb));
+        base_w = (uint32_t)__builtin_amdgcn_readfirstlane((int)base_w);
+        const uint32_t ow = base_w + (uint32_t)__popcll(wb & ((1ull << lane) - 1ull));
+        if (wide && ow < a.cap_wide) a.wide_tiles[ow] = make_uint4((uint32_t)image, (uint32_t)(chunk * a.n_strips + strip), (uint32_t)oy0, (uint32_t)oy1);
     }
-    const int cnt = nx * ny;
+    // items
+    const int cnt = wide ? 0 : nx * ny;
     int incl = cnt; // inclusive prefix sum over the wave
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {

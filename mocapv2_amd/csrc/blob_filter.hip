@@ -331,7 +331,9 @@ __device__ __forceinline__ TileId decode_tile(const FilterArgs& a, int b)
     return t;
 }
 
-template <bool REMAP, bool TINY, bool PIPE>
+// LIST: instead of every tile of every image, the waves work through a list of (image, tile, first row, last row)
+// entries -- the tiles whose boxes settle_tiles_kernel found too wide for the box kernel to be the cheaper way.
+template <bool REMAP, bool TINY, bool PIPE, bool LIST>
 __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
 {
     __shared__ uint32_t lut[256];
@@ -341,11 +343,19 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform: keeps the row loop scalar
 
-    const TileId tid_ = decode_tile(a, blockIdx.x);
-    if (!tid_.valid) return;
-    const int slot = tid_.slot, image = tid_.image;
-    const int chunk = tid_.cgroup * 4 + wv;
-    if (chunk * a.rows_per_chunk >= a.H) return;
+    int slot = 0, image = 0, chunk = 0;
+    uint32_t n_list = 0;
+    if (LIST) {
+        n_list = *a.n_tiles;
+        n_list = n_list < a.cap_tiles ? n_list : a.cap_tiles;
+        if ((uint32_t)(blockIdx.x * 4 + wv) >= n_list) return;
+    } else {
+        const TileId tid_ = decode_tile(a, blockIdx.x);
+        if (!tid_.valid) return;
+        slot = tid_.slot; image = tid_.image;
+        chunk = tid_.cgroup * 4 + wv;
+        if (chunk * a.rows_per_chunk >= a.H) return;
+    }
     // lut[w]: byte k = number of set bits among bits k..k+4 of the 8-bit window w.  Every wave writes the whole table
     // (identical values), so no workgroup barrier is needed.
 #pragma unroll
@@ -355,11 +365,22 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
         for (int k = 0; k < 4; k++) v |= (uint32_t)__popc((i >> k) & 0x1fu) << (8 * k);
         lut[i] = v;
     }
-    for (int strip = 0; strip < a.n_strips; strip++) {
+    const uint32_t it_first = LIST ? (uint32_t)(blockIdx.x * 4 + wv) : 0u, it_end = LIST ? n_list : (uint32_t)a.n_strips;
+    const uint32_t it_step = LIST ? gridDim.x * 4u : 1u;
+    for (uint32_t it = it_first; it < it_end; it += it_step) {
+        int strip = (int)it, r0e = 0, r1e = 0x7fffffff;
+        if (LIST) {
+            const uint4 e = a.tiles[it];
+            image = __builtin_amdgcn_readfirstlane((int)e.x);
+            const int tile = __builtin_amdgcn_readfirstlane((int)e.y);
+            r0e = __builtin_amdgcn_readfirstlane((int)e.z); r1e = __builtin_amdgcn_readfirstlane((int)e.w) + 1;
+            chunk = tile / a.n_strips; strip = tile - chunk * a.n_strips;
+            slot = image % a.cam_mod;
+        }
         const int tile_r0 = chunk * a.rows_per_chunk;              // the tile's mask rows [tile_r0, tile_r1)
         const int tile_r1 = tile_r0 + a.rows_per_chunk < a.H ? tile_r0 + a.rows_per_chunk : a.H;
         const size_t cell_index = ((size_t)image * a.n_cgroups * 4 + chunk) * a.n_strips + strip;
-        const int r0 = tile_r0, r1 = tile_r1;
+        const int r0 = r0e > tile_r0 ? r0e : tile_r0, r1 = r1e < tile_r1 ? r1e : tile_r1; // the rows filtered
         const int xbase = strip * 240 - 8;
 
         const int Hm1 = a.H - 1;
@@ -569,7 +590,7 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
             // bit 31 marks a filtered tile; bits 0..16 are the groups
             if (lane == 0) a.cells[cell_index] = cellmask | 0x80000000u;
         }
-    } // strips
+    } // strips / list entries
 }
 
 // ---- map construction: cv::initUndistortRectifyMap as called by cv::undistort (stripe by stripe) -------------
@@ -795,13 +816,24 @@ void launch_filter_mask(const FilterArgs& a, bool remap, hipStream_t s)
 {
     const int blocks = a.cam_mod * a.n_cgroups * a.n_steps;
     if (remap && a.pipelined)
-        hipLaunchKernelGGL((filter_mask_kernel<true, false, true>), dim3(blocks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((filter_mask_kernel<true, false, true, false>), dim3(blocks), dim3(256), 0, s, a);
     else if (remap)
-        hipLaunchKernelGGL((filter_mask_kernel<true, false, false>), dim3(blocks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((filter_mask_kernel<true, false, false, false>), dim3(blocks), dim3(256), 0, s, a);
     else if (a.W >= 4)
-        hipLaunchKernelGGL((filter_mask_kernel<false, false, false>), dim3(blocks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((filter_mask_kernel<false, false, false, false>), dim3(blocks), dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL((filter_mask_kernel<false, true, false>), dim3(blocks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((filter_mask_kernel<false, true, false, false>), dim3(blocks), dim3(256), 0, s, a);
+}
+
+// the same row pipeline over the list of wide tiles (a.tiles / a.n_tiles): a fixed grid, four entries per workgroup at a time
+void launch_filter_tiles(const FilterArgs& a, bool remap, int blocks, hipStream_t s)
+{
+    if (remap && a.pipelined)
+        hipLaunchKernelGGL((filter_mask_kernel<true, false, true, true>), dim3(blocks), dim3(256), 0, s, a);
+    else if (remap)
+        hipLaunchKernelGGL((filter_mask_kernel<true, false, false, true>), dim3(blocks), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((filter_mask_kernel<false, false, false, true>), dim3(blocks), dim3(256), 0, s, a);
 }
 void launch_bright_cells(const BrightArgs& a, hipStream_t s)
 {

@@ -19,6 +19,8 @@ struct FilterArgs {
     // undistort tables of the first slot used (remap variant only), each [cam_mod][H][W]:
     const uint32_t* map;  //   tap position: (sx - x) | (sy - y) << 16, the 2x2 tap window clamped into the image
     const uint32_t* mapw; //   blend weights 32*(wx0 | wx1<<8 | wy1<<16 | wy0<<24)/32, taps outside the image weigh 0
+    const uint4* tiles; const uint32_t* n_tiles; uint32_t cap_tiles; // list form (launch_filter_tiles): entries image, tile (chunk *
+                          //   n_strips + strip), first row, last row; their number
     int pipelined;        // 1 = software-pipelined gather (table words 8 rows ahead, taps 4 rows ahead; W % 4 == 0, H >= 2), 0 = per-pixel gather
     int cam_mod;          // undistort slot of image n = n % cam_mod (map already points at the first slot)
     int n_images, n_steps; // n_steps = ceil(n_images / cam_mod)
@@ -55,6 +57,10 @@ struct BoxArgs {
     uint64_t* timing;           // optional [grid][6] phase clock of the box kernel (MOCAP_BOX_TIMING=1, a debugging aid), else null
     int prio;                   // 1 = raise the wave priority of the box kernel (A/B switch)
     int stage_bytes;            // LDS bytes the source staging may use (BOX_SCAP; smaller values are a test switch)
+    uint4* wide_tiles;          // tiles whose box is wider than `wide_quads` patch quads go to this list instead (image, tile, first row,
+                                //   last row; counted in n_items[8]) and through the sliding row pipeline of filter_mask_kernel, which
+                                //   does less work per pixel on wide regions than the box kernel
+    uint32_t cap_wide; int wide_quads_remap, wide_quads_identity;
     int dense;                  // 1 = no early-out: every tile is filtered whole
     int ext_mask;               // 1 = caller-owned mask (cleared by the scan kernel, or written whole when dense)
 };
@@ -108,6 +114,7 @@ struct ContourArgs {
 enum { BLOB_ERR_CANDIDATES = -2, BLOB_ERR_CONTOURS = -3, BLOB_ERR_STEPS = -4, BLOB_ERR_DEPTH = -5 };
 
 void launch_filter_mask(const FilterArgs& a, bool remap, hipStream_t s);
+void launch_filter_tiles(const FilterArgs& a, bool remap, int blocks, hipStream_t s);
 struct BrightArgs {
     const uint8_t* src; size_t image_stride; int pitch, H, W, n_images; // W >= 8
     int cam_mod;                  // undistort slot of image n = n % cam_mod (the tables already point at the first slot)

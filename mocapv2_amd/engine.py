@@ -14,6 +14,13 @@ import torch
 from . import _abi
 
 MAX_BLOBS = 128       # centroid record capacity per camera image
+# Fixed point of cv2.cvtColor(., COLOR_BGR2GRAY) on 8-bit images in the camera loop (RealtimeTracking_FLIR.py:104).
+# The reference pins no OpenCV version (README.md:65), so `pip install opencv-python` gives a current 4.x, whose
+# RGB2Gray<uchar> works with gray_shift = 15 (RY15 = 9798, GY15 = 19235, BY15 = 3735, + 2^14, >> 15;
+# modules/imgproc/src/color.simd_helpers.hpp); OpenCV 2.x / 3.x used the 14-bit set (4899, 9617, 1868).  Both are
+# implemented and tested; the default follows the version the reference's users get today.  oracle/check_against_cv2.py
+# settles it wherever cv2 can be imported (it cannot in the build container).
+GRAY_SHIFT = 15
 REC_INTS = 2 + 2 * MAX_BLOBS  # int32 record: count, pad, xy[MAX_BLOBS][2]
 
 
@@ -111,7 +118,7 @@ class MocapContext:
         return flat, n, stride, pitch
 
     def blob_centroids(self, frames, cam_mod=1, slot_base=0, max_blobs=MAX_BLOBS, records=None, bayer_pattern=None,
-                       gray_shift=14, gray=None):
+                       gray_shift=GRAY_SHIFT, gray=None):
         """_find_dot over uint8 frames [..., H, W] resident on the GPU (image n uses undistort slot
         slot_base + n % cam_mod).  Results land in centroid records, int32 [n, 2 + 2*max_blobs]:
         record[0] = number of image points, record[2:] = (cx, cy) pairs in the reference's contour order.
@@ -198,7 +205,7 @@ class MocapContext:
                                               bayer.stride(0), _stream()))
         return out
 
-    def bayer_gray(self, bayer, pattern=3, gray_shift=14, out=None):
+    def bayer_gray(self, bayer, pattern=3, gray_shift=GRAY_SHIFT, out=None):
         """Raw Bayer frames uint8 [H, W] or [n, H, W] on the GPU -> gray frames of the same shape:
         cv2.cvtColor(cv2.cvtColor(raw, COLOR_BAYER_GR2BGR), COLOR_BGR2GRAY) of the reference's camera loop
         (RealtimeTracking_FLIR.py:103-104) in one pass.  pattern 0..3 = BG, GB, RG, GR."""

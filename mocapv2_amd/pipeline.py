@@ -10,7 +10,7 @@ With one rank the block is the whole grid and no collective runs.
 import numpy as np
 import torch
 
-from .engine import MocapContext
+from .engine import GRAY_SHIFT, MocapContext
 
 
 def shard_plan(n_cams, steps_per_rank, world, rank):
@@ -100,7 +100,7 @@ class BatchTracker:
     the next (the streaming scan).  Results of a batch are complete once its stream (or the device) is synchronised."""
 
     def __init__(self, K, dist, R, t, F, width, height, steps_per_rank, world=1, rank=0, device=0, group=None,
-                 max_points=32, max_groups=4096, depth=1, bayer_pattern=None, gray_shift=14, collective="auto",
+                 max_points=32, max_groups=4096, depth=1, bayer_pattern=None, gray_shift=GRAY_SHIFT, collective="auto",
                  force_collective=False):
         """collective: how the centroid records are exchanged when world > 1 --
              "rccl"  mocap_allgather_centroids: ncclAllGather called by the library on the batch's own HIP stream, one

@@ -14,7 +14,7 @@ business (`send=` callback; networking is outside the path), and the message byt
 import numpy as np
 import torch
 
-from .engine import MocapContext
+from .engine import GRAY_SHIFT, MocapContext
 from .pipeline import BatchTracker
 
 OBJ_COUNT = 4  # RealtimeTracking_FLIR.py:181
@@ -37,7 +37,7 @@ class ReplayTracker:
     them from the same detections.  `batch` time steps go through the GPU at once."""
 
     def __init__(self, K, dist, R, t, F, width, height, batch=64, obj_count=OBJ_COUNT, device=0, max_points=32,
-                 max_groups=4096, bayer_pattern=None, gray_shift=14):
+                 max_groups=4096, bayer_pattern=None, gray_shift=GRAY_SHIFT):
         self.n_cam = len(K)
         self.batch = int(batch)
         self.obj_count = obj_count

@@ -460,7 +460,8 @@ def test_replay_from_raw_bayer_frames():
     raw[:, :, 0::2, 1::2] *= 0.9
     raw[:, :, 1::2, 0::2] *= 0.95
     raw = np.clip(raw + rng.integers(0, 3, raw.shape), 0, 255).astype(np.uint8)
-    gray = np.stack([np.stack([oracle.bayer_gray(raw[t, c], 3, 14) for c in range(3)]) for t in range(T)])
+    from mocapv2_amd.engine import GRAY_SHIFT
+    gray = np.stack([np.stack([oracle.bayer_gray(raw[t, c], 3, GRAY_SHIFT) for c in range(3)]) for t in range(T)])
     arrays = scene_arrays(sc)
     a = list(ReplayTracker(*arrays, 640, 360, batch=4, bayer_pattern=3).run(raw))
     b = list(ReplayTracker(*arrays, 640, 360, batch=4).run(gray))
@@ -477,6 +478,7 @@ def test_blob_centroids_from_bayer_equals_the_two_steps(torch_cuda, monkeypatch,
     """mocap_blob_centroids_bayer (gray conversion fused with the early-out's scan where width % 16 == 0 and
     height % 8 == 0, separate kernels otherwise) = mocap_bayer_gray_u8 followed by mocap_blob_centroids, and the gray
     frames it leaves behind are the oracle's; two batches on one context, then once more with the early-out off."""
+    from mocapv2_amd.engine import GRAY_SHIFT
     torch = torch_cuda
     from mocapv2_amd.engine import MocapContext
     rng = np.random.default_rng(W + H + int(scale))
@@ -498,10 +500,10 @@ def test_blob_centroids_from_bayer_equals_the_two_steps(torch_cuda, monkeypatch,
             d = torch.from_numpy(raw).cuda()
             gray = torch.zeros_like(d)
             rec = ctx.blob_centroids(d, cam_mod=2, bayer_pattern=3, gray=gray).cpu().numpy()
-            two = ref.blob_centroids(ref.bayer_gray(d, 3, 14), cam_mod=2).cpu().numpy()
+            two = ref.blob_centroids(ref.bayer_gray(d, 3), cam_mod=2).cpu().numpy()
             g = gray.cpu().numpy()
             for i in range(4):
-                assert np.array_equal(g[i], oracle.bayer_gray(raw[i], 3, 14)), (skip, b, i)
+                assert np.array_equal(g[i], oracle.bayer_gray(raw[i], 3, GRAY_SHIFT)), (skip, b, i)
                 n = rec[i, 0]
                 assert n == two[i, 0] and n >= 0 and np.array_equal(rec[i, 2:2 + 2 * n], two[i, 2:2 + 2 * n]), (skip, b, i)
             assert rec[:, 0].sum() >= (4 if W >= 640 else 0)
