@@ -561,7 +561,8 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
         BrightArgs b{(const uint8_t*)frames, image_stride, pitch, c->H, c->W, n_images, cam_mod, ncx_magic, wide, base, allow / 4, allow_cut1 / 4, allow_cut2 / 4,
                      c->reach + (size_t)slot_base * source_cells(c), c->cflags + (size_t)slot_base * source_cells(c),
                      c->tile_rows, tl.n_cgroups * 4, tl.n_strips, (uint32_t)(((1u << 23) + tl.rows - 1) / tl.rows),
-                     mask, own_mask ? 0 : (size_t)n_images * c->H * c->wpr, ((uintptr_t)mask & 15) == 0, nullptr, base_alt, allow_alt / 4};
+                     mask, own_mask ? 0 : (size_t)n_images * c->H * c->wpr, ((uintptr_t)mask & 15) == 0, nullptr, base_alt, allow_alt / 4, 0};
+        { const char* e = getenv("MOCAP_SCAN_PRIO"); if (e) b.prio = atoi(e); } // A/B switch
         const bool probe = fixed_base < 0 && !c->probe_pending && allow_alt >= 0 && base_alt != base && !bayer &&
                            (c->probe_age == 0 || c->probe_age >= 32);
         if (probe) {
@@ -653,6 +654,8 @@ static int run_contours(mocap_ctx* c, const uint32_t* mask, const uint32_t* cell
         c->cwork_images = n_images;
     }
     a.work = c->cwork;
+    a.prio = 0;
+    { const char* e = getenv("MOCAP_CONTOUR_PRIO"); if (e) a.prio = atoi(e); } // A/B switch (no effect measured)
     a.timing = nullptr;
     static const bool phase_timing = getenv("MOCAP_CONTOUR_TIMING") && atoi(getenv("MOCAP_CONTOUR_TIMING")) != 0;
     if (phase_timing) { // debugging aid: synchronous, prints the mean duration of the kernel's phases
@@ -983,6 +986,8 @@ int mocap_correspond(mocap_ctx_t c, const void* pts, long pt_st, long pt_sc, con
     a.pt_st = pt_st; a.pt_sc = pt_sc; a.cnt_st = cnt_st; a.cnt_sc = cnt_sc;
     a.cutoff = cutoff; a.max_groups = max_groups; a.root_xyz = root_xyz; a.root_err = root_err; a.root_grp = root_grp;
     a.root_idx = root_idx; a.order = order; a.n_roots = n_roots; a.scratch = c->scratch; a.step_budget = (int)budget;
+    a.prio = 0;
+    { const char* e = getenv("MOCAP_CORR_PRIO"); if (e) a.prio = atoi(e); } // A/B switch (no effect measured)
     EvPair p; bool on;
     prof_begin(c, 2, (hipStream_t)stream, p, on);
     launch_correspond(a, (hipStream_t)stream);

@@ -286,6 +286,9 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
     int16_t* const kept_idx = (int16_t*)(scratch + MAXR * 8);
     int8_t* const kept_depth = (int8_t*)(scratch + MAXR * 8 + MAXK * 2);
 
+    if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
+    else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
     const int image = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = uni(tid >> 6);

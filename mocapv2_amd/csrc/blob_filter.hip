@@ -207,6 +207,9 @@ __device__ __forceinline__ uint32_t remap_combine(const TapSlot& ts, const LaneC
 template <bool WIDE, bool FULL = false>
 __global__ __launch_bounds__(256) void bright_cells_kernel(BrightArgs a)
 {
+    if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
+    else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
     const int ncx = (a.W + 7) >> 3, ncy = (a.H + 7) >> 3, n = ncx * ncy;
     const int image = blockIdx.y;
     const uint8_t* __restrict__ img = a.src + (size_t)image * a.image_stride;

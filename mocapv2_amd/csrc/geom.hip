@@ -11,6 +11,7 @@
 // index space and triangulated one group per lane; per-root error means use NumPy's pairwise summation order.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "kernels.h"
 
 namespace mocap {
@@ -209,6 +210,9 @@ template <typename PT>
 __global__ __launch_bounds__(256) void correspond_kernel(CorrArgs a)
 {
     extern __shared__ unsigned char smem[];
+    if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
+    else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
     const int C = a.C, P = a.P, t = blockIdx.x, tid = threadIdx.x;
     // LDS carve: nm[P][C] (u8), midx[P][C][MAXM] (u8), G[P] (int), goff[P+1] (int), slot[P] (int)
     uint8_t* nm = smem;
@@ -402,10 +406,14 @@ size_t correspond_smem_bytes(int P, int C)
 void launch_correspond(const CorrArgs& a, hipStream_t s)
 {
     size_t sm = correspond_smem_bytes(a.P, a.C);
+    // threads per time step (MOCAP_CORR_THREADS: A/B switch; one wave per step measured 0.064 against 0.051 ms alone and the
+    // same in the three-batch pipeline)
+    static const int env_threads = getenv("MOCAP_CORR_THREADS") ? atoi(getenv("MOCAP_CORR_THREADS")) : 0;
+    const int threads = (env_threads == 64 || env_threads == 128 || env_threads == 256) ? env_threads : 256;
     if (a.pts_f64)
-        hipLaunchKernelGGL(correspond_kernel<double>, dim3(a.T), dim3(256), sm, s, a);
+        hipLaunchKernelGGL(correspond_kernel<double>, dim3(a.T), dim3(threads), sm, s, a);
     else
-        hipLaunchKernelGGL(correspond_kernel<int32_t>, dim3(a.T), dim3(256), sm, s, a);
+        hipLaunchKernelGGL(correspond_kernel<int32_t>, dim3(a.T), dim3(threads), sm, s, a);
 }
 void launch_triangulate(const TriArgs& a, hipStream_t s)
 {

@@ -109,6 +109,7 @@ struct ContourArgs {
     int rows_per_chunk, n_chunks, n_strips;
     uint64_t* timing;      // optional [n_images][8] phase clock (debugging aid), else null
     void* work;            // [n_images] per-image workspace of contour_work_bytes() each
+    int prio;              // wave priority (s_setprio 0..3): the walks are serial chains, cheap to favour and costly to delay
 };
 
 enum { BLOB_ERR_CANDIDATES = -2, BLOB_ERR_CONTOURS = -3, BLOB_ERR_STEPS = -4, BLOB_ERR_DEPTH = -5 };
@@ -131,6 +132,7 @@ struct BrightArgs {
     // probe (optional): on every 16th image also count the cells that are hot under the current base and under the alternative
     // base `base_alt` / threshold `hot_alt`, into probe[2 * (block & 127) + 0 / 1]: the host compares the sums and switches
     uint32_t* probe; int base_alt, hot_alt;
+    int prio;                     // wave priority of the scan (s_setprio): its few instructions are loads that keep HBM busy
 };
 void launch_bright_cells(const BrightArgs& a, hipStream_t s);
 // set-up statistics of an undistort table, for the dark-tile bound: stats[0] = largest total blend weight any source
@@ -188,6 +190,7 @@ struct CorrArgs {
     int32_t* root_idx;         // [T][P]  camera-0 index of the j-th surviving root
     int32_t* order;            // [T][P]  argsort(root_err)
     int32_t* n_roots;          // [T]  (<0 = error)
+    int prio;                  // wave priority (s_setprio 0..3), see ContourArgs
     double* scratch;           // [T][step_budget] per-group errors, the groups of a time step back to back in root order
     int step_budget;           // groups per time step the scratch holds
 };

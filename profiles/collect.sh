@@ -5,8 +5,9 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 set -e
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_d3 -o d3 -- python3 $R/bench.py --cpu-steps 0 --no-secondary > $R/gpurun_out/prof_d3.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_d1 -o d1 -- python3 $R/bench.py --depth 1 --cpu-steps 0 --no-secondary > $R/gpurun_out/prof_d1.json
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_fetch -o f -- python3 $R/bench.py --depth 1 --steps 3 --warmup 1 --cpu-steps 0 --no-secondary > $R/gpurun_out/prof_fetch.json
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_write -o w -- python3 $R/bench.py --depth 1 --steps 3 --warmup 1 --cpu-steps 0 --no-secondary > $R/gpurun_out/prof_write.json
+ARGS="--cpu-steps 0 --no-secondary --no-extra"
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_d3 -o d3 -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_d3.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_d1 -o d1 -- python3 $R/bench.py --depth 1 $ARGS > $R/gpurun_out/prof_d1.json
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_fetch -o f -- python3 $R/bench.py --depth 1 --steps 3 --warmup 2 $ARGS > $R/gpurun_out/prof_fetch.json
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_write -o w -- python3 $R/bench.py --depth 1 --steps 3 --warmup 2 $ARGS > $R/gpurun_out/prof_write.json
 find $R/gpurun_out/prof_d3 $R/gpurun_out/prof_d1 $R/gpurun_out/prof_fetch $R/gpurun_out/prof_write -name "*.csv" | head -20
