@@ -60,6 +60,7 @@ struct mocap_ctx {
     uint32_t* cur_box;                     // [mask_images][tiles][4] output region / scan box of the last batch per tile (BoxArgs)
     BoxItem* items; uint32_t* n_items; uint32_t cap_items; // work list of the box kernel
     uint4* wide_tiles; uint32_t cap_wide;                  // list of the tiles with wide boxes (filter_mask_kernel, list form)
+    hipStream_t side; hipEvent_t ev_fork, ev_join;         // the wide tiles are filtered beside the box kernel: side stream, fork / join events
     // excess base of the scan, adapted between batches: two candidates (tight / tolerant of bright backgrounds), the current
     // one, and a probe now and then that counts the hot cells both would leave (BrightArgs::probe)
     int base_sel; int probe_age; bool probe_pending; uint32_t* probe_dev; uint32_t* probe_host; hipEvent_t probe_ev;
@@ -156,6 +157,7 @@ int mocap_ctx_create(int device_id, int width, int height, int n_slots, mocap_ct
     c->cells_ext = nullptr; c->cur_box_ext = nullptr; c->cells_ext_images = 0; c->cwork = nullptr; c->cwork_images = 0;
     c->cams = nullptr; c->n_cam = 0; c->n_F = 0; c->scratch = nullptr; c->scratch_elems = 0; c->profiling = false;
     c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1;
+    c->side = nullptr; c->ev_fork = nullptr; c->ev_join = nullptr;
     c->base_sel = 1; { const char* e = getenv("MOCAP_BASE_SEL"); if (e) c->base_sel = atoi(e) != 0; } c->probe_age = 0; c->probe_pending = false; c->probe_dev = nullptr; c->probe_host = nullptr; c->probe_ev = nullptr;
     {
         hipDeviceProp_t prop;
@@ -175,6 +177,9 @@ int mocap_ctx_create(int device_id, int width, int height, int n_slots, mocap_ct
     if (e == hipSuccess) e = hipMalloc(&c->probe_dev, 1024);
     if (e == hipSuccess) e = hipHostMalloc(&c->probe_host, 1024);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->probe_ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(&c->cams, sizeof(CameraTable));
     if (e == hipSuccess) e = hipMemset(c->cams, 0, sizeof(CameraTable));
     if (e != hipSuccess) {
@@ -191,6 +196,9 @@ int mocap_ctx_destroy(mocap_ctx_t c)
     (void)hipSetDevice(c->device);
     for (auto& v : c->ev) for (auto& p : v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     if (c->comm && g_rccl.lib) { (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
+    if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->probe_ev) { (void)hipEventSynchronize(c->probe_ev); (void)hipEventDestroy(c->probe_ev); }
     if (c->probe_dev) (void)hipFree(c->probe_dev);
     if (c->probe_host) (void)hipHostFree(c->probe_host);
@@ -599,9 +607,11 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
         HIP_TRY(hipMemsetAsync(a.timing, 0, sizeof(uint64_t) * 6 * c->box_grid, s));
     }
     prof_begin(c, 0, s, p, on);
-    launch_box_filter(a, c->box_grid, s);
-    HIP_TRY(hipGetLastError());
-    if (a.wide_tiles) { // the tiles with wide boxes: the row pipeline over their list
+    // MOCAP_WIDE_FORK=1: the wide-tile kernel on a side stream beside the box kernel (fork / join by events).  Measured: the pair takes
+    // 0.53 ms instead of 0.49 alone and the three-batch pipeline 310k instead of 319k frames/s, so it is off.
+    static const bool fork_wide = getenv("MOCAP_WIDE_FORK") && atoi(getenv("MOCAP_WIDE_FORK")) != 0;
+    if (a.wide_tiles) { // the tiles with wide boxes: the row pipeline over their list, beside the box kernel (both only read what
+                        // settle left and write disjoint tiles): forked onto the context's side stream, joined before the contours
         FilterArgs f;
         f.src = a.src; f.image_stride = image_stride; f.pitch = pitch; f.H = c->H; f.W = c->W;
         f.mask = mask; f.words_per_row = c->wpr; f.cam_mod = cam_mod; f.cells = cells;
@@ -611,9 +621,19 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
         f.n_strips = tl.n_strips; f.rows_per_chunk = tl.rows; f.n_cgroups = tl.n_cgroups;
         f.tiles = c->wide_tiles; f.n_tiles = c->n_items + 8; f.cap_tiles = c->cap_wide;
         f.pipelined = (c->W & 3) == 0 && c->H >= 2;
-        launch_filter_tiles(f, remap, c->box_grid / 4 > 0 ? c->box_grid / 4 : 1, s);
+        hipStream_t ws = s;
+        if (fork_wide) {
+            HIP_TRY(hipEventRecord(c->ev_fork, s));
+            HIP_TRY(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+            ws = c->side;
+        }
+        launch_filter_tiles(f, remap, c->box_grid / 4 > 0 ? c->box_grid / 4 : 1, ws);
         HIP_TRY(hipGetLastError());
+        if (fork_wide) HIP_TRY(hipEventRecord(c->ev_join, c->side));
     }
+    launch_box_filter(a, c->box_grid, s);
+    HIP_TRY(hipGetLastError());
+    if (a.wide_tiles && fork_wide) HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
     prof_end(c, 0, s, p, on);
     if (box_timing) {
         std::vector<uint64_t> t((size_t)6 * c->box_grid);
