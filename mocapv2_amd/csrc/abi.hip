@@ -549,6 +549,8 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
     // 0.53 instead of 0.49.  MOCAP_WIDE_QUADS="remap,identity" overrides (A/B switch; 1000 = never).
     a.wide_tiles = c->wide_tiles; a.cap_wide = c->cap_wide; a.wide_quads_remap = 40; a.wide_quads_identity = 40;
     { const char* e = getenv("MOCAP_WIDE_QUADS"); int r_ = 0, i_ = 0; if (e && sscanf(e, "%d,%d", &r_, &i_) == 2) { a.wide_quads_remap = r_; a.wide_quads_identity = i_; } }
+    a.wide_bands = 1; // measured: 2 / 4 bands 0.50 / 0.55 ms against 0.475 (8 markers), 1.33 / 1.58 against 1.22 (32 markers): the kernel is work-bound
+    { const char* e = getenv("MOCAP_WIDE_BANDS"); if (e && atoi(e) >= 1 && atoi(e) <= 4) a.wide_bands = atoi(e); } // A/B switch
     if (c->W < 4) a.wide_tiles = nullptr;
     a.stage_bytes = BOX_SCAP;
     a.prio = 0;
@@ -627,11 +629,13 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
             HIP_TRY(hipStreamWaitEvent(c->side, c->ev_fork, 0));
             ws = c->side;
         }
-        launch_filter_tiles(f, remap, c->box_grid / 4 > 0 ? c->box_grid / 4 : 1, ws);
+        static const bool skip_wide = getenv("MOCAP_EXPERIMENT_SKIP_WIDE") != nullptr; // timing experiments only
+        if (!skip_wide) launch_filter_tiles(f, remap, c->box_grid / 4 > 0 ? c->box_grid / 4 : 1, ws);
         HIP_TRY(hipGetLastError());
         if (fork_wide) HIP_TRY(hipEventRecord(c->ev_join, c->side));
     }
-    launch_box_filter(a, c->box_grid, s);
+    static const bool skip_box = getenv("MOCAP_EXPERIMENT_SKIP_BOX") != nullptr; // timing experiments only: the mask is not written
+    if (!skip_box) launch_box_filter(a, c->box_grid, s);
     HIP_TRY(hipGetLastError());
     if (a.wide_tiles && fork_wide) HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
     prof_end(c, 0, s, p, on);
@@ -683,8 +687,9 @@ static int run_contours(mocap_ctx* c, const uint32_t* mask, const uint32_t* cell
         HIP_TRY(hipMemsetAsync(a.timing, 0, sizeof(uint64_t) * 8 * n_images, s));
     }
     EvPair p; bool on;
+    static const bool skip_contours = getenv("MOCAP_EXPERIMENT_SKIP_CONTOURS") != nullptr; // timing experiments only: results are stale
     prof_begin(c, 1, s, p, on);
-    launch_contours(a, s);
+    if (!skip_contours) launch_contours(a, s);
     prof_end(c, 1, s, p, on);
     HIP_TRY(hipGetLastError());
     if (phase_timing) {
@@ -746,8 +751,8 @@ static int ensure_mask(mocap_ctx* c, int n_images)
         if (cap > 0xffffffffull) return fail(MOCAP_E_UNSUPPORTED, "batch too large for the work list");
         HIP_TRY(hipMalloc(&c->items, sizeof(BoxItem) * cap));
         c->cap_items = (uint32_t)cap;
-        HIP_TRY(hipMalloc(&c->wide_tiles, sizeof(uint4) * (size_t)n_images * cells_per_image(c)));
-        c->cap_wide = (uint32_t)((size_t)n_images * cells_per_image(c));
+        HIP_TRY(hipMalloc(&c->wide_tiles, sizeof(uint4) * 4 * (size_t)n_images * cells_per_image(c))); // up to 4 row bands per tile
+        c->cap_wide = (uint32_t)(4 * (size_t)n_images * cells_per_image(c));
         c->mask_dirty = false;
     }
     return 0;
@@ -1009,8 +1014,9 @@ int mocap_correspond(mocap_ctx_t c, const void* pts, long pt_st, long pt_sc, con
     a.prio = 0;
     { const char* e = getenv("MOCAP_CORR_PRIO"); if (e) a.prio = atoi(e); } // A/B switch (no effect measured)
     EvPair p; bool on;
+    static const bool skip_corr = getenv("MOCAP_EXPERIMENT_SKIP_CORR") != nullptr; // timing experiments only
     prof_begin(c, 2, (hipStream_t)stream, p, on);
-    launch_correspond(a, (hipStream_t)stream);
+    if (!skip_corr) launch_correspond(a, (hipStream_t)stream);
     prof_end(c, 2, (hipStream_t)stream, p, on);
     HIP_TRY(hipGetLastError());
     return MOCAP_OK;

@@ -174,12 +174,22 @@ __global__ __launch_bounds__(256) void settle_tiles_kernel(BoxArgs a)
             for (int b = b0; b <= b1; b++) m[(size_t)y * rb + b] = 0;
     }
 
-    if (uint64_t wb = __ballot(wide)) { // the wide tiles of this wave: one slot each in their list
+    if (uint64_t wb = __ballot(wide)) { // the wide tiles of this wave: `wide_bands` slots each in their list (the row pipeline is a
+        // serial walk down the rows, so a tile's latency, not its work, sets the duration of that short kernel: its rows are cut
+        // into bands for several waves, 8 halo rows each)
+        const int nbands = a.wide_bands;
         uint32_t base_w = 0;
-        if (lane == 0) base_w = atomicAdd(a.n_items + 8, (uint32_t)__popcll(wb));
+        if (lane == 0) base_w = atomicAdd(a.n_items + 8, (uint32_t)(__popcll(wb) * nbands));
         base_w = (uint32_t)__builtin_amdgcn_readfirstlane((int)base_w);
-        const uint32_t ow = base_w + (uint32_t)__popcll(wb & ((1ull << lane) - 1ull));
-        if (wide && ow < a.cap_wide) a.wide_tiles[ow] = make_uint4((uint32_t)image, (uint32_t)(chunk * a.n_strips + strip), (uint32_t)oy0, (uint32_t)oy1);
+        const uint32_t ow = base_w + (uint32_t)(__popcll(wb & ((1ull << lane) - 1ull)) * nbands);
+        if (wide) {
+            const int hb = (oy1 - oy0 + nbands) / nbands; // rows per band
+            for (int b = 0; b < nbands; b++) {
+                const int y0 = oy0 + b * hb, y1 = imin(y0 + hb - 1, oy1);
+                if (ow + b < a.cap_wide) // an empty band (y0 > y1) is skipped by the kernel
+                    a.wide_tiles[ow + b] = make_uint4((uint32_t)image, (uint32_t)(chunk * a.n_strips + strip), (uint32_t)y0, (uint32_t)(y0 <= y1 ? y1 : y0 - 1));
+            }
+        }
     }
     // items
     const int cnt = wide ? 0 : nx * ny;
@@ -471,6 +481,31 @@ __global__ __launch_bounds__(64) void box_filter_kernel(BoxArgs a)
                 const uint32_t shs = (uint32_t)(sb < 0 || sb > 31 ? 0 : sb);
                 constexpr int SU = 14;
                 const int nround = (SR + rpi - 1) / rpi;
+                // the whole source rectangle inside the image (the usual case): no clamps, no masks
+                const bool interior = sya >= 0 && syb <= Hm1 && sxa >= 0 && sxa + SP <= W;
+                if (interior) {
+                    const uint32_t step = (uint32_t)__mul24(rpi, a_pitch);
+                    const int scc = sc < dpr ? sc : dpr - 1; // (lanes past the last dword of a row re-read it)
+                    const uint32_t glast = (uint32_t)__mul24(syb, a_pitch) + (uint32_t)(sxa + 4 * scc); // same column, last row
+                    uint32_t goff = (uint32_t)__mul24(sya + (srs < SR ? srs : SR - 1), a_pitch) + (uint32_t)(sxa + 4 * scc);
+                    int li = __mul24(srs, dpr) + sc;
+                    const int lstep = __mul24(rpi, dpr), lend = s_on ? __mul24(SR, dpr) : 0;
+                    for (int r0 = 0; r0 < nround; r0 += 2 * SU) {
+                        uint32_t v[2 * SU];
+#pragma unroll
+                        for (int u = 0; u < 2 * SU; u++) {
+                            // rows past the rectangle re-read its last row: always inside the image
+                            __builtin_memcpy(&v[u], img + goff, 4);
+                            goff = goff + step < glast ? goff + step : glast;
+                        }
+                        if (r0 == 0) load_table(ta, 0);
+#pragma unroll
+                        for (int u = 0; u < 2 * SU; u++) {
+                            if (li < lend) ((uint32_t*)Sbuf)[li] = v[u];
+                            li += lstep;
+                        }
+                    }
+                } else
                 for (int r0 = 0; r0 < nround; r0 += 2 * SU) {
                     uint32_t v[2 * SU];
 #pragma unroll

@@ -384,6 +384,7 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
         const int tile_r1 = tile_r0 + a.rows_per_chunk < a.H ? tile_r0 + a.rows_per_chunk : a.H;
         const size_t cell_index = ((size_t)image * a.n_cgroups * 4 + chunk) * a.n_strips + strip;
         const int r0 = r0e > tile_r0 ? r0e : tile_r0, r1 = r1e < tile_r1 ? r1e : tile_r1; // the rows filtered
+        if (LIST && r0 >= r1) continue; // an empty band
         const int xbase = strip * 240 - 8;
 
         const int Hm1 = a.H - 1;
@@ -590,8 +591,8 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
             const int groups = (tile_r1 - tile_r0 + 7) >> 3;
             for (int g = 0; g < groups; g++)
                 if (__ballot(out_lane && ((lacc >> g) & 1u)) != 0ull) cellmask |= 1u << g;
-            // bit 31 marks a filtered tile; bits 0..16 are the groups
-            if (lane == 0) a.cells[cell_index] = cellmask | 0x80000000u;
+            // bit 31 marks a filtered tile; bits 0..16 are the groups (list form: several bands of a tile add their bits)
+            if (lane == 0) { if (LIST) atomicOr(&a.cells[cell_index], cellmask | 0x80000000u); else a.cells[cell_index] = cellmask | 0x80000000u; }
         }
     } // strips / list entries
 }

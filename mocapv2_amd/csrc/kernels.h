@@ -60,7 +60,7 @@ struct BoxArgs {
     uint4* wide_tiles;          // tiles whose box is wider than `wide_quads` patch quads go to this list instead (image, tile, first row,
                                 //   last row; counted in n_items[8]) and through the sliding row pipeline of filter_mask_kernel, which
                                 //   does less work per pixel on wide regions than the box kernel
-    uint32_t cap_wide; int wide_quads_remap, wide_quads_identity;
+    uint32_t cap_wide; int wide_quads_remap, wide_quads_identity, wide_bands;
     int dense;                  // 1 = no early-out: every tile is filtered whole
     int ext_mask;               // 1 = caller-owned mask (cleared by the scan kernel, or written whole when dense)
 };
