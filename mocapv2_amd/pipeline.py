@@ -157,18 +157,35 @@ class BatchTracker:
         from .engine import comm_unique_id
         from . import _abi
         dev = self.lanes[0].ctx.device
+        ok = True
         for lane in self.lanes:  # same order on every rank: communicator creation is collective
-            if self.world == 1:
-                uid = comm_unique_id()
-            else:
-                on_gpu = dist.get_backend(self.group) == "nccl"
-                box = torch.zeros(_abi.COMM_ID_BYTES, dtype=torch.uint8, device=dev if on_gpu else "cpu")
-                if self.rank == 0:
-                    box.copy_(torch.frombuffer(bytearray(comm_unique_id()), dtype=torch.uint8))
-                dist.broadcast(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
-                uid = bytes(box.cpu().numpy().tobytes())
-            lane.ctx.comm_init(uid, self.rank, self.world)
-            lane.gathered = torch.empty((self.world * self.per, self.rec_ints), dtype=torch.int32, device=dev)
+            try:
+                if self.world == 1:
+                    uid = comm_unique_id()
+                else:
+                    on_gpu = dist.get_backend(self.group) == "nccl"
+                    box = torch.zeros(_abi.COMM_ID_BYTES, dtype=torch.uint8, device=dev if on_gpu else "cpu")
+                    if self.rank == 0:
+                        box.copy_(torch.frombuffer(bytearray(comm_unique_id()), dtype=torch.uint8))
+                    dist.broadcast(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+                    uid = bytes(box.cpu().numpy().tobytes())
+                lane.ctx.comm_init(uid, self.rank, self.world)
+                lane.gathered = torch.empty((self.world * self.per, self.rec_ints), dtype=torch.int32, device=dev)
+            except Exception as e:  # noqa: BLE001 -- e.g. librccl not loadable: say so, and let every rank take the same road
+                import sys
+                print(f"[mocapv2_amd] rank {self.rank}: mocap_comm_init failed ({e}); exchanging through torch.distributed instead",
+                      file=sys.stderr)
+                ok = False
+                break
+        if self.world > 1 and have_pg:  # all ranks must agree on the transport
+            on_gpu = dist.get_backend(self.group) == "nccl"
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if on_gpu else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            ok = bool(flag.item())
+        if not ok:
+            for lane in self.lanes:
+                lane.gathered = None
+            return "torch"
         return "rccl"
 
     # the buffers of the batch most recently submitted
