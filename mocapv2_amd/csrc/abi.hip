@@ -611,7 +611,7 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
     prof_begin(c, 0, s, p, on);
     // MOCAP_WIDE_FORK=1: the wide-tile kernel on a side stream beside the box kernel (fork / join by events).  Measured: the pair takes
     // 0.53 ms instead of 0.49 alone and the three-batch pipeline 310k instead of 319k frames/s, so it is off.
-    static const bool fork_wide = getenv("MOCAP_WIDE_FORK") && atoi(getenv("MOCAP_WIDE_FORK")) != 0;
+    const bool fork_wide = getenv("MOCAP_WIDE_FORK") && atoi(getenv("MOCAP_WIDE_FORK")) != 0;
     if (a.wide_tiles) { // the tiles with wide boxes: the row pipeline over their list, beside the box kernel (both only read what
                         // settle left and write disjoint tiles): forked onto the context's side stream, joined before the contours
         FilterArgs f;

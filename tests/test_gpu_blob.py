@@ -507,3 +507,41 @@ def test_blob_centroids_from_bayer_equals_the_two_steps(torch_cuda, monkeypatch,
                 n = rec[i, 0]
                 assert n == two[i, 0] and n >= 0 and np.array_equal(rec[i, 2:2 + 2 * n], two[i, 2:2 + 2 * n]), (skip, b, i)
             assert rec[:, 0].sum() >= (4 if W >= 640 else 0)
+
+
+@pytest.mark.parametrize("env", [
+    {"MOCAP_WIDE_QUADS": "0,0"},                              # every marked tile through the row pipeline's list form
+    {"MOCAP_WIDE_QUADS": "1000,1000"},                        # every marked tile through the box kernel
+    {"MOCAP_WIDE_QUADS": "0,0", "MOCAP_WIDE_BANDS": "3"},     # ... its rows cut into bands
+    {"MOCAP_WIDE_QUADS": "0,0", "MOCAP_WIDE_FORK": "1"},      # ... on the side stream beside the box kernel
+    {"MOCAP_EXCESS_BASE": "0"}, {"MOCAP_EXCESS_BASE": "100"}, {"MOCAP_EXCESS_BASE": "200"},  # pinned excess bases
+    {"MOCAP_BASE_SEL": "0"},                                  # start with the tight base (then adapt)
+    {"MOCAP_BOX_BLOCKS_PER_CU": "1"},
+], ids=lambda e: ",".join(f"{k[6:]}={v}" for k, v in e.items()))
+def test_tuning_switches_do_not_change_results(torch_cuda, monkeypatch, env):
+    """Routing thresholds, row bands, the side stream, the scan's excess base (pinned or adapting) and the grid size are
+    performance knobs: centroids and masks equal the oracle's whatever they are.  Three batches on one context -- dark
+    frames, frames with a bright background (where the tolerant base is the better one), dark frames again -- so that the
+    base adapts in between and the mask's "zero outside the recorded regions" invariant is exercised across the switch."""
+    torch = torch_cuda
+    from gpu_util import unpack_mask
+    from mocapv2_amd.engine import MocapContext
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    W, H = 640, 360
+    sc = Scene(2, width=W, height=H, dist=np.array(MILD_DIST))
+    ctx = MocapContext(W, H, n_slots=2)
+    for sl in range(2):
+        ctx.set_undistort(sl, sc.K, sc.dist)
+    rng = np.random.default_rng(17)
+    for b, (lo, hi) in enumerate([(0, 60), (95, 115), (0, 60), (0, 60)]):
+        frames = np.stack([sc.render(rng, sc.markers(rng, 5, extent=0.8), i % 2, radius_range=(15, 20), noise_min=lo, noise_max=hi, salt=0.001)
+                           for i in range(34)])  # 34 images: every 16th one is probed
+        dev = torch.from_numpy(frames).cuda()
+        rec = ctx.blob_centroids(dev, cam_mod=2).cpu().numpy()
+        got, _ = unpack_mask(ctx.filter_mask(dev, cam_mod=2), W)
+        for i in range(len(frames)):
+            exp, m = oracle.find_dot(frames[i], sc.K, sc.dist, return_mask=True)
+            n = rec[i, 0]
+            assert n == len(exp) and rec[i, 2:2 + 2 * n].reshape(-1, 2).tolist() == exp, (b, i, env)
+            assert np.array_equal(got[i], m != 0), (b, i, env)
