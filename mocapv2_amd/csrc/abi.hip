@@ -56,7 +56,8 @@ struct mocap_ctx {
     bool mask_dirty;                       // the general kernel wrote the mask whole: clear it before the box path runs again
     uint32_t* cells; size_t cells_images; // occupancy cells written by the filter kernels for c->mask
     int last_images;                       // images of the most recent batch that wrote c->cells
-    uint32_t* tile_rows;                   // [mask_images][tiles][4] the scan's box per tile, beside cells (see BoxArgs)
+    uint32_t* tile_rows;                   // [2][mask_images][tiles][4] the scan's box per tile (see BoxArgs): two arrays, alternating
+    int tile_rows_flip;                    //   per batch: the one the scan widens and settle reads / the one settle empties
     uint32_t* cur_box;                     // [mask_images][tiles][4] output region / scan box of the last batch per tile (BoxArgs)
     BoxItem* items; uint32_t* n_items; uint32_t cap_items; // work list of the box kernel
     uint4* wide_tiles; uint32_t cap_wide;                  // list of the tiles with wide boxes (filter_mask_kernel, list form)
@@ -153,7 +154,7 @@ int mocap_ctx_create(int device_id, int width, int height, int n_slots, mocap_ct
     c->prm = mocap_blob_params{5, 5, 255 * 0.85, 500.0, 0.5};
     c->maps = nullptr; c->map4 = nullptr; c->srcbox = nullptr; c->reach = nullptr; c->cflags = nullptr; c->map_flags = nullptr;
     c->mask = nullptr; c->mask_images = 0; c->mask_dirty = false; c->cells = nullptr; c->cells_images = 0; c->last_images = 0;
-    c->tile_rows = nullptr; c->cur_box = nullptr; c->items = nullptr; c->n_items = nullptr; c->cap_items = 0; c->wide_tiles = nullptr; c->cap_wide = 0;
+    c->tile_rows = nullptr; c->tile_rows_flip = 0; c->cur_box = nullptr; c->items = nullptr; c->n_items = nullptr; c->cap_items = 0; c->wide_tiles = nullptr; c->cap_wide = 0;
     c->cells_ext = nullptr; c->cur_box_ext = nullptr; c->cells_ext_images = 0; c->cwork = nullptr; c->cwork_images = 0;
     c->cams = nullptr; c->n_cam = 0; c->n_F = 0; c->scratch = nullptr; c->scratch_elems = 0; c->profiling = false;
     c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1;
@@ -538,7 +539,13 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
     a.cam_mod = cam_mod; a.n_images = n_images; a.n_steps = (n_images + cam_mod - 1) / cam_mod;
     a.thr_mul = thr_mul;
     a.rows_per_chunk = tl.rows; a.n_strips = tl.n_strips; a.n_chunks = tl.n_cgroups * 4;
-    a.tile_rows = c->tile_rows;
+    const size_t tr_words = c->mask_images * cells_per_image(c) * 4;
+    uint32_t* const tr_cur = c->tile_rows + (c->tile_rows_flip ? tr_words : 0);
+    a.tile_rows = tr_cur;
+    a.tile_rows_next = c->tile_rows + (c->tile_rows_flip ? 0 : tr_words);
+    c->tile_rows_flip ^= 1;
+    a.cluster = 1;
+    { const char* e = getenv("MOCAP_CLUSTER"); if (e) a.cluster = atoi(e) != 0; } // A/B switch
     a.cur_box = own_mask ? c->cur_box : c->cur_box_ext;
     a.items = c->items; a.n_items = c->n_items; a.cap_items = c->cap_items;
     a.dense = allow < 0;
@@ -570,7 +577,7 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
         const uint32_t ncx_magic = (ncx64 > 1 && ncells * ncx64 < (1ull << 32)) ? (uint32_t)(((1ull << 32) + ncx64 - 1) / ncx64) : 0u;
         BrightArgs b{(const uint8_t*)frames, image_stride, pitch, c->H, c->W, n_images, cam_mod, ncx_magic, wide, base, allow / 4, allow_cut1 / 4, allow_cut2 / 4,
                      c->reach + (size_t)slot_base * source_cells(c), c->cflags + (size_t)slot_base * source_cells(c),
-                     c->tile_rows, tl.n_cgroups * 4, tl.n_strips, (uint32_t)(((1u << 23) + tl.rows - 1) / tl.rows),
+                     tr_cur, tl.n_cgroups * 4, tl.n_strips, (uint32_t)(((1u << 23) + tl.rows - 1) / tl.rows),
                      mask, own_mask ? 0 : (size_t)n_images * c->H * c->wpr, ((uintptr_t)mask & 15) == 0, nullptr, base_alt, allow_alt / 4, 0};
         { const char* e = getenv("MOCAP_SCAN_PRIO"); if (e) b.prio = atoi(e); } // A/B switch
         const bool probe = fixed_base < 0 && !c->probe_pending && allow_alt >= 0 && base_alt != base && !bayer &&
@@ -651,6 +658,9 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
             mx = tot > mx ? tot : mx;
         }
         const double n = sum[5] > 0 ? sum[5] : 1;
+        uint32_t cnt[16];
+        HIP_TRY(hipMemcpy(cnt, c->n_items, sizeof(cnt), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[box] list: %u items, %u wide-tile entries\n", cnt[0], cnt[8]);
         fprintf(stderr, "[box] items %.0f (%.1f per wave) | cycles per item: header+wait %.0f, stage %.0f, patch %.0f, threshold %.0f, majority+next %.0f | busiest wave %.0f cycles\n",
                 sum[5], sum[5] / c->box_grid, sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n, mx);
     }
@@ -742,8 +752,10 @@ static int ensure_mask(mocap_ctx* c, int n_images)
     {   // every tile starts with the empty box (0xffffffff, 0) and an empty recorded region (x0 = 1 > x1 = 0)
         std::vector<uint32_t> init((size_t)n_images * cells_per_image(c) * 4);
         for (size_t i = 0; i < init.size(); i += 2) { init[i] = 0xffffffffu; init[i + 1] = 0u; }
-        HIP_TRY(hipMalloc(&c->tile_rows, sizeof(uint32_t) * init.size()));
+        HIP_TRY(hipMalloc(&c->tile_rows, 2 * sizeof(uint32_t) * init.size()));
         HIP_TRY(hipMemcpy(c->tile_rows, init.data(), sizeof(uint32_t) * init.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->tile_rows + init.size(), init.data(), sizeof(uint32_t) * init.size(), hipMemcpyHostToDevice));
+        c->tile_rows_flip = 0;
         for (size_t i = 0; i < init.size(); i++) init[i] = 1u;
         HIP_TRY(hipMalloc(&c->cur_box, sizeof(uint32_t) * init.size()));
         HIP_TRY(hipMemcpy(c->cur_box, init.data(), sizeof(uint32_t) * init.size(), hipMemcpyHostToDevice));

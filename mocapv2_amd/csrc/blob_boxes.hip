@@ -116,13 +116,15 @@ __global__ __launch_bounds__(256) void settle_tiles_kernel(BoxArgs a)
     const int tile_x0 = 240 * strip, tile_x1 = imin(tile_x0 + 239, a.W - 1);
     int bx0 = 0, bx1 = a.W - 1, by0 = 0, by1 = a.H - 1; // the scan's box: where exact pixels are needed / bits can be set
     bool marked = valid;
+    uint4 raw = make_uint4(0xffffffffu, 0u, 0xffffffffu, 0u);
     if (valid && !a.dense) {
-        const uint4 r = *(const uint4*)(a.tile_rows + 4 * idx);
-        marked = r.x <= r.y;
-        if (marked) {
-            by0 = (int)r.x; by1 = (int)r.y; bx0 = (int)r.z; bx1 = (int)r.w;
-            *(uint4*)(a.tile_rows + 4 * idx) = make_uint4(0xffffffffu, 0u, 0xffffffffu, 0u); // ready for the next batch
-        }
+        // the scan's boxes of this batch are only read here (neighbouring tiles look at each other's); the buffer the NEXT
+        // batch's scan will widen -- read by the previous batch's settle -- is emptied instead
+        raw = *(const uint4*)(a.tile_rows + 4 * idx);
+        marked = raw.x <= raw.y;
+        if (marked) { by0 = (int)raw.x; by1 = (int)raw.y; bx0 = (int)raw.z; bx1 = (int)raw.w; }
+        const uint4 nxt = *(const uint4*)(a.tile_rows_next + 4 * idx);
+        if (nxt.x <= nxt.y) *(uint4*)(a.tile_rows_next + 4 * idx) = make_uint4(0xffffffffu, 0u, 0xffffffffu, 0u);
     }
     // output region of the tile: the box clipped to the tile, whole mask bytes
     int ox0 = imax(bx0, tile_x0) & ~7, ox1 = imin(imin(bx1, tile_x1) | 7, tile_x1);
@@ -133,13 +135,43 @@ __global__ __launch_bounds__(256) void settle_tiles_kernel(BoxArgs a)
     // sliding row pipeline, which then writes the whole width of the tile
     int nx = 0, ny = 0, nb = 0, h = 0;
     bool wide = false;
+    // The marked tiles of an aligned 2 x 2 block of tiles whose boxes together are small (one marker on a tile border,
+    // nothing else nearby) are filtered ONCE, as the union of their boxes clipped to the block, by the item the first of them
+    // emits -- instead of one clipped piece per tile, each with its own halo rows, staging and set-up.  Every tile of the
+    // block takes the same decision from the same read-only data; each still records its own clipped region.
+    int ix0 = ox0, ix1 = ox1, iy0 = oy0, iy1 = oy1; // region the emitted items cover
+    int ux0 = bx0, ux1 = bx1, uy0 = by0, uy1 = by1; // box the items take their exact pixels from
+    bool emits = marked;
+    if (marked && !a.dense && a.cluster) {
+        const int c0 = chunk & ~1, s0 = strip & ~1;
+        int n_marked = 0, first = -1, X0 = 0x7fffffff, X1 = -1, Y0 = 0x7fffffff, Y1 = -1;
+        for (int k = 0; k < 4; k++) {
+            const int cy = c0 + (k >> 1), sx = s0 + (k & 1);
+            if (cy >= a.n_chunks || sx >= a.n_strips || cy * a.rows_per_chunk >= a.H) continue;
+            const uint4 o = *(const uint4*)(a.tile_rows + 4 * (((size_t)image * a.n_chunks + cy) * a.n_strips + sx));
+            if (o.x > o.y) continue;
+            if (first < 0) first = k;
+            n_marked++;
+            Y0 = imin(Y0, (int)o.x); Y1 = imax(Y1, (int)o.y); X0 = imin(X0, (int)o.z); X1 = imax(X1, (int)o.w);
+        }
+        if (n_marked >= 2) {
+            // the union, clipped to the block and the image, in whole mask bytes
+            const int bx_lo = 240 * s0, bx_hi = imin(240 * (s0 + 2) - 1, a.W - 1), by_lo = c0 * a.rows_per_chunk, by_hi = imin((c0 + 2) * a.rows_per_chunk, a.H) - 1;
+            const int ex0 = imax(X0, bx_lo) & ~7, ex1 = imin(X1 | 7, bx_hi), ey0 = imax(Y0, by_lo), ey1 = imin(Y1, by_hi);
+            if (((ex1 - ex0 + 8) >> 3) <= 13 && ey1 - ey0 + 1 <= 100) {
+                emits = first == ((chunk - c0) * 2 + (strip - s0));
+                ix0 = ex0; ix1 = ex1; iy0 = ey0; iy1 = ey1;
+                ux0 = X0; ux1 = X1; uy0 = Y0; uy1 = Y1;
+            }
+        }
+    }
     if (marked) {
-        nb = (ox1 - ox0 + 8) >> 3; h = oy1 - oy0 + 1;
+        nb = (ix1 - ix0 + 8) >> 3; h = iy1 - iy0 + 1;
         choose_split(nb, h, nx, ny);
         const int slot_ = image % a.cam_mod;
         const int limit = ((a.remap_bits >> slot_) & 1ull) ? a.wide_quads_remap : a.wide_quads_identity;
-        wide = a.wide_tiles != nullptr && 2 * nb + 2 * nx >= limit;
-        if (wide) { ox0 = tile_x0; ox1 = tile_x1; }
+        wide = emits && ix0 == ox0 && ix1 == ox1 && iy0 == oy0 && iy1 == oy1 && a.wide_tiles != nullptr && 2 * nb + 2 * nx >= limit;
+        if (wide) { ox0 = tile_x0; ox1 = tile_x1; ix0 = ox0; ix1 = ox1; }
     }
     const uint32_t nout_x = (uint32_t)ox0 | ((uint32_t)ox1 << 16), nout_y = (uint32_t)oy0 | ((uint32_t)oy1 << 16);
 
@@ -192,7 +224,7 @@ __global__ __launch_bounds__(256) void settle_tiles_kernel(BoxArgs a)
         }
     }
     // items
-    const int cnt = wide ? 0 : nx * ny;
+    const int cnt = (wide || !emits) ? 0 : nx * ny;
     int incl = cnt; // inclusive prefix sum over the wave
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -209,8 +241,8 @@ __global__ __launch_bounds__(256) void settle_tiles_kernel(BoxArgs a)
         const int pb = (nb + nx - 1) / nx, ph = (h + ny - 1) / ny;
         for (int jy = 0; jy < ny; jy++)
             for (int jx = 0; jx < nx; jx++, o++) {
-                const int x0 = ox0 + 8 * pb * jx, x1 = imin(x0 + 8 * pb - 1, ox1);
-                const int y0 = oy0 + ph * jy, y1 = imin(y0 + ph - 1, oy1);
+                const int x0 = ix0 + 8 * pb * jx, x1 = imin(x0 + 8 * pb - 1, ix1);
+                const int y0 = iy0 + ph * jy, y1 = imin(y0 + ph - 1, iy1);
                 if (o >= a.cap_items) continue; // cannot happen: the list holds BOX_MAX_PARTS items per tile
                 uint4 it;
                 it.x = (uint32_t)image;
@@ -219,7 +251,7 @@ __global__ __launch_bounds__(256) void settle_tiles_kernel(BoxArgs a)
                 it.w = (uint32_t)y0 | ((uint32_t)y1 << 16);
                 if (x0 > x1 || y0 > y1) it.z = 1u; // an empty part (rounding of the split): the consumer skips it
                 ((uint4*)a.items)[2 * o] = it;
-                ((uint4*)a.items)[2 * o + 1] = make_uint4((uint32_t)bx0 | ((uint32_t)bx1 << 16), (uint32_t)by0 | ((uint32_t)by1 << 16), 0u, 0u);
+                ((uint4*)a.items)[2 * o + 1] = make_uint4((uint32_t)ux0 | ((uint32_t)ux1 << 16), (uint32_t)uy0 | ((uint32_t)uy1 << 16), 0u, 0u);
             }
     }
 }
@@ -373,10 +405,9 @@ __global__ __launch_bounds__(64) void box_filter_kernel(BoxArgs a)
             nitem = take_resolve(nn_raw);
             continue;
         }
-        const int image = g.image, tile = g.tile, slot = g.slot;
+        const int image = g.image, slot = g.slot;
         const int ox0 = g.ox0, oy0 = g.oy0, oy1 = g.oy1, Q = g.Q, px0 = g.px0, ty0 = g.ty0, ty1 = g.ty1, hy0 = g.hy0, PR = g.PR;
         const int ey0 = g.ey0, ey1 = g.ey1, eq0 = g.eq0, eq1 = g.eq1;
-        const size_t idx = (size_t)image * a_n_chunks * a_n_strips + tile;
         const float rcpQ = __builtin_amdgcn_rcpf((float)Q);
         const int rpw = small_div(64, rcpQ);
         const int rsub = small_div(lane, rcpQ), q = lane - rsub * Q;
@@ -634,11 +665,13 @@ __global__ __launch_bounds__(64) void box_filter_kernel(BoxArgs a)
         tick(3);
 
         // ---- pass C: majority (>= 13 of 25) of every output row, two quads -> one byte of the bit mask -----------------
-        const int tile_r0 = (tile / a_n_strips) * a_rows_per_chunk;
+        // the item's output region lies in at most 2 x 2 tiles: chunks chunk0 (+1), strips strip0 (+1)
+        const int chunk0 = oy0 / a_rows_per_chunk, strip0 = ox0 / 240;
+        const int tile_r0 = chunk0 * a_rows_per_chunk, tile_r1 = tile_r0 + a_rows_per_chunk; // first row of chunk0 / of chunk0 + 1
         uint8_t* __restrict__ mrow = (uint8_t*)(a_mask + (size_t)image * H * a_words_per_row);
         const int out_byte = (ox0 >> 3) + ((q - 1) >> 1);
         const bool stores = lane_on && (q & 1) && q <= Q - 3 && out_byte < ((W + 7) >> 3) && out_byte < row_bytes;
-        uint32_t lacc = 0; // bit g: rows 8g..8g+7 of the tile's chunk hold set pixels in this lane's columns
+        uint32_t lacc = 0, lacc1 = 0; // bit g: rows 8g..8g+7 of chunk0 (lacc) / chunk0 + 1 (lacc1) hold set pixels in this lane's columns
         const int ntrip_c = (oy1 - oy0 + 1 + rpw - 1) / rpw;
         const bool inner = oy0 >= 2 && oy1 + 2 <= Hm1; // no row of the item's windows is replicated
         auto pass_c = [&](auto inner_c) __attribute__((always_inline)) {
@@ -664,17 +697,25 @@ __global__ __launch_bounds__(64) void box_filter_kernel(BoxArgs a)
                 const uint32_t byte = mn | ((odd & 0xfu) << 4);
                 const bool st = stores && y <= oy1;
                 if (st) mrow[(size_t)y * row_bytes + out_byte] = (uint8_t)byte;
-                lacc |= ((st && byte != 0u) ? 1u : 0u) << ((yy - tile_r0) >> 3);
+                const uint32_t hit = (st && byte != 0u) ? 1u : 0u;
+                if (yy < tile_r1) lacc |= hit << ((yy - tile_r0) >> 3);
+                else lacc1 |= hit << ((yy - tile_r1) >> 3);
             }
         };
         if (inner) pass_c(std::true_type{});
         else pass_c(std::false_type{});
-        {   // occupancy word of the tile (read by the contour kernel): OR of every lane's row groups; bit 31 = filtered
-            uint32_t cellmask = 0;
-            const int g0 = (oy0 - tile_r0) >> 3, g1 = (oy1 - tile_r0) >> 3;
-            for (int gg = g0; gg <= g1; gg++)
-                if (__ballot((lacc >> gg) & 1u) != 0ull) cellmask |= 1u << gg;
-            if (lane == 0) atomicOr(&a_cells[idx], cellmask | 0x80000000u);
+        {   // occupancy words of the tiles (read by the contour kernel): OR of every lane's row groups; bit 31 = filtered
+            const int lstrip = (out_byte >= 30 * (strip0 + 1)) ? 1 : 0;   // this lane's bytes lie in strip0 or strip0 + 1
+            const int chunk1 = oy1 / a_rows_per_chunk, strip1 = (g.ox1 >> 3) / 30;
+            for (int cc = 0; cc <= chunk1 - chunk0; cc++)
+                for (int ss = 0; ss <= strip1 - strip0; ss++) {
+                    const uint32_t la = cc ? lacc1 : lacc;
+                    uint32_t cellmask = 0;
+                    for (int gg = 0; gg < 9; gg++)
+                        if (__ballot(lstrip == ss && ((la >> gg) & 1u)) != 0ull) cellmask |= 1u << gg;
+                    const size_t cidx = ((size_t)image * a_n_chunks + chunk0 + cc) * a_n_strips + strip0 + ss;
+                    if (lane == 0) atomicOr(&a_cells[cidx], cellmask | 0x80000000u);
+                }
         }
         g = gn; sbp = sbn; item = nitem;
         nitem = take_resolve(nn_raw);

@@ -48,8 +48,10 @@ struct BoxArgs {
     int cam_mod, n_images, n_steps;
     int thr_mul;
     int rows_per_chunk, n_strips, n_chunks;
-    uint32_t* tile_rows;        // [n_images][n_chunks][n_strips][4]: the scan's boxes (first / last row, first / last column;
-                                //   (0xffffffff, 0) = none), reset by settle
+    uint32_t* tile_rows;        // [n_images][n_chunks][n_strips][4]: the scan's boxes of this batch (first / last row, first / last
+                                //   column; (0xffffffff, 0) = none), read-only for settle
+    uint32_t* tile_rows_next;   // the same array for the next batch (the two alternate): emptied by settle
+    int cluster;                // 1 = a box spanning tiles that all hold it becomes one item (A/B switch)
     uint32_t* cur_box;          // [n_images][n_chunks][n_strips][4]: words 0-1 the tile's output region of this batch
                                 //   (x0 | x1 << 16, y0 | y1 << 16; x0 > x1 = none) = what the mask may hold there; words 2-3 the
                                 //   scan's box (not clipped to the tile)
