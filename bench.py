@@ -204,7 +204,7 @@ def parity_report(results, records, out, n_cam, max_points):
             "oracle": "oracle/ C restatement (geometry half pinned to the reference, blob half parity unpinned: DESIGN.md 2)"}
 
 
-KERNELS = (("scan", "bright_cells_kernel"), ("settle", "settle_tiles_kernel"), ("filter", "box_filter_kernel"))
+KERNELS = (("scan", "bright_cells_kernel"), ("settle", "settle_tiles_kernel"), ("filter", "box_filter_kernel + filter_mask_kernel (wide tiles)"))
 
 
 def roofline_of(prof, wl, n_images, n_launch_groups, traffic_key):
@@ -228,7 +228,8 @@ def roofline_of(prof, wl, n_images, n_launch_groups, traffic_key):
         if n == 0:
             continue
         ms = prof[key + "_ms"] / n
-        ent[name] = {"kernel": name, "avg_launch_ms": round(ms, 4), "traffic": traffic.get(name)}
+        parts = [traffic.get(p.split(" (")[0]) for p in name.split(" + ")]  # HBM bytes of every kernel behind this timer
+        ent[name] = {"kernel": name, "avg_launch_ms": round(ms, 4), "traffic": sum(parts) if parts and all(t is not None for t in parts) else None}
         if key == "scan" or len([k for k, _ in KERNELS if prof[k + "_launches"]]) == 1:
             ach = bytes_img * per_launch / (ms * 1e-3) / 1e9
             ent[name].update({"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -238,7 +239,7 @@ def roofline_of(prof, wl, n_images, n_launch_groups, traffic_key):
             ent[name]["avg_launch_ms_in_timed_region"] = round(tr[key + "_ms"] / tr[key + "_launches"], 4)
     stage_ms = sum(e["avg_launch_ms"] for e in ent.values())
     ach = bytes_img * per_launch / (stage_ms * 1e-3) / 1e9
-    tr_known = [traffic.get(k) for k in ent]
+    tr_known = [e["traffic"] for e in ent.values()]
     roof = {"bound": "hbm", "kernel": " + ".join(ent), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4),
             "traffic": sum(tr_known) if tr_known and all(t is not None for t in tr_known) else None,
