@@ -539,13 +539,13 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
     a.cam_mod = cam_mod; a.n_images = n_images; a.n_steps = (n_images + cam_mod - 1) / cam_mod;
     a.thr_mul = thr_mul;
     a.rows_per_chunk = tl.rows; a.n_strips = tl.n_strips; a.n_chunks = tl.n_cgroups * 4;
-    const size_t tr_words = c->mask_images * cells_per_image(c) * 8;
+    const size_t tr_words = c->mask_images * cells_per_image(c) * 4;
     uint32_t* const tr_cur = c->tile_rows + (c->tile_rows_flip ? tr_words : 0);
     a.tile_rows = tr_cur;
     a.tile_rows_next = c->tile_rows + (c->tile_rows_flip ? 0 : tr_words);
     c->tile_rows_flip ^= 1;
-    a.halves = 1;
-    { const char* e = getenv("MOCAP_HALVES"); if (e) a.halves = atoi(e) != 0; } // A/B switch
+    a.cluster = 1;
+    { const char* e = getenv("MOCAP_CLUSTER"); if (e) a.cluster = atoi(e) != 0; } // A/B switch
     a.cur_box = own_mask ? c->cur_box : c->cur_box_ext;
     a.items = c->items; a.n_items = c->n_items; a.cap_items = c->cap_items;
     a.dense = allow < 0;
@@ -564,7 +564,7 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
     { const char* e = getenv("MOCAP_BOX_PRIO"); if (e) a.prio = atoi(e) != 0; } // A/B switch
     { const char* e = getenv("MOCAP_BOX_STAGE_BYTES"); if (e && atoi(e) >= 0 && atoi(e) < BOX_SCAP) a.stage_bytes = atoi(e); } // test switch
     a.ext_mask = own_mask ? 0 : 1;
-    if ((size_t)n_images * cells_per_image(c) * 2 * BOX_MAX_PARTS > (size_t)c->cap_items) return fail(MOCAP_E_STATE, "work list smaller than the batch");
+    if ((size_t)n_images * cells_per_image(c) * BOX_MAX_PARTS > (size_t)c->cap_items) return fail(MOCAP_E_STATE, "work list smaller than the batch");
     HIP_TRY(hipMemsetAsync(c->n_items, 0, 1024, s));
     if (!a.dense) { // one streaming pass over the frames marks the tiles (and their boxes) that can hold set pixels
         // floor(i / ncx) = umulhi(i, ceil(2^32 / ncx)) is exact while i * ncx < 2^32
@@ -577,7 +577,7 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
         const uint32_t ncx_magic = (ncx64 > 1 && ncells * ncx64 < (1ull << 32)) ? (uint32_t)(((1ull << 32) + ncx64 - 1) / ncx64) : 0u;
         BrightArgs b{(const uint8_t*)frames, image_stride, pitch, c->H, c->W, n_images, cam_mod, ncx_magic, wide, base, allow / 4, allow_cut1 / 4, allow_cut2 / 4,
                      c->reach + (size_t)slot_base * source_cells(c), c->cflags + (size_t)slot_base * source_cells(c),
-                     tr_cur, tl.n_cgroups * 4, 2 * tl.n_strips, (uint32_t)(((1u << 23) + tl.rows - 1) / tl.rows),
+                     tr_cur, tl.n_cgroups * 4, tl.n_strips, (uint32_t)(((1u << 23) + tl.rows - 1) / tl.rows),
                      mask, own_mask ? 0 : (size_t)n_images * c->H * c->wpr, ((uintptr_t)mask & 15) == 0, nullptr, base_alt, allow_alt / 4, 0};
         { const char* e = getenv("MOCAP_SCAN_PRIO"); if (e) b.prio = atoi(e); } // A/B switch
         const bool probe = fixed_base < 0 && !c->probe_pending && allow_alt >= 0 && base_alt != base && !bayer &&
@@ -750,16 +750,16 @@ static int ensure_mask(mocap_ctx* c, int n_images)
     if (c->items) { HIP_TRY(hipFree(c->items)); c->items = nullptr; c->cap_items = 0; }
     if (c->wide_tiles) { HIP_TRY(hipFree(c->wide_tiles)); c->wide_tiles = nullptr; c->cap_wide = 0; }
     {   // every tile starts with the empty box (0xffffffff, 0) and an empty recorded region (x0 = 1 > x1 = 0)
-        std::vector<uint32_t> init((size_t)n_images * cells_per_image(c) * 8); // one box per half tile
+        std::vector<uint32_t> init((size_t)n_images * cells_per_image(c) * 4);
         for (size_t i = 0; i < init.size(); i += 2) { init[i] = 0xffffffffu; init[i + 1] = 0u; }
         HIP_TRY(hipMalloc(&c->tile_rows, 2 * sizeof(uint32_t) * init.size()));
         HIP_TRY(hipMemcpy(c->tile_rows, init.data(), sizeof(uint32_t) * init.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->tile_rows + init.size(), init.data(), sizeof(uint32_t) * init.size(), hipMemcpyHostToDevice));
         c->tile_rows_flip = 0;
-        init.assign((size_t)n_images * cells_per_image(c) * 4, 1u);
+        for (size_t i = 0; i < init.size(); i++) init[i] = 1u;
         HIP_TRY(hipMalloc(&c->cur_box, sizeof(uint32_t) * init.size()));
         HIP_TRY(hipMemcpy(c->cur_box, init.data(), sizeof(uint32_t) * init.size(), hipMemcpyHostToDevice));
-        const size_t cap = (size_t)n_images * cells_per_image(c) * 2 * BOX_MAX_PARTS; // settle_tiles_kernel cuts a tile into at most that many items
+        const size_t cap = (size_t)n_images * cells_per_image(c) * BOX_MAX_PARTS; // settle_tiles_kernel cuts a tile into at most that many items
         if (cap > 0xffffffffull) return fail(MOCAP_E_UNSUPPORTED, "batch too large for the work list");
         HIP_TRY(hipMalloc(&c->items, sizeof(BoxItem) * cap));
         c->cap_items = (uint32_t)cap;

@@ -114,77 +114,70 @@ __global__ __launch_bounds__(256) void settle_tiles_kernel(BoxArgs a)
     const size_t idx = ((size_t)image * a.n_chunks + chunk) * a.n_strips + strip;
     const int tile_r0 = chunk * a.rows_per_chunk, tile_r1 = imin(tile_r0 + a.rows_per_chunk, a.H) - 1;
     const int tile_x0 = 240 * strip, tile_x1 = imin(tile_x0 + 239, a.W - 1);
-    // The scan keeps one box per HALF tile (120 columns): hx[k] = the box of the hot-cell rectangles that overlap half k
-    // (not clipped to it).  This batch's boxes are only read here; the array the NEXT batch's scan will widen -- read by
-    // the previous batch's settle -- is emptied instead.
-    int hx0[2] = {0, 0}, hx1[2] = {-1, -1}, hy0[2] = {0, 0}, hy1[2] = {-1, -1};
-    bool hm[2] = {false, false};
+    int bx0 = 0, bx1 = a.W - 1, by0 = 0, by1 = a.H - 1; // the scan's box: where exact pixels are needed / bits can be set
+    bool marked = valid;
+    uint4 raw = make_uint4(0xffffffffu, 0u, 0xffffffffu, 0u);
     if (valid && !a.dense) {
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const size_t hidx = 4 * (2 * idx + k);
-            const uint4 r = *(const uint4*)(a.tile_rows + hidx);
-            hm[k] = r.x <= r.y;
-            if (hm[k]) { hy0[k] = (int)r.x; hy1[k] = (int)r.y; hx0[k] = (int)r.z; hx1[k] = (int)r.w; }
-            const uint4 nxt = *(const uint4*)(a.tile_rows_next + hidx);
-            if (nxt.x <= nxt.y) *(uint4*)(a.tile_rows_next + hidx) = make_uint4(0xffffffffu, 0u, 0xffffffffu, 0u);
-        }
-    }
-    bool marked = valid && (a.dense || hm[0] || hm[1]);
-    // union of the two: where exact pixels are needed / bits can be set in this tile
-    int bx0 = 0, bx1 = a.W - 1, by0 = 0, by1 = a.H - 1;
-    if (marked && !a.dense) {
-        bx0 = hm[0] ? (hm[1] ? imin(hx0[0], hx0[1]) : hx0[0]) : hx0[1];
-        bx1 = hm[0] ? (hm[1] ? imax(hx1[0], hx1[1]) : hx1[0]) : hx1[1];
-        by0 = hm[0] ? (hm[1] ? imin(hy0[0], hy0[1]) : hy0[0]) : hy0[1];
-        by1 = hm[0] ? (hm[1] ? imax(hy1[0], hy1[1]) : hy1[0]) : hy1[1];
+        // the scan's boxes of this batch are only read here (neighbouring tiles look at each other's); the buffer the NEXT
+        // batch's scan will widen -- read by the previous batch's settle -- is emptied instead
+        raw = *(const uint4*)(a.tile_rows + 4 * idx);
+        marked = raw.x <= raw.y;
+        if (marked) { by0 = (int)raw.x; by1 = (int)raw.y; bx0 = (int)raw.z; bx1 = (int)raw.w; }
+        const uint4 nxt = *(const uint4*)(a.tile_rows_next + 4 * idx);
+        if (nxt.x <= nxt.y) *(uint4*)(a.tile_rows_next + 4 * idx) = make_uint4(0xffffffffu, 0u, 0xffffffffu, 0u);
     }
     // output region of the tile: the box clipped to the tile, whole mask bytes
     int ox0 = imax(bx0, tile_x0) & ~7, ox1 = imin(imin(bx1, tile_x1) | 7, tile_x1);
     int oy0 = imax(by0, tile_r0), oy1 = imin(by1, tile_r1);
     if (marked && (ox0 > ox1 || oy0 > oy1)) marked = false;
     if (!marked) { ox0 = 1; ox1 = 0; oy0 = 1; oy1 = 0; }
-    // How the tile is filtered.  Its output region is cut into items for the box kernel; or -- a wide box -- its rows go
-    // through the sliding row pipeline, which then writes the whole width of the tile; or -- wide only because its two halves
-    // hold separate things (a marker here, a few noise pixels near the image border there) -- each half gets items of its own.
-    int nset = 0;                                   // item sets: 0 (wide or unmarked), 1 (the union) or 2 (the halves)
-    int sx0[2], sx1[2], sy0[2], sy1[2], ux0[2], ux1[2], uy0[2], uy1[2], snx[2] = {0, 0}, sny[2] = {0, 0};
+    // how the tile is filtered: cut into items for the box kernel, or -- a wide box -- as the tile's rows through the
+    // sliding row pipeline, which then writes the whole width of the tile
+    int nx = 0, ny = 0, nb = 0, h = 0;
     bool wide = false;
+    // The marked tiles of an aligned 2 x 2 block of tiles whose boxes together are small (one marker on a tile border,
+    // nothing else nearby) are filtered ONCE, as the union of their boxes clipped to the block, by the item the first of them
+    // emits -- instead of one clipped piece per tile, each with its own halo rows, staging and set-up.  Every tile of the
+    // block takes the same decision from the same read-only data; each still records its own clipped region.
+    int ix0 = ox0, ix1 = ox1, iy0 = oy0, iy1 = oy1; // region the emitted items cover
+    int ux0 = bx0, ux1 = bx1, uy0 = by0, uy1 = by1; // box the items take their exact pixels from
+    bool emits = marked;
+    if (marked && !a.dense && a.cluster) {
+        const int c0 = chunk & ~1, s0 = strip & ~1;
+        int n_marked = 0, first = -1, X0 = 0x7fffffff, X1 = -1, Y0 = 0x7fffffff, Y1 = -1;
+        for (int k = 0; k < 4; k++) {
+            const int cy = c0 + (k >> 1), sx = s0 + (k & 1);
+            if (cy >= a.n_chunks || sx >= a.n_strips || cy * a.rows_per_chunk >= a.H) continue;
+            const uint4 o = *(const uint4*)(a.tile_rows + 4 * (((size_t)image * a.n_chunks + cy) * a.n_strips + sx));
+            if (o.x > o.y) continue;
+            if (first < 0) first = k;
+            n_marked++;
+            Y0 = imin(Y0, (int)o.x); Y1 = imax(Y1, (int)o.y); X0 = imin(X0, (int)o.z); X1 = imax(X1, (int)o.w);
+        }
+        if (n_marked >= 2) {
+            // the union, clipped to the block and the image, in whole mask bytes
+            const int bx_lo = 240 * s0, bx_hi = imin(240 * (s0 + 2) - 1, a.W - 1), by_lo = c0 * a.rows_per_chunk, by_hi = imin((c0 + 2) * a.rows_per_chunk, a.H) - 1;
+            const int ex0 = imax(X0, bx_lo) & ~7, ex1 = imin(X1 | 7, bx_hi), ey0 = imax(Y0, by_lo), ey1 = imin(Y1, by_hi);
+            if (((ex1 - ex0 + 8) >> 3) <= 13 && ey1 - ey0 + 1 <= 100) {
+                emits = first == ((chunk - c0) * 2 + (strip - s0));
+                ix0 = ex0; ix1 = ex1; iy0 = ey0; iy1 = ey1;
+                ux0 = X0; ux1 = X1; uy0 = Y0; uy1 = Y1;
+            }
+        }
+    }
     if (marked) {
-        int nx, ny;
-        const int nb = (ox1 - ox0 + 8) >> 3, h = oy1 - oy0 + 1;
+        nb = (ix1 - ix0 + 8) >> 3; h = iy1 - iy0 + 1;
         choose_split(nb, h, nx, ny);
         const int slot_ = image % a.cam_mod;
         const int limit = ((a.remap_bits >> slot_) & 1ull) ? a.wide_quads_remap : a.wide_quads_identity;
-        wide = a.wide_tiles != nullptr && 2 * nb + 2 * nx >= limit;
-        nset = 1;
-        sx0[0] = ox0; sx1[0] = ox1; sy0[0] = oy0; sy1[0] = oy1; ux0[0] = bx0; ux1[0] = bx1; uy0[0] = by0; uy1[0] = by1; snx[0] = nx; sny[0] = ny;
-        if (wide && !a.dense && a.halves && hm[0] && hm[1] && hx1[0] < hx0[1]) {
-            // two disjoint halves: worth it if their patches together are clearly narrower than the union's
-            int q = 0;
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                sx0[k] = imax(hx0[k], tile_x0) & ~7; sx1[k] = imin(imin(hx1[k], tile_x1) | 7, tile_x1);
-                sy0[k] = imax(hy0[k], tile_r0); sy1[k] = imin(hy1[k], tile_r1);
-                ux0[k] = hx0[k]; ux1[k] = hx1[k]; uy0[k] = hy0[k]; uy1[k] = hy1[k];
-                snx[k] = sny[k] = 0;
-                if (sx0[k] <= sx1[k] && sy0[k] <= sy1[k]) {
-                    choose_split((sx1[k] - sx0[k] + 8) >> 3, sy1[k] - sy0[k] + 1, snx[k], sny[k]);
-                    q += 2 * ((sx1[k] - sx0[k] + 8) >> 3) + 2 * snx[k];
-                }
-            }
-            if (sx1[0] < sx0[1] && q + 8 <= 2 * nb + 2 * nx) { wide = false; nset = 2; }
-            else { sx0[0] = ox0; sx1[0] = ox1; sy0[0] = oy0; sy1[0] = oy1; ux0[0] = bx0; ux1[0] = bx1; uy0[0] = by0; uy1[0] = by1; snx[0] = nx; sny[0] = ny; }
-        }
-        if (wide) { ox0 = tile_x0; ox1 = tile_x1; nset = 0; }
+        wide = emits && ix0 == ox0 && ix1 == ox1 && iy0 == oy0 && iy1 == oy1 && a.wide_tiles != nullptr && 2 * nb + 2 * nx >= limit;
+        if (wide) { ox0 = tile_x0; ox1 = tile_x1; ix0 = ox0; ix1 = ox1; }
     }
     const uint32_t nout_x = (uint32_t)ox0 | ((uint32_t)ox1 << 16), nout_y = (uint32_t)oy0 | ((uint32_t)oy1 << 16);
 
     // What the previous batch wrote in this tile of the context's own mask and this batch will not overwrite is
     // cleared here (the mask keeps "zero outside the recorded regions" from batch to batch; a caller-owned mask was
-    // cleared by the scan kernel instead, or is written whole when every tile is filtered).  With two item sets the
-    // recorded region is still the union's: the columns between the halves are simply never written, so they are cleared
-    // whenever the previous region is not inside ONE of the regions written now.
+    // cleared by the scan kernel instead, or is written whole when every tile is filtered).
     bool need_clear = false;
     uint32_t pout_x = 1u, pout_y = 1u; // empty
     if (valid) {
@@ -193,12 +186,7 @@ __global__ __launch_bounds__(256) void settle_tiles_kernel(BoxArgs a)
             const uint4 prev = *cb;
             pout_x = prev.x; pout_y = prev.y;
             const int px0 = (int)(prev.x & 0xffffu), px1 = (int)(prev.x >> 16), py0 = (int)(prev.y & 0xffffu), py1 = (int)(prev.y >> 16);
-            if (px0 <= px1) {
-                bool inside = false;
-                if (marked && nset == 0) inside = ox0 <= px0 && px1 <= ox1 && oy0 <= py0 && py1 <= oy1; // the whole width, the union's rows
-                for (int k = 0; k < nset; k++) inside = inside || (sx0[k] <= px0 && px1 <= sx1[k] && sy0[k] <= py0 && py1 <= sy1[k]);
-                need_clear = !inside;
-            }
+            if (px0 <= px1) need_clear = !(marked && ox0 <= px0 && px1 <= ox1 && oy0 <= py0 && py1 <= oy1);
             if (prev.x != nout_x || prev.y != nout_y || marked)
                 *cb = make_uint4(nout_x, nout_y, (uint32_t)bx0 | ((uint32_t)bx1 << 16), (uint32_t)by0 | ((uint32_t)by1 << 16));
             if (a.cells[idx] != 0u) a.cells[idx] = 0u;
@@ -218,7 +206,9 @@ __global__ __launch_bounds__(256) void settle_tiles_kernel(BoxArgs a)
             for (int b = b0; b <= b1; b++) m[(size_t)y * rb + b] = 0;
     }
 
-    if (uint64_t wb = __ballot(wide)) { // the wide tiles of this wave: `wide_bands` slots each in their list
+    if (uint64_t wb = __ballot(wide)) { // the wide tiles of this wave: `wide_bands` slots each in their list (the row pipeline is a
+        // serial walk down the rows, so a tile's latency, not its work, sets the duration of that short kernel: its rows are cut
+        // into bands for several waves, 8 halo rows each)
         const int nbands = a.wide_bands;
         uint32_t base_w = 0;
         if (lane == 0) base_w = atomicAdd(a.n_items + 8, (uint32_t)(__popcll(wb) * nbands));
@@ -234,7 +224,7 @@ __global__ __launch_bounds__(256) void settle_tiles_kernel(BoxArgs a)
         }
     }
     // items
-    const int cnt = snx[0] * sny[0] * (nset >= 1 ? 1 : 0) + snx[1] * sny[1] * (nset == 2 ? 1 : 0);
+    const int cnt = (wide || !emits) ? 0 : nx * ny;
     int incl = cnt; // inclusive prefix sum over the wave
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -247,16 +237,13 @@ __global__ __launch_bounds__(256) void settle_tiles_kernel(BoxArgs a)
     if (lane == 0) base = atomicAdd(a.n_items, (uint32_t)wave_total);
     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
     uint32_t o = base + (uint32_t)(incl - cnt);
-    for (int k = 0; k < nset; k++) {
-        const int nx = snx[k], ny = sny[k];
-        if (nx * ny == 0) continue;
-        const int nb = (sx1[k] - sx0[k] + 8) >> 3, h = sy1[k] - sy0[k] + 1;
+    if (cnt) {
         const int pb = (nb + nx - 1) / nx, ph = (h + ny - 1) / ny;
         for (int jy = 0; jy < ny; jy++)
             for (int jx = 0; jx < nx; jx++, o++) {
-                const int x0 = sx0[k] + 8 * pb * jx, x1 = imin(x0 + 8 * pb - 1, sx1[k]);
-                const int y0 = sy0[k] + ph * jy, y1 = imin(y0 + ph - 1, sy1[k]);
-                if (o >= a.cap_items) continue; // cannot happen: the list holds 2 * BOX_MAX_PARTS items per tile
+                const int x0 = ix0 + 8 * pb * jx, x1 = imin(x0 + 8 * pb - 1, ix1);
+                const int y0 = iy0 + ph * jy, y1 = imin(y0 + ph - 1, iy1);
+                if (o >= a.cap_items) continue; // cannot happen: the list holds BOX_MAX_PARTS items per tile
                 uint4 it;
                 it.x = (uint32_t)image;
                 it.y = (uint32_t)(chunk * a.n_strips + strip);
@@ -264,7 +251,7 @@ __global__ __launch_bounds__(256) void settle_tiles_kernel(BoxArgs a)
                 it.w = (uint32_t)y0 | ((uint32_t)y1 << 16);
                 if (x0 > x1 || y0 > y1) it.z = 1u; // an empty part (rounding of the split): the consumer skips it
                 ((uint4*)a.items)[2 * o] = it;
-                ((uint4*)a.items)[2 * o + 1] = make_uint4((uint32_t)ux0[k] | ((uint32_t)ux1[k] << 16), (uint32_t)uy0[k] | ((uint32_t)uy1[k] << 16), 0u, 0u);
+                ((uint4*)a.items)[2 * o + 1] = make_uint4((uint32_t)ux0 | ((uint32_t)ux1 << 16), (uint32_t)uy0 | ((uint32_t)uy1 << 16), 0u, 0u);
             }
     }
 }

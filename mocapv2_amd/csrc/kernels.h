@@ -48,10 +48,10 @@ struct BoxArgs {
     int cam_mod, n_images, n_steps;
     int thr_mul;
     int rows_per_chunk, n_strips, n_chunks;
-    uint32_t* tile_rows;        // [n_images][n_chunks][n_strips][2][4]: the scan's boxes of this batch, one per HALF tile (120 columns):
-                                //   first / last row, first / last column; (0xffffffff, 0) = none; read-only for settle
+    uint32_t* tile_rows;        // [n_images][n_chunks][n_strips][4]: the scan's boxes of this batch (first / last row, first / last
+                                //   column; (0xffffffff, 0) = none), read-only for settle
     uint32_t* tile_rows_next;   // the same array for the next batch (the two alternate): emptied by settle
-    int halves;                 // 1 = a tile that is wide only because its halves hold separate boxes gets items per half (A/B switch)
+    int cluster;                // 1 = a box spanning tiles that all hold it becomes one item (A/B switch)
     uint32_t* cur_box;          // [n_images][n_chunks][n_strips][4]: words 0-1 the tile's output region of this batch
                                 //   (x0 | x1 << 16, y0 | y1 << 16; x0 > x1 = none) = what the mask may hold there; words 2-3 the
                                 //   scan's box (not clipped to the tile)
@@ -128,7 +128,7 @@ struct BrightArgs {
                                   //   _corner for cells feeding windows the image border cuts in one axis / in both
     const uint2* reach;           // [cam_mod][cells]: box of the output pixels that read the 8x8 source cell, x0 | x1 << 16, y0 | y1 << 16
     const uint8_t* cflags;        // [cam_mod][cells]: 1 / 2 = the cell feeds windows the image border cuts in one axis / in both
-    uint32_t* tile_rows; int n_chunks, n_strips; uint32_t rows_magic; // boxes per half tile (BoxArgs::tile_rows); n_strips = HALF tiles per row;
+    uint32_t* tile_rows; int n_chunks, n_strips; uint32_t rows_magic; // reachable mask rows / columns per tile, see FilterArgs;
                                   //   rows_magic = ceil(2^23 / rows per chunk)
     uint32_t* mask; size_t mask_words; int mask_aligned16; // caller-owned bit masks to clear on the side (mask_words = 0: none)
     // probe (optional): on every 16th image also count the cells that are hot under the current base and under the alternative

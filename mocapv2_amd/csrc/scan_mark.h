@@ -37,8 +37,7 @@ __device__ __forceinline__ void mark_hot_cell(const BrightArgs& a, const uint2* 
             const int ya = y0 - 4 > 0 ? y0 - 4 : 0, yb = y1 + 4 < a.H - 1 ? y1 + 4 : a.H - 1;
             // floor(v / d) = (v * ceil(2^23 / d)) >> 23 for v < 32768 and d >= 8: no integer division in this kernel
             const int ch0 = (int)(((uint32_t)ya * a.rows_magic) >> 23), ch1 = (int)(((uint32_t)yb * a.rows_magic) >> 23);
-            // columns of boxes: HALF tiles of 120 pixels (a.n_strips counts those); floor(v / 120) = (v * ceil(2^23 / 120)) >> 23 for v < 74898
-            const int st0 = (int)(((uint32_t)xa * 69906u) >> 23), st1 = (int)(((uint32_t)xb * 69906u) >> 23);
+            const int st0 = (int)(((uint32_t)xa * 34953u) >> 23), st1 = (int)(((uint32_t)xb * 34953u) >> 23);
             for (int ch = ch0; ch <= ch1; ch++)
                 for (int st = st0; st <= st1; st++) {
                     const int t = ch * a.n_strips + st;
