@@ -7,8 +7,9 @@
 //
 // Two kernels per batch, behind the scan:
 //   settle_tiles_kernel  one thread per (tile, image): turns the box the scan left on the tile (reachable mask rows and
-//                        columns) into work items of a bounded size in ONE global list, clears what the previous batch
-//                        left in the mask where this batch will not write, resets the scan's box for the next batch;
+//                        columns) into work items of a bounded size in ONE global list -- or, a wide box, into an entry of the
+//                        wide-tile list that the sliding row pipeline of blob_filter.hip works through --, clears what the
+//                        previous batch left in the mask where this batch will not write, empties the next batch's boxes;
 //   box_filter_kernel    a fixed grid of single-wave workgroups consumes the list.  One wave owns one item and keeps
 //                        everything in LDS: the source pixels its undistortion reads (staged with coalesced row loads,
 //                        zero border = cv::remap's BORDER_CONSTANT), the horizontal 5-sums of the undistorted patch, the
@@ -16,7 +17,8 @@
 //                        compactly -- a 72-pixel-wide box keeps 60 of 64 lanes busy with three rows per instruction --
 //                        and horizontal neighbours come from DPP wave shifts.  The undistort table is one 4-byte word per
 //                        pixel (11-bit displacements, 5-bit fractions), read with one 16-byte load per quad.
-// No workgroup barrier anywhere: a wave never waits for another one, the list balances the load.
+// No workgroup barrier anywhere: a wave never waits for another one; items are taken from the list dynamically (one atomic
+// per item on one of 8 per-XCD run heads), so waves with expensive items simply take fewer.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(64) void box_filter_kernel(BoxArgs a)
         const int qc = q < eq0 ? eq0 : (q > eq1 ? eq1 : q);
         const int xc = imax(px0 + 4 * qc, 0); // column of a quad of the exact region (loads of other lanes go there and are discarded)
         const uint8_t* __restrict__ img = a_src + (size_t)image * a_image_stride;
-        const int ntrip_a = (PR + rpw - 1) / rpw, ngroup_a = (ntrip_a + BOX_GROUP - 1) / BOX_GROUP;
+        const int ntrip_a = (PR + rpw - 1) / rpw;
         __syncthreads(); // (single wave) the previous item's LDS reads are done
         tick(0);
 
