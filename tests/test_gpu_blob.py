@@ -375,6 +375,66 @@ def test_early_out_fuzz_thresholds_and_brightness(torch_cuda, seed):
             assert cnt[i] == len(pts) and xy[i, :cnt[i]].tolist() == pts, (seed, b, i)
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MOCAP_FUZZ_LARGE_SEEDS", "6"))))
+def test_box_items_fuzz_large_frames(torch_cuda, seed):
+    """Full-size frames aimed at the work list of the sparse filter: discs of 3..70 px radius (boxes split into parts,
+    boxes too wide for an item -> the row pipeline), rings, discs centred on tile corners (x = 240 k, y = 68 k: the 2x2
+    tile clusters) and on the image border, three cameras with different lens tables in one time-major batch, two
+    batches per context (the on-demand clearing of the previous batch's boxes).  Mask and centroids = the oracle's."""
+    from gpu_util import unpack_mask
+    torch = torch_cuda
+    from mocapv2_amd.engine import MocapContext
+    rng = np.random.default_rng(31000 + seed)
+    W, H = [(1920, 1080), (1280, 720), (1924, 1082)][seed % 3]
+    C = 3
+    scales = [float(rng.choice([0.0, 1.0, 2.5, -2.0])) for _ in range(C)]
+    sc = Scene(1, width=W, height=H)
+    ctx = MocapContext(W, H, n_slots=C)
+    ident = [ctx.set_undistort(c, sc.K, np.array(MILD_DIST) * scales[c]) for c in range(C)]
+    yy, xx = np.mgrid[0:H, 0:W]
+    seen = 0
+    for b in range(2):
+        frames = rng.integers(0, 61, (2 * C, H, W), dtype=np.uint8)
+        for i in range(2 * C):
+            for _ in range(int(rng.integers(1, 9))):
+                kind = rng.random()
+                r = float(rng.uniform(3, 24)) if kind < 0.6 else float(rng.uniform(24, 70))
+                where = rng.random()
+                if where < 0.35:   # on a tile corner (+- a few pixels)
+                    cx = 240.0 * int(rng.integers(1, max(2, W // 240))) + rng.uniform(-6, 6)
+                    cy = 68.0 * int(rng.integers(1, max(2, H // 68))) + rng.uniform(-6, 6)
+                elif where < 0.5:  # on the image border
+                    cx, cy = (float(rng.choice([0, W - 1])), rng.uniform(0, H)) if rng.random() < 0.5 else (rng.uniform(0, W), float(rng.choice([0, H - 1])))
+                else:
+                    cx, cy = rng.uniform(0, W), rng.uniform(0, H)
+                x0, x1 = max(0, int(cx - r - 3)), min(W, int(cx + r + 4))
+                y0, y1 = max(0, int(cy - r - 3)), min(H, int(cy + r + 4))
+                if x0 >= x1 or y0 >= y1:
+                    continue
+                d = np.sqrt((xx[y0:y1, x0:x1] - cx) ** 2 + (yy[y0:y1, x0:x1] - cy) ** 2)
+                disc = (np.clip((r + 0.75 - d) / 1.5, 0, 1) * 255).astype(np.uint8)
+                if rng.random() < 0.25:  # a ring: hole borders
+                    disc[d < 0.5 * r] = 0
+                frames[i, y0:y1, x0:x1] = np.maximum(frames[i, y0:y1, x0:x1], disc)
+            k = int(rng.choice([0, 200, 2000]))
+            frames[i, rng.integers(0, H, k), rng.integers(0, W, k)] = 255
+        d = torch.from_numpy(frames).cuda()
+        got, pad = unpack_mask(ctx.filter_mask(d, cam_mod=C), W)
+        assert not pad.any()
+        xy, cnt = ctx.record_views(ctx.blob_centroids(d, cam_mod=C))
+        xy, cnt = xy.cpu().numpy(), cnt.cpu().numpy()
+        for i in range(2 * C):
+            c = i % C
+            dist = np.array(MILD_DIST) * scales[c]
+            und = frames[i] if ident[c] else oracle.undistort(frames[i], sc.K, dist)
+            exp = oracle.image_filter(und, 0) != 0
+            assert np.array_equal(got[i], exp), (seed, b, i, scales[c], np.argwhere(got[i] != exp)[:4])
+            pts = oracle.find_dot(frames[i], sc.K, dist)
+            assert cnt[i] == len(pts) and xy[i, :cnt[i]].tolist() == pts, (seed, b, i)
+            seen += len(pts)
+    assert seen > 0
+
+
 @pytest.mark.parametrize("W,H", [(16000, 48), (40, 5000), (4096, 72)])
 def test_extreme_aspect_ratios(torch_cuda, W, H):
     """More than 64 strips per chunk (lane-parallel tile test in two rounds), many chunk groups, patches per tile."""
