@@ -166,9 +166,15 @@ class BatchTracker:
                     on_gpu = dist.get_backend(self.group) == "nccl"
                     box = torch.zeros(_abi.COMM_ID_BYTES, dtype=torch.uint8, device=dev if on_gpu else "cpu")
                     if self.rank == 0:
-                        box.copy_(torch.frombuffer(bytearray(comm_unique_id()), dtype=torch.uint8))
+                        try:
+                            box.copy_(torch.frombuffer(bytearray(comm_unique_id()), dtype=torch.uint8))
+                        except Exception as e:  # noqa: BLE001 -- the broadcast below still runs (every rank is waiting in it) and carries zeros
+                            import sys
+                            print(f"[mocapv2_amd] rank 0: mocap_comm_unique_id failed ({e})", file=sys.stderr)
                     dist.broadcast(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
                     uid = bytes(box.cpu().numpy().tobytes())
+                    if not any(uid):
+                        raise RuntimeError("rank 0 could not create a communicator id")
                 lane.ctx.comm_init(uid, self.rank, self.world)
                 lane.gathered = torch.empty((self.world * self.per, self.rec_ints), dtype=torch.int32, device=dev)
             except Exception as e:  # noqa: BLE001 -- e.g. librccl not loadable: say so, and let every rank take the same road
