@@ -67,6 +67,7 @@ struct mocap_ctx {
     int base_sel; int probe_age; bool probe_pending; uint32_t* probe_dev; uint32_t* probe_host; hipEvent_t probe_ev;
     uint32_t* cells_ext; uint32_t* cur_box_ext; size_t cells_ext_images; // the same for caller-owned masks (mocap_filter_mask)
     void* cwork; size_t cwork_images;      // contour kernel workspace, contour_work_bytes() per image
+    uint32_t* walk_list; uint32_t* walk_count; // contour stage, split form: the batch's border walks (grown with cwork) and their number
     CameraTable* cams; int n_cam, n_F;
     double* scratch; size_t scratch_elems;
     void* comm; int comm_rank, comm_world; // RCCL communicator of mocap_comm_init (ncclComm_t), else null
@@ -155,7 +156,7 @@ int mocap_ctx_create(int device_id, int width, int height, int n_slots, mocap_ct
     c->maps = nullptr; c->map4 = nullptr; c->srcbox = nullptr; c->reach = nullptr; c->cflags = nullptr; c->map_flags = nullptr;
     c->mask = nullptr; c->mask_images = 0; c->mask_dirty = false; c->cells = nullptr; c->cells_images = 0; c->last_images = 0;
     c->tile_rows = nullptr; c->tile_rows_flip = 0; c->cur_box = nullptr; c->items = nullptr; c->n_items = nullptr; c->cap_items = 0; c->wide_tiles = nullptr; c->cap_wide = 0;
-    c->cells_ext = nullptr; c->cur_box_ext = nullptr; c->cells_ext_images = 0; c->cwork = nullptr; c->cwork_images = 0;
+    c->cells_ext = nullptr; c->cur_box_ext = nullptr; c->cells_ext_images = 0; c->cwork = nullptr; c->cwork_images = 0; c->walk_list = nullptr; c->walk_count = nullptr;
     c->cams = nullptr; c->n_cam = 0; c->n_F = 0; c->scratch = nullptr; c->scratch_elems = 0; c->profiling = false;
     c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1;
     c->side = nullptr; c->ev_fork = nullptr; c->ev_join = nullptr;
@@ -219,6 +220,8 @@ int mocap_ctx_destroy(mocap_ctx_t c)
     if (c->cells) (void)hipFree(c->cells);
     if (c->tile_rows) (void)hipFree(c->tile_rows);
     if (c->cwork) (void)hipFree(c->cwork);
+    if (c->walk_list) (void)hipFree(c->walk_list);
+    if (c->walk_count) (void)hipFree(c->walk_count);
     if (c->cams) (void)hipFree(c->cams);
     if (c->scratch) (void)hipFree(c->scratch);
     delete c;
@@ -667,7 +670,15 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
     return 0;
 }
 
-static int run_contours(mocap_ctx* c, const uint32_t* mask, const uint32_t* cells, int n_images, int32_t* out_xy, long xy_stride,
+// the tiles' output regions / scan boxes of the batch just filtered into the context's mask (settle_tiles_kernel), when the
+// sparse path ran (the general dense kernel keeps none); MOCAP_CONTOUR_BOXES=0: whole strips (A/B switch, same results)
+static const uint32_t* contour_boxes(mocap_ctx* c)
+{
+    static const bool off = getenv("MOCAP_CONTOUR_BOXES") && atoi(getenv("MOCAP_CONTOUR_BOXES")) == 0;
+    return (c->mask_dirty || off) ? nullptr : c->cur_box;
+}
+
+static int run_contours(mocap_ctx* c, const uint32_t* mask, const uint32_t* cells, const uint32_t* boxes, int n_images, int32_t* out_xy, long xy_stride,
                         int32_t* out_count, long count_stride, int max_blobs, mocap_contour* dbg, int32_t* dbg_count, int dbg_cap, hipStream_t s)
 {
     ContourArgs a;
@@ -679,15 +690,23 @@ static int run_contours(mocap_ctx* c, const uint32_t* mask, const uint32_t* cell
     long long ms = 4LL * c->H * c->W + 16;
     a.max_steps = ms > (1 << 22) ? (1 << 22) : (int)ms;
     Tiling tl = tiling(c);
-    a.cells = cells; a.rows_per_chunk = tl.rows; a.n_chunks = tl.n_cgroups * 4; a.n_strips = tl.n_strips;
-    if ((long long)a.n_chunks * a.n_strips * ((tl.rows + 7) / 8) > 65535) a.cells = nullptr; // cell ids are 16-bit in the kernel: scan every row instead
+    a.cells = cells; a.boxes = boxes; a.rows_per_chunk = tl.rows; a.n_chunks = tl.n_cgroups * 4; a.n_strips = tl.n_strips;
+    if ((long long)a.n_chunks * a.n_strips * ((tl.rows + 7) / 8) > 65535 || c->wpr > 4096) a.cells = nullptr; // cell ids are 16-bit, first words 12-bit in the kernel: scan every row instead
     if ((size_t)n_images > c->cwork_images) {
         std::lock_guard<std::mutex> lk(c->mu);
         if (c->cwork) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c->cwork)); c->cwork = nullptr; c->cwork_images = 0; }
+        if (c->walk_list) { HIP_TRY(hipFree(c->walk_list)); c->walk_list = nullptr; }
         HIP_TRY(hipMalloc(&c->cwork, contour_work_bytes() * (size_t)n_images));
+        HIP_TRY(hipMalloc(&c->walk_list, contour_walk_bytes() * (size_t)n_images));
+        if (!c->walk_count) HIP_TRY(hipMalloc(&c->walk_count, 256));
         c->cwork_images = n_images;
     }
     a.work = c->cwork;
+    // The split form (candidates per image -> all walks of the batch, 64 to a wave -> tree per image) is the default;
+    // MOCAP_CONTOURS_SPLIT=0 runs the one-kernel-per-image form (A/B switch; same results).
+    static const bool split = !(getenv("MOCAP_CONTOURS_SPLIT") && atoi(getenv("MOCAP_CONTOURS_SPLIT")) == 0);
+    a.walk_list = split ? c->walk_list : nullptr; a.walk_count = c->walk_count;
+    a.follow_grid = c->box_grid / 2 > 0 ? c->box_grid / 2 : 1; // 4 one-wave workgroups per CU (33 KB of LDS each)
     a.prio = 0;
     { const char* e = getenv("MOCAP_CONTOUR_PRIO"); if (e) a.prio = atoi(e); } // A/B switch (no effect measured)
     a.timing = nullptr;
@@ -798,7 +817,7 @@ int mocap_contours_from_mask(mocap_ctx_t c, const uint32_t* mask_dev, int n_imag
         return fail(MOCAP_E_INVALID, "n_images=%d max_blobs=%d strides %ld %ld", n_images, max_blobs, xy_stride, count_stride);
     if ((dbg != nullptr) != (dbg_count != nullptr) || (dbg && dbg_cap < 1)) return fail(MOCAP_E_INVALID, "inconsistent debug buffers");
     if (set_device(c)) return MOCAP_E_HIP;
-    return run_contours(c, mask_dev, nullptr, n_images, out_xy, xy_stride, out_count, count_stride, max_blobs, dbg, dbg_count, dbg_cap,
+    return run_contours(c, mask_dev, nullptr, nullptr, n_images, out_xy, xy_stride, out_count, count_stride, max_blobs, dbg, dbg_count, dbg_cap,
                         (hipStream_t)stream);
 }
 
@@ -813,7 +832,7 @@ int mocap_blob_centroids(mocap_ctx_t c, const void* frames, int n_images, int ca
     if (set_device(c)) return MOCAP_E_HIP;
     if ((rc = ensure_mask(c, n_images))) return rc;
     if ((rc = run_filter(c, frames, n_images, cam_mod, slot_base, image_stride, pitch, c->mask, c->cells, (hipStream_t)stream))) return rc;
-    return run_contours(c, c->mask, c->cells, n_images, out_xy, xy_stride, out_count, count_stride, max_blobs, nullptr, nullptr, 0,
+    return run_contours(c, c->mask, c->cells, contour_boxes(c), n_images, out_xy, xy_stride, out_count, count_stride, max_blobs, nullptr, nullptr, 0,
                         (hipStream_t)stream);
 }
 
@@ -835,7 +854,7 @@ int mocap_blob_centroids_bayer(mocap_ctx_t c, const void* bayer_frames, void* gr
     if ((rc = ensure_mask(c, n_images))) return rc;
     if ((rc = run_filter(c, gray_frames, n_images, cam_mod, slot_base, image_stride, pitch, c->mask, c->cells, (hipStream_t)stream, &b)))
         return rc;
-    return run_contours(c, c->mask, c->cells, n_images, out_xy, xy_stride, out_count, count_stride, max_blobs, nullptr, nullptr, 0,
+    return run_contours(c, c->mask, c->cells, contour_boxes(c), n_images, out_xy, xy_stride, out_count, count_stride, max_blobs, nullptr, nullptr, 0,
                         (hipStream_t)stream);
 }
 

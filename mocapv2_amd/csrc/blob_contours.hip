@@ -39,6 +39,9 @@ constexpr int MAXD = 8;     // nesting depth of a kept contour
 constexpr int MAXCELL = 4096; // occupancy cells (strip x 8 rows) scanned per image
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// lane L receives lane L - 1's / L + 1's value (0 at the ends of the wave and from lanes that are switched off)
+__device__ __forceinline__ uint32_t lane_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /*wave_shr:1*/, 0xf, 0xf, true); }
+__device__ __forceinline__ uint32_t lane_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /*wave_shl:1*/, 0xf, 0xf, true); }
 
 struct Mask {
     const uint32_t* w;
@@ -107,6 +110,9 @@ __device__ __forceinline__ double run_length(int s, int k)
 // double sum is exact in any order.
 // `win` (optional): 64 rows of the mask from row sy - 1 down, columns sx - 31 .. sx + 32, staged in LDS by the caller;
 // rows are taken from there while the walk stays inside that window's columns.
+// WS: distance (in 64-bit words) between consecutive rows of `win` (1: a window of its own; 64: row-major over the 64 windows
+// of a wave, so that the lanes' reads fall into different LDS banks).
+template <int WS = 1>
 __device__ __forceinline__ void follow(const Mask& M, int sx, int sy, int first, int abort_fg, int abort_ebg, int max_steps,
                                        Trace& T, const double* diag_len, const uint64_t* win = nullptr)
 {
@@ -123,7 +129,7 @@ __device__ __forceinline__ void follow(const Mask& M, int sx, int sy, int first,
     bool staged = win != nullptr; // the LDS window still matches x0
     auto fetch = [&](int yy) -> uint64_t {
         const unsigned r = (unsigned)(yy - wy0);
-        if (staged && r < 64u) return win[r];
+        if (staged && r < 64u) return win[r * WS];
         return row64(M, yy, x0);
     };
     uint64_t rU = fetch(y - 1), rM = fetch(y), rD = fetch(y + 1);
@@ -267,8 +273,22 @@ constexpr int NWIN = 16; // candidates per image whose mask window is staged in 
 struct ContourWork {
     ContourRec recs[MAXR];
     int32_t kept_path[MAXK][MAXD];
+    // hand-over between the three kernels of the split form (candidates -> follow -> order)
+    int32_t st_ncand;        // candidates of the image, or -1: the candidates kernel reported an error for it
+    int32_t st_nrec;         // borders recorded by the follow kernel (atomic)
+    int32_t st_err;          // follow kernel: 1 = a walk ran into the step limit
+    int32_t st_pad;
+    uint32_t cand[MAXC];
+    int32_t rkey[MAXR];
+    int16_t rsx[MAXR], rsy[MAXR];
+    int16_t rbox[MAXR][4];
+    uint8_t rhole[MAXR], rkept[MAXR];
 };
 
+// MODE 0: the whole job for one image (candidates, walks, tree).  MODE 1 / MODE 2: the first and the last part of the split
+// form -- candidates only (handed to contour_follow_kernel through the workspace and the batch-wide walk list) / tree only
+// (from the records that kernel left).
+template <int MODE>
 __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
 {
     __shared__ uint32_t cand[MAXC];
@@ -282,6 +302,8 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
     __shared__ double diag_len[64]; // float32 length of a diagonal run of k steps, as a double
     __shared__ uint64_t win[NWIN][64]; // mask windows of the first NWIN candidates (see follow)
     uint16_t* const cell_list = (uint16_t*)scratch;
+    uint16_t* const cell_rng = (uint16_t*)win;   // phase A only: first word | words << 12 of each listed cell's column range
+    static_assert(sizeof(uint64_t) * NWIN * 64 >= MAXCELL * 2, "cell ranges overlay the windows");
     int16_t (*const rbox)[4] = (int16_t (*)[4])scratch;          // bounding box of each border: x0, y0, x1, y1
     int16_t* const kept_idx = (int16_t*)(scratch + MAXR * 8);
     int8_t* const kept_depth = (int8_t*)(scratch + MAXR * 8 + MAXK * 2);
@@ -302,8 +324,26 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
     auto stamp = [&](int i) { if (tick && tid == 0) tick[i] = wall_clock64(); };
     stamp(0);
     __syncthreads();
+    if constexpr (MODE == 2) {
+        // the records of the follow kernel: counts, then the small per-border fields into LDS
+        if (work.st_ncand < 0) return; // the candidates kernel has reported this image's error
+        if (tid == 0) { nrec = work.st_nrec; err = work.st_err; }
+        __syncthreads();
+        if (nrec > MAXR || err) {
+            if (tid == 0) { *out_count = err ? BLOB_ERR_STEPS : BLOB_ERR_CONTOURS; if (a.dbg_count) a.dbg_count[image] = 0; }
+            return;
+        }
+        for (int c = tid; c < nrec; c += NTHREADS) {
+            rkey[c] = work.rkey[c]; rsx[c] = work.rsx[c]; rsy[c] = work.rsy[c];
+            rhole[c] = work.rhole[c]; rkept[c] = work.rkept[c];
+            rlink[c] = -1; rparent[c] = -1;
+            rbox[c][0] = work.rbox[c][0]; rbox[c][1] = work.rbox[c][1]; rbox[c][2] = work.rbox[c][2]; rbox[c][3] = work.rbox[c][3];
+        }
+        __syncthreads();
+    }
 
     // ---- phase A: candidate starts -------------------------------------------------------------------------------
+    if constexpr (MODE != 2) {
     // A border can only start where the mask has set pixels.  The filter kernel leaves an occupancy word per
     // (strip, chunk): bit g = rows 8g..8g+7 of the chunk contain set pixels in that 240-column strip.  Occupied
     // cells, plus their right and lower neighbours (a hole can start in an empty cell whose W / N neighbour pixel
@@ -313,6 +353,8 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
         const int R = a.rows_per_chunk, NS = a.n_strips, NCH = a.n_chunks;
         const int gpc = (R + 7) >> 3;                       // 8-row groups per chunk
         const uint32_t* cells = a.cells ? a.cells + (size_t)image * NCH * NS : nullptr;
+        const uint32_t* boxes = (a.cells && a.boxes) ? a.boxes + (size_t)image * NCH * NS * 4 : nullptr;
+        const bool ranged = cells != nullptr; // cell_rng holds the words to examine (the whole strip without boxes)
         const int n_cells = NCH * NS * gpc;
         if (cells) {
             // one task = one (chunk, strip) occupancy word: its own groups, and the groups its right and lower
@@ -323,92 +365,158 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
                 const uint32_t own = cells[t] & 0x7fffffffu;
                 const uint32_t left = st > 0 ? cells[t - 1] & 0x7fffffffu : 0u;
                 const uint32_t up = ch > 0 ? cells[t - NS] & 0x7fffffffu : 0u;
-                uint32_t scan = own | left | (own << 1) | ((up >> (gpc - 1)) & 1u);
+                const uint32_t upbit = (up >> (gpc - 1)) & 1u;
+                uint32_t scan = own | left | (own << 1) | upbit;
                 scan &= (1u << gpc) - 1u;
+                if (!scan) continue;
+                // columns that can hold set pixels: the tile's output region and the scan's box (settle, BoxArgs::cur_box);
+                // a hole start lies at most one column right of them
+                const int xa = 240 * st, xb = xa + 240 < a.W ? xa + 240 : a.W;
+                int ox0 = xa, ox1 = xb - 1, ux0 = xa, ux1 = xb - 1;
+                if (boxes) {
+                    const uint4 ob = *(const uint4*)(boxes + 4 * (size_t)t);
+                    const int r0 = (int)(ob.x & 0xffffu), r1 = (int)(ob.x >> 16), b0 = (int)(ob.z & 0xffffu) & ~7, b1 = (int)(ob.z >> 16) | 7;
+                    if (r0 <= r1) { ox0 = r0 > b0 ? r0 : b0; ox1 = (r1 < b1 ? r1 : b1) + 1; }
+                    if (upbit) {
+                        const uint4 ub = *(const uint4*)(boxes + 4 * (size_t)(t - NS));
+                        const int u0 = (int)(ub.x & 0xffffu), u1 = (int)(ub.x >> 16), c0 = (int)(ub.z & 0xffffu) & ~7, c1 = (int)(ub.z >> 16) | 7;
+                        if (u0 <= u1) { ux0 = u0 > c0 ? u0 : c0; ux1 = (u1 < c1 ? u1 : c1) + 1; }
+                    }
+                    ox0 = ox0 < xa ? xa : ox0; ox1 = ox1 > xb - 1 ? xb - 1 : ox1;
+                    ux0 = ux0 < xa ? xa : ux0; ux1 = ux1 > xb - 1 ? xb - 1 : ux1;
+                    if (ox0 > ox1) { ox0 = xa; ox1 = xb - 1; }
+                    if (ux0 > ux1) { ux0 = xa; ux1 = xb - 1; }
+                }
+                const uint32_t ownish = own | (own << 1);
                 while (scan) {
                     const int g = __ffs((int)scan) - 1;
                     scan &= scan - 1;
                     if (ch * R + 8 * g >= a.H || 8 * g >= R) continue;
                     const int slot = atomicAdd(&ncell, 1);
-                    if (slot < MAXCELL) cell_list[slot] = (uint16_t)((ch * NS + st) * gpc + g);
+                    if (slot >= MAXCELL) continue;
+                    cell_list[slot] = (uint16_t)((ch * NS + st) * gpc + g);
+                    int c0 = 0x7fffffff, c1 = -1;
+                    if ((ownish >> g) & 1u) { c0 = ox0; c1 = ox1; }
+                    if ((left >> g) & 1u) { c0 = c0 < xa ? c0 : xa; c1 = c1 > xa ? c1 : xa; }
+                    if (g == 0 && upbit) { c0 = c0 < ux0 ? c0 : ux0; c1 = c1 > ux1 ? c1 : ux1; }
+                    const int k0 = c0 >> 5, k1 = c1 >> 5;
+                    cell_rng[slot] = (uint16_t)(k0 | ((k1 - k0 + 1) << 12)); // k0 < 4096 (checked on the host), at most 10 words
                 }
             }
             __syncthreads();
             if (ncell > MAXCELL && tid == 0) atomicMax(&err, 4);
         }
         const int ncl = cells ? (ncell < MAXCELL ? ncell : MAXCELL) : n_cells;
-        // one task = one row of one cell: the (up to 9) mask words covering the strip's 240 columns
-        for (int t = tid; t < ncl * 8; t += NTHREADS) {
-            int cell = cells ? (int)cell_list[t >> 3] : (t >> 3), j = t & 7;
-            int g = cell % gpc, st = (cell / gpc) % NS, ch = cell / (gpc * NS);
-            int y = ch * R + 8 * g + j;
-            int yend = (ch + 1) * R < a.H ? (ch + 1) * R : a.H;
-            if (y >= yend || 8 * g + j >= R) continue;
-            const int xa = 240 * st, xb = xa + 240 < a.W ? xa + 240 : a.W; // columns [xa, xb)
+        // One task = one cell, taken by a group of 8 lanes: lane i of the group holds word kf - 1 + i of a row (kf = first
+        // word of the cell's column range, see above) and of the row above it, so a wave's loads cover 8 rows x 32 contiguous
+        // bytes; lanes 1..6 test their word with the neighbours' words from lanes i - 1 / i + 1 (DPP), ranges longer than 6
+        // words take further passes.  The 16 loads of a cell's 8 rows are in flight together.
+        const int sub = tid & 7, grp8 = tid >> 3;
+        for (int ci0 = 0; ci0 < ncl; ci0 += NTHREADS / 8) {
+            const int ci = ci0 + grp8;
+            const bool cv = ci < ncl;
+            const int cell = cv ? (cells ? (int)cell_list[ci] : ci) : 0;
+            const int g = cell % gpc, st = (cell / gpc) % NS, ch = cell / (gpc * NS);
+            const int y0 = ch * R + 8 * g;
+            const int yend = (ch + 1) * R < a.H ? (ch + 1) * R : a.H;
+            const int xa = 240 * st, xb = xa + 240 < a.W ? xa + 240 : a.W; // the strip's columns [xa, xb)
             const int ka = xa >> 5, kb = (xb - 1) >> 5;
-            // words are requested three iterations before they are needed (a dependent L2 round trip per word otherwise)
-            uint32_t prev_w = ka > 0 ? M.word(y, ka - 1) : 0u, prev_n = ka > 0 ? M.word(y - 1, ka - 1) : 0u;
-            uint32_t cur_w = M.word(y, ka), cur_n = M.word(y - 1, ka);
-            uint32_t w1 = M.word(y, ka + 1), n1 = M.word(y - 1, ka + 1);
-            uint32_t w2 = M.word(y, ka + 2), n2 = M.word(y - 1, ka + 2);
-            uint32_t w3 = M.word(y, ka + 3), n3 = M.word(y - 1, ka + 3);
-            for (int k = ka; k <= kb; k++) {
-                const uint32_t next_w = w1, next_n = n1;
-                w1 = w2; n1 = n2; w2 = w3; n2 = n3;
-                w3 = k + 4 <= kb + 1 ? M.word(y, k + 4) : 0u; n3 = k + 4 <= kb + 1 ? M.word(y - 1, k + 4) : 0u;
-                uint32_t w = cur_w, n = cur_n;
-                uint32_t Wn = (w << 1) | (prev_w >> 31);
-                // Necessary conditions, evaluated on the 64 columns starting at this word (this word + the next):
-                // a raster-first foreground pixel starts a run none of whose pixels touches (8-connectivity) the
-                // row above; a raster-first hole pixel starts a background run none of whose pixels has
-                // background directly above (4-connectivity).  "Touches" are spread leftwards along the run for 12
-                // columns; beyond that the candidate is merely kept -- the follow step decides.
-                uint64_t w64 = (uint64_t)w | ((uint64_t)next_w << 32), n64 = (uint64_t)n | ((uint64_t)next_n << 32);
-                uint64_t above64 = n64 | (n64 << 1) | (uint64_t)(prev_n >> 31) | (n64 >> 1); // NE of column 63 unknown: treated as clear
-                uint32_t outer = w & ~Wn & ~(uint32_t)above64;
-                if (outer) {
-                    uint64_t touch = w64 & above64;
+            int kf = ka, cnt = kb - ka + 1;
+            if (ranged && cv) { const uint32_t rg = cell_rng[ci]; kf = (int)(rg & 0xfffu); cnt = (int)(rg >> 12); }
+            if (!cv) cnt = 0;
+            for (int p0 = 0; p0 < cnt; p0 += 6) {
+                const int k = kf - 1 + p0 + sub;
+                const bool tests = sub >= 1 && sub <= 6 && k < kf + cnt && k >= ka && k <= kb;
+                for (int jh = 0; jh < 8; jh += 4) { // four rows at a time: their 8 loads are in flight together
+                uint32_t wr[4], nr_[4];
 #pragma unroll
-                    for (int i = 0; i < 12; i++) touch |= (touch >> 1) & w64;
-                    outer &= ~(uint32_t)touch;
+                for (int j = 0; j < 4; j++) {
+                    const int y = y0 + jh + j;
+                    const bool rowv = y < yend && 8 * g + jh + j < R;
+                    wr[j] = rowv ? M.word(y, k) : 0u;
+                    nr_[j] = rowv ? M.word(y - 1, k) : 0u;
                 }
-                uint32_t hole = ~w & Wn & n;
-                if (hole) {
-                    uint64_t bg64 = ~w64, touch = bg64 & ~n64;
+                // the neighbours' words, exchanged while every lane of the group is active (before any lane-divergent code)
+                uint32_t pw[4], pn[4], nw[4], nn[4];
 #pragma unroll
-                    for (int i = 0; i < 12; i++) touch |= (touch >> 1) & bg64;
-                    hole &= ~(uint32_t)touch;
+                for (int j = 0; j < 4; j++) { pw[j] = lane_prev(wr[j]); pn[j] = lane_prev(nr_[j]); nw[j] = lane_next(wr[j]); nn[j] = lane_next(nr_[j]); }
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) {
+                    const int j = jh + jj;
+                    const int y = y0 + j;
+                    const uint32_t w = wr[jj], n = nr_[jj];
+                    const uint32_t prev_w = pw[jj], prev_n = pn[jj], next_w = nw[jj], next_n = nn[jj];
+                    if (!tests || !(y < yend && 8 * g + j < R)) continue;
+                    const uint32_t Wn = (w << 1) | (prev_w >> 31);
+                    // Necessary conditions, evaluated on the 64 columns starting at this word (this word + the next):
+                    // a raster-first foreground pixel starts a run none of whose pixels touches (8-connectivity) the
+                    // row above; a raster-first hole pixel starts a background run none of whose pixels has
+                    // background directly above (4-connectivity).  "Touches" are spread leftwards along the run for 12
+                    // columns; beyond that the candidate is merely kept -- the follow step decides.
+                    const uint64_t w64 = (uint64_t)w | ((uint64_t)next_w << 32), n64 = (uint64_t)n | ((uint64_t)next_n << 32);
+                    const uint64_t above64 = n64 | (n64 << 1) | (uint64_t)(prev_n >> 31) | (n64 >> 1); // NE of column 63 unknown: treated as clear
+                    uint32_t outer = w & ~Wn & ~(uint32_t)above64;
+                    if (outer) {
+                        uint64_t touch = w64 & above64;
+#pragma unroll
+                        for (int i = 0; i < 12; i++) touch |= (touch >> 1) & w64;
+                        outer &= ~(uint32_t)touch;
+                    }
+                    uint32_t hole = ~w & Wn & n;
+                    if (hole) {
+                        uint64_t bg64 = ~w64, touch = bg64 & ~n64;
+#pragma unroll
+                        for (int i = 0; i < 12; i++) touch |= (touch >> 1) & bg64;
+                        hole &= ~(uint32_t)touch;
+                    }
+                    // keep only this strip's columns (and, for holes, columns inside the image)
+                    const int lo = xa - 32 * k, hi = xb - 32 * k; // bit range [lo, hi)
+                    uint32_t m = 0xffffffffu;
+                    if (lo > 0) m &= ~((1u << lo) - 1u);
+                    if (hi < 32) m &= (1u << hi) - 1u;
+                    outer &= m; hole &= m;
+                    while (outer) {
+                        const int b = __ffs((int)outer) - 1;
+                        outer &= outer - 1;
+                        const int slot = atomicAdd(&ncand, 1);
+                        if (slot < MAXC) cand[slot] = (uint32_t)(32 * k + b) | ((uint32_t)y << 16);
+                    }
+                    while (hole) {
+                        const int b = __ffs((int)hole) - 1;
+                        hole &= hole - 1;
+                        const int slot = atomicAdd(&ncand, 1);
+                        if (slot < MAXC) cand[slot] = (uint32_t)(32 * k + b) | ((uint32_t)y << 16) | 0x8000u;
+                    }
                 }
-                // keep only this cell's columns (and, for holes, columns inside the image)
-                int lo = xa - 32 * k, hi = xb - 32 * k; // bit range [lo, hi)
-                uint32_t m = 0xffffffffu;
-                if (lo > 0) m &= ~((1u << lo) - 1u);
-                if (hi < 32) m &= (1u << hi) - 1u;
-                outer &= m; hole &= m;
-                while (outer) {
-                    int b = __ffs((int)outer) - 1;
-                    outer &= outer - 1;
-                    int slot = atomicAdd(&ncand, 1);
-                    if (slot < MAXC) cand[slot] = (uint32_t)(32 * k + b) | ((uint32_t)y << 16);
                 }
-                while (hole) {
-                    int b = __ffs((int)hole) - 1;
-                    hole &= hole - 1;
-                    int slot = atomicAdd(&ncand, 1);
-                    if (slot < MAXC) cand[slot] = (uint32_t)(32 * k + b) | ((uint32_t)y << 16) | 0x8000u;
-                }
-                prev_w = cur_w; prev_n = cur_n; cur_w = next_w; cur_n = next_n;
             }
         }
     }
     __syncthreads();
     stamp(1);
     if (ncand > MAXC || err) {
-        if (tid == 0) { *out_count = BLOB_ERR_CANDIDATES; if (a.dbg_count) a.dbg_count[image] = 0; }
+        if (tid == 0) { *out_count = BLOB_ERR_CANDIDATES; if (a.dbg_count) a.dbg_count[image] = 0; if (MODE == 1) work.st_ncand = -1; }
+        return;
+    }
+    }
+    if constexpr (MODE == 1) {
+        // hand the candidates over: into the image's workspace, and one entry each (image << 10 | index) into the batch's walk list
+        __shared__ uint32_t wbase;
+        const int nc1 = ncand;
+        if (tid == 0) {
+            work.st_ncand = nc1; work.st_nrec = 0; work.st_err = 0;
+            wbase = nc1 ? atomicAdd(a.walk_count, (uint32_t)nc1) : 0u;
+        }
+        __syncthreads();
+        for (int c = tid; c < nc1; c += NTHREADS) {
+            work.cand[c] = cand[c];
+            a.walk_list[wbase + (uint32_t)c] = ((uint32_t)image << 10) | (uint32_t)c;
+        }
         return;
     }
 
     // ---- phase B: one lane follows one candidate; the raster-first ones become records ---------------------------
+    if constexpr (MODE == 0) {
     const int nc = ncand;
     // The walks read the mask rows below each start one at a time.  For the first NWIN candidates (all of them, in a
     // typical frame) the 64 rows from the start downwards are staged in LDS first, one row per lane: one round of
@@ -454,6 +562,7 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
     if (nrec > MAXR || err) {
         if (tid == 0) { *out_count = err ? BLOB_ERR_STEPS : BLOB_ERR_CONTOURS; if (a.dbg_count) a.dbg_count[image] = 0; }
         return;
+    }
     }
 
     // ---- phase C1: link = the border that owns the crack met when scanning left from the start ------------------
@@ -579,11 +688,81 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
     }
 }
 
+// The walks of the whole batch, one lane each, 64 to a wave whatever image they belong to: an image of a sparse IR frame has
+// a handful of borders, so the per-image kernel's walking wave runs its ~150 instructions per border step for 8 busy lanes;
+// here every lane of a wave follows a border, and the batch needs 1/3 - 1/4 of the wave instructions.  One wave per
+// workgroup; a wave takes 64 consecutive entries of the walk list at a time.  The 64 mask windows (64 rows x 64 columns from
+// one row above each start) are staged in LDS first, row-major over the wave's windows (bank-conflict-free for lanes at
+// different rows).  A raster-first walk becomes a record of its image: slot by an atomic on the image's counter.
+__global__ __launch_bounds__(64) void contour_follow_kernel(ContourArgs a)
+{
+    __shared__ uint64_t win[64][64]; // [row of the window][lane = candidate of the wave]
+    __shared__ double diag_len[64];
+    const int lane = threadIdx.x;
+    diag_len[lane] = run_length(1, lane);
+    const uint32_t total = *a.walk_count;
+    ContourWork* const works = (ContourWork*)a.work;
+    const size_t image_words = (size_t)a.H * a.words_per_row;
+    for (uint32_t base = blockIdx.x * 64u; base < total; base += gridDim.x * 64u) {
+        const int n_here = uni((int)(total - base < 64u ? total - base : 64u));
+        const bool has = lane < n_here;
+        const uint32_t e = has ? a.walk_list[base + (uint32_t)lane] : a.walk_list[base];
+        const int image = (int)(e >> 10), ci = (int)(e & 1023u);
+        ContourWork& work = works[image];
+        const uint32_t v = work.cand[ci];
+        const int is_hole = (int)((v >> 15) & 1u), x = (int)(v & 0x7fffu), y = (int)(v >> 16);
+        const int sx = x - is_hole;
+        __syncthreads(); // (one wave) the previous round's window reads are done
+#pragma unroll 8
+        for (int c = 0; c < n_here; c++) {
+            const int img_c = __builtin_amdgcn_readlane(image, c), sx_c = __builtin_amdgcn_readlane(sx, c), sy_c = __builtin_amdgcn_readlane(y, c);
+            const Mask Mc{a.mask + (size_t)img_c * image_words, a.words_per_row, a.H, a.W, a.W + 1};
+            win[lane][c] = row64(Mc, sy_c - 1 + lane, sx_c - 31);
+        }
+        __syncthreads();
+        if (has) {
+            const Mask M{a.mask + (size_t)image * image_words, a.words_per_row, a.H, a.W, a.W + 1};
+            const int key = y * M.RS + x;
+            Trace T;
+            if (!is_hole) follow<64>(M, x, y, 4, key, -1, a.max_steps, T, diag_len, &win[0][lane]);
+            else follow<64>(M, x - 1, y, 0, -1, key, a.max_steps, T, diag_len, &win[0][lane]);
+            if (T.status == 2) atomicMax(&work.st_err, 1);
+            if (T.status == 0) {
+                const int slot = atomicAdd(&work.st_nrec, 1);
+                if (slot < MAXR) {
+                    ContourRec r;
+                    r.key = key; r.is_hole = is_hole;
+                    r.sx = sx; r.sy = y;
+                    r.npts = T.npts; r.steps = T.steps;
+                    r.a00 = T.a00; r.a10 = T.a10; r.a01 = T.a01;
+                    r.area = fabs((double)T.a00 * 0.5);
+                    r.perimeter = T.npts > 1 ? T.per : 0.0;
+                    r.link = -1; r.parent = -1; r.order = -1;
+                    select_contour(r, a.min_area, a.min_circ);
+                    work.recs[slot] = r;
+                    work.rkey[slot] = key; work.rsx[slot] = (int16_t)sx; work.rsy[slot] = (int16_t)y;
+                    work.rhole[slot] = (uint8_t)is_hole; work.rkept[slot] = (uint8_t)r.kept;
+                    work.rbox[slot][0] = (int16_t)T.bx0; work.rbox[slot][1] = (int16_t)T.by0;
+                    work.rbox[slot][2] = (int16_t)T.bx1; work.rbox[slot][3] = (int16_t)T.by1;
+                }
+            }
+        }
+    }
+}
+
 size_t contour_work_bytes() { return sizeof(ContourWork); }
+size_t contour_walk_bytes() { return sizeof(uint32_t) * MAXC; }
 
 void launch_contours(const ContourArgs& a, hipStream_t s)
 {
-    hipLaunchKernelGGL(contours_kernel, dim3(a.n_images), dim3(NTHREADS), 0, s, a);
+    if (a.walk_list && !a.timing && a.n_images < (1 << 22)) {
+        (void)hipMemsetAsync(a.walk_count, 0, sizeof(uint32_t), s);
+        hipLaunchKernelGGL(contours_kernel<1>, dim3(a.n_images), dim3(NTHREADS), 0, s, a);
+        hipLaunchKernelGGL(contour_follow_kernel, dim3(a.follow_grid), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(contours_kernel<2>, dim3(a.n_images), dim3(NTHREADS), 0, s, a);
+        return;
+    }
+    hipLaunchKernelGGL(contours_kernel<0>, dim3(a.n_images), dim3(NTHREADS), 0, s, a);
 }
 
 } // namespace mocap

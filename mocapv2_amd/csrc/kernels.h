@@ -108,10 +108,14 @@ struct ContourArgs {
     int dbg_cap;
     int max_steps;
     const uint32_t* cells; // occupancy written by the filter kernel (see FilterArgs), or null = scan every row
+    const uint32_t* boxes; // with cells: per tile [4] the output region and the scan's box (BoxArgs::cur_box), or null = whole strips
     int rows_per_chunk, n_chunks, n_strips;
     uint64_t* timing;      // optional [n_images][8] phase clock (debugging aid), else null
     void* work;            // [n_images] per-image workspace of contour_work_bytes() each
     int prio;              // wave priority (s_setprio 0..3): the walks are serial chains, cheap to favour and costly to delay
+    uint32_t* walk_list;   // split form: [n_images * contour_walk_bytes() / 4] entries image << 10 | candidate, or null = one kernel per image
+    uint32_t* walk_count;  // split form: number of entries (zeroed by launch_contours)
+    int follow_grid;       // split form: workgroups (waves) of the follow kernel
 };
 
 enum { BLOB_ERR_CANDIDATES = -2, BLOB_ERR_CONTOURS = -3, BLOB_ERR_STEPS = -4, BLOB_ERR_DEPTH = -5 };
@@ -148,6 +152,7 @@ void launch_remap_stats(const StatArgs& a, hipStream_t s);
 void launch_undistort_map(const MapArgs& m, hipStream_t s);
 void launch_contours(const ContourArgs& a, hipStream_t s);
 size_t contour_work_bytes();
+size_t contour_walk_bytes(); // walk list bytes per image (split form of the contour stage)
 void launch_box_blur(const uint8_t* src, uint8_t* dst, int H, int W, int sp, int dp, int ksize, hipStream_t s);
 void launch_undistort(const uint8_t* src, uint8_t* dst, int H, int W, int sp, int dp, const uint32_t* map, const uint32_t* mapw,
                       hipStream_t s);
