@@ -266,7 +266,7 @@ def roofline_of(prof, wl, n_images, n_launch_groups, traffic_key):
         # frame -> centroid: the filter stage plus the contour kernel (north_star's 'blob-centroid kernel' as a whole)
         cms = prof["contour_ms"] / prof["contour_launches"]
         b2c = bytes_img * per_launch / ((stage_ms + cms) * 1e-3) / 1e9
-        roof["blob_to_centroid"] = {"kernel": roof["kernel"] + " + contours_kernel", "avg_launch_ms": round(stage_ms + cms, 4),
+        roof["blob_to_centroid"] = {"kernel": roof["kernel"] + " + contours_kernel<1> + contour_follow_kernel + contours_kernel<2>", "avg_launch_ms": round(stage_ms + cms, 4),
                                     "achieved": round(b2c, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b2c / HBM_PEAK_GBS, 4)}
     return roof
 

@@ -289,7 +289,7 @@ struct ContourWork {
 // form -- candidates only (handed to contour_follow_kernel through the workspace and the batch-wide walk list) / tree only
 // (from the records that kernel left).
 template <int MODE>
-__global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
+__device__ __forceinline__ void contours_body(const ContourArgs& a)
 {
     __shared__ uint32_t cand[MAXC];
     // phase A: cell_list (uint16 [MAXCELL]); afterwards: rbox (int16 [MAXR][4]), kept_idx (int16 [MAXK]), kept_depth (int8 [MAXK])
@@ -688,6 +688,11 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
     }
 }
 
+template <int MODE>
+__global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a) { contours_body<MODE>(a); }
+// (capping the candidates kernel at 72 registers for 7 workgroups per CU instead of 5 spills 13 of them: 325 k against 337 k frames/s)
+__global__ __launch_bounds__(NTHREADS) void contour_candidates_kernel(ContourArgs a) { contours_body<1>(a); }
+
 // The walks of the whole batch, one lane each, 64 to a wave whatever image they belong to: an image of a sparse IR frame has
 // a handful of borders, so the per-image kernel's walking wave runs its ~150 instructions per border step for 8 busy lanes;
 // here every lane of a wave follows a border, and the batch needs 1/3 - 1/4 of the wave instructions.  One wave per
@@ -757,7 +762,7 @@ void launch_contours(const ContourArgs& a, hipStream_t s)
 {
     if (a.walk_list && !a.timing && a.n_images < (1 << 22)) {
         (void)hipMemsetAsync(a.walk_count, 0, sizeof(uint32_t), s);
-        hipLaunchKernelGGL(contours_kernel<1>, dim3(a.n_images), dim3(NTHREADS), 0, s, a);
+        hipLaunchKernelGGL(contour_candidates_kernel, dim3(a.n_images), dim3(NTHREADS), 0, s, a);
         hipLaunchKernelGGL(contour_follow_kernel, dim3(a.follow_grid), dim3(64), 0, s, a);
         hipLaunchKernelGGL(contours_kernel<2>, dim3(a.n_images), dim3(NTHREADS), 0, s, a);
         return;
