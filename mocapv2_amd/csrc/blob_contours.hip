@@ -9,21 +9,22 @@
 //     the raster-minimum of the border it lies on;
 //   * a hole border starts at the foreground pixel left of a background pixel whose W and N neighbours are
 //     foreground and that is the raster-minimum of the left-side cracks of the border.
-// Candidates are found with word-parallel bit tests on the mask, guided by the occupancy words the filter kernel
-// leaves per tile.  Each candidate is then followed by ONE LANE: the lane keeps the three 64-column mask rows around
-// its current pixel in registers (a vertical move loads one new row through L1/L2), the walker state and the
-// integer Green's-theorem sums are per-lane registers, so the 64 lanes of a wave follow 64 borders at once and an
-// image needs only one small workgroup -- thousands of images are in flight on the chip at the same time, which is
-// what a batch of sparse IR frames needs (a border walk is a serial chain of ~150 instructions per step, so the
-// kernel is bound by how many walks run concurrently, not by any one of them).  The step itself is literally the
-// reference border-following step (same neighbour order, same CHAIN_APPROX_SIMPLE vertex rule); a candidate is
-// dropped as soon as it meets an earlier pixel of its own border.  The polygon sums are exact integers (int64),
+// Candidates are found with word-parallel bit tests on the mask, guided by the occupancy words the filter kernels leave
+// per tile and by the tiles' boxes (settle_tiles_kernel); a group of 8 lanes holds consecutive words of a mask row.  Each
+// candidate is then followed by ONE LANE: the lane keeps the three 64-column mask rows around its current pixel in registers
+// (a vertical move takes one new row from a 64 x 64 window staged in LDS, from L1/L2 outside it), the walker state and the
+// integer Green's-theorem sums are per-lane registers, so the 64 lanes of a wave follow 64 borders at once (a border walk is
+// a serial chain of ~150 instructions per step: what counts is how many walks share a wave's instruction stream).  The step
+// itself is literally the reference border-following step (same neighbour order, same CHAIN_APPROX_SIMPLE vertex rule); a
+// candidate is dropped as soon as it meets an earlier pixel of its own border.  The polygon sums are exact integers (int64),
 // the perimeter is a sum of float32 square roots held exactly in a double.
 // Tree order (parent = enclosing border, siblings in reverse discovery order, pre-order walk) is rebuilt from
 // "which border owns the crack left of my start pixel": from the bounding boxes when that is unambiguous, else by
 // following that border once.
-// One workgroup of 4 waves per image; the full border records live in a per-image global workspace (L2), the small
-// per-border fields the tree phases need in LDS (~13 KB per workgroup); the mask is 1/8 B per pixel, read through L2.
+// Three kernels per batch: contour_candidates_kernel (one workgroup of 4 waves per image) -> contour_follow_kernel (every
+// walk of the batch, 64 to a wave whatever image they belong to) -> contours_kernel<2> (tree and output, one workgroup per
+// image); the hand-over is the per-image global workspace (L2) and one batch-wide walk list.  contours_kernel<0> is the same
+// work as one kernel per image (MOCAP_CONTOURS_SPLIT=0, and whenever the phase clock is on).  The mask is 1/8 B per pixel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "kernels.h"
