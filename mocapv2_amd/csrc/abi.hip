@@ -674,7 +674,8 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
 // sparse path ran (the general dense kernel keeps none); MOCAP_CONTOUR_BOXES=0: whole strips (A/B switch, same results)
 static const uint32_t* contour_boxes(mocap_ctx* c)
 {
-    static const bool off = getenv("MOCAP_CONTOUR_BOXES") && atoi(getenv("MOCAP_CONTOUR_BOXES")) == 0;
+    const char* e = getenv("MOCAP_CONTOUR_BOXES");
+    const bool off = e && atoi(e) == 0;
     return (c->mask_dirty || off) ? nullptr : c->cur_box;
 }
 
@@ -704,7 +705,8 @@ static int run_contours(mocap_ctx* c, const uint32_t* mask, const uint32_t* cell
     a.work = c->cwork;
     // The split form (candidates per image -> all walks of the batch, 64 to a wave -> tree per image) is the default;
     // MOCAP_CONTOURS_SPLIT=0 runs the one-kernel-per-image form (A/B switch; same results).
-    static const bool split = !(getenv("MOCAP_CONTOURS_SPLIT") && atoi(getenv("MOCAP_CONTOURS_SPLIT")) == 0);
+    const char* es = getenv("MOCAP_CONTOURS_SPLIT");
+    const bool split = !(es && atoi(es) == 0);
     a.walk_list = split ? c->walk_list : nullptr; a.walk_count = c->walk_count;
     a.follow_grid = c->box_grid / 2 > 0 ? c->box_grid / 2 : 1; // 4 one-wave workgroups per CU (33 KB of LDS each)
     a.prio = 0;

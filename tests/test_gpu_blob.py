@@ -577,10 +577,13 @@ def test_blob_centroids_from_bayer_equals_the_two_steps(torch_cuda, monkeypatch,
     {"MOCAP_EXCESS_BASE": "0"}, {"MOCAP_EXCESS_BASE": "100"}, {"MOCAP_EXCESS_BASE": "200"},  # pinned excess bases
     {"MOCAP_BASE_SEL": "0"},                                  # start with the tight base (then adapt)
     {"MOCAP_BOX_BLOCKS_PER_CU": "1"},
+    {"MOCAP_CONTOURS_SPLIT": "0"},                            # the contour stage as one kernel per image
+    {"MOCAP_CONTOUR_BOXES": "0"},                             # candidates from whole strips instead of the tiles' boxes
+    {"MOCAP_CONTOURS_SPLIT": "0", "MOCAP_CONTOUR_BOXES": "0"},
 ], ids=lambda e: ",".join(f"{k[6:]}={v}" for k, v in e.items()))
 def test_tuning_switches_do_not_change_results(torch_cuda, monkeypatch, env):
-    """Routing thresholds, row bands, the side stream, the scan's excess base (pinned or adapting) and the grid size are
-    performance knobs: centroids and masks equal the oracle's whatever they are.  Three batches on one context -- dark
+    """Routing thresholds, row bands, the side stream, the scan's excess base (pinned or adapting), the grid size and the
+    form of the contour stage are performance knobs: centroids and masks equal the oracle's whatever they are.  Three batches on one context -- dark
     frames, frames with a bright background (where the tolerant base is the better one), dark frames again -- so that the
     base adapts in between and the mask's "zero outside the recorded regions" invariant is exercised across the switch."""
     torch = torch_cuda
