@@ -66,19 +66,43 @@ def parse_args(argv=None):
                     help="secondary measurement: the resident frames are raw Bayer GR sensor frames and every step starts with the "
                          "Bayer -> gray pre-pass (RealtimeTracking_FLIR.py:103-104); not the headline workload")
     ap.add_argument("--cpu-steps", type=int, default=256, help="time steps in the CPU baseline / parity sample (0 = skip)")
+    ap.add_argument("--cpu-single-steps", type=int, default=48, help="time steps of the single-thread CPU baseline leg (0 = skip)")
+    ap.add_argument("--batches", type=int, default=3,
+                    help="distinct resident batches the timed region rotates through (every image slot sees a different frame from "
+                         "one step to the next, so the mask's on-demand clearing and the scan's base probe are inside the measurement)")
     ap.add_argument("--no-secondary", dest="secondary", action="store_false",
                     help="skip the early-out-off rerun and the other distortion variant")
     ap.add_argument("--no-extra", dest="extra", action="store_false", help="skip the extra workload sections")
     return ap.parse_args(argv)
 
 
+def visible_gpu_count():
+    """GPUs this process would see, counted WITHOUT touching HIP (no torch.cuda call, no library load): the parent of the
+    rank processes must stay GPU-free because it starts another program afterwards.  Sources: the visibility lists of the
+    environment, else the KFD topology in sysfs (a node with simd_count > 0 is a GPU).  None = cannot tell."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    nodes = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for d in os.listdir(nodes):
+            with open(os.path.join(nodes, d, "properties")) as f:
+                for line in f:
+                    if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                        n += 1
+        return n
+    except OSError:
+        return None
+
+
 def self_launch(args):
-    """`python bench.py --gpus N` outside torchrun: start the N ranks as children of a launcher process.  Nothing in this
-    process has touched a GPU yet (device_count() does not initialise HIP on this image)."""
-    import torch
-    n_dev = torch.cuda.device_count()
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as children of a launcher process.  This process never
+    touches a GPU: the devices are counted from the environment / sysfs (visible_gpu_count), not through torch.cuda."""
+    n_dev = visible_gpu_count()
     extra = []
-    if n_dev < args.gpus and not args.rehearse_on_one_gpu:
+    if n_dev is not None and n_dev < args.gpus and not args.rehearse_on_one_gpu:
         raise SystemExit(f"--gpus {args.gpus}: only {n_dev} GPU(s) visible (add --rehearse-on-one-gpu to run the ranks on one GPU "
                          "through gloo: a functional check, not a measurement)")
     with socket.socket() as s:
@@ -144,11 +168,23 @@ class Workload:
         return out
 
 
-def cpu_baseline(wl, arrays, frames, n_steps):
-    """The oracle (scalar C port of the reference's CPU path) on `n_steps` time steps of the benchmark batch
-    (frames uint8 [T, C, H, W], reused cyclically): thread-per-camera blob extraction as the reference does
-    (RealtimeTracking_FLIR.py:307-312), then correspondence + DLT.  Returns the rate and every time step's results
-    (image-point lists per camera, correspondence output) for the parity comparison."""
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(wl, arrays, frames, n_steps, threads=None):
+    """The oracle (scalar C port of the reference's CPU path, gcc -O3) on `n_steps` time steps of the benchmark batch
+    (frames uint8 [T, C, H, W], reused cyclically): blob extraction with one thread per camera as the reference does
+    (RealtimeTracking_FLIR.py:307-312) -- or on `threads` threads (1 = the single-thread leg of BASELINE.md section 4) --
+    then correspondence + DLT.  Returns the rate and every time step's results (image-point lists per camera,
+    correspondence output) for the parity comparison."""
     from concurrent.futures import ThreadPoolExecutor
 
     import oracle
@@ -157,7 +193,7 @@ def cpu_baseline(wl, arrays, frames, n_steps):
     prm = oracle.default_params(undistort=True, filter_order=2)
     oracle.lib()
     T = frames.shape[0]
-    pool = ThreadPoolExecutor(C)
+    pool = ThreadPoolExecutor(threads or C)
     from mocapv2_amd.engine import GRAY_SHIFT
     gray = (lambda im: oracle.bayer_gray(im, 3, GRAY_SHIFT)) if wl.bayer else (lambda im: im)
     results = []
@@ -182,13 +218,18 @@ def cpu_baseline(wl, arrays, frames, n_steps):
     return n_steps / dt, dt, results
 
 
-def parity_report(results, records, out, n_cam, max_points):
-    """The timed GPU batch against the oracle on every time step of the CPU sample: image points per camera (bit-exact
-    bar) and 3-D points (1e-7 world units = 1e-4 mm bar).  records [T*C, rec] host, out: host arrays."""
-    mism_images = mism_roots = n_points = gave_up = 0
+def parity_report(results, batches, n_cam, max_points, T):
+    """The results the timed region left behind against the oracle: for every resident batch (the last pass of each, taken
+    from the buffers of the lane that ran it) every time step of the CPU sample -- image points per camera (bit-exact bar)
+    and 3-D points (1e-7 world units = 1e-4 mm bar).  results: (base time step, lists, oracle correspondence) of the CPU
+    sample; batches: (time shift of the batch, records [T*C, rec] host, out host arrays); slot s of a batch holds base time
+    step (s + shift) % T."""
+    mism_images = mism_roots = n_points = gave_up = compared = 0
     sq = 0.0
     max_abs = 0.0
-    for s, lists, ref in results:
+    pairs = [((base - shift) % T, lists, ref, records, out) for shift, records, out in batches for base, lists, ref in results if base < T]
+    for s, lists, ref, records, out in pairs:
+        compared += 1
         for c in range(n_cam):
             rec = records[s * n_cam + c]
             n = int(rec[0])
@@ -209,13 +250,29 @@ def parity_report(results, records, out, n_cam, max_points):
             max_abs = max(max_abs, float(np.abs(d).max()))
             n_points += k
     rmse = (sq / max(1, n_points)) ** 0.5
-    return {"time_steps_compared": len(results), "points_compared": n_points,
+    return {"time_steps_compared": compared, "resident_batches_compared": len(batches), "points_compared": n_points,
             "centroid_mismatches": mism_images, "correspondence_mismatches": mism_roots,
             "time_steps_both_gave_up": gave_up,
             "rmse_3d_vs_oracle": rmse, "max_abs_3d": max_abs, "unit": "world units (m)",
             "rmse_3d_mm": rmse * 1e3, "tolerance_mm": 1e-4,
             "ok": bool(mism_images == 0 and mism_roots == 0 and max_abs < 1e-7),
             "oracle": "oracle/ C restatement (geometry half pinned to the reference, blob half parity unpinned: DESIGN.md 2)"}
+
+
+def same_results(rec_a, out_a, rec_b, out_b):
+    """Two passes over one batch left the same results: counts, the image points below each count, root counts and the 3-D
+    points / groups / order below each root count (what lies beyond a count is whatever an earlier batch left there)."""
+    import torch
+    ca, cb = rec_a[:, 0], rec_b[:, 0]
+    if not torch.equal(ca, cb) or not torch.equal(out_a["n"], out_b["n"]):
+        return False
+    col = torch.arange(rec_a.shape[1] - 2, device=rec_a.device)[None, :]
+    live = col < 2 * ca.clamp(min=0)[:, None]
+    if not torch.equal(rec_a[:, 2:][live], rec_b[:, 2:][live]):
+        return False
+    n = out_a["n"].clamp(min=0)
+    roots = torch.arange(out_a["xyz"].shape[1], device=n.device)[None, :] < n[:, None]
+    return all(torch.equal(out_a[k][roots], out_b[k][roots]) for k in ("xyz", "grp", "order"))
 
 
 KERNELS = (("scan", "bright_cells_kernel"), ("settle", "settle_tiles_kernel"), ("filter", "box_filter_kernel + filter_mask_kernel (wide tiles)"))
@@ -230,12 +287,19 @@ def roofline_of(prof, wl, n_images, n_launch_groups, traffic_key):
     bytes_img = wl.width * wl.height
     traffic, source = {}, None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if traffic_key and os.path.exists(tpath):  # HBM bytes per launch from the builder's PMC passes (profiles/README.md)
+    if not traffic_key:
+        source = "none: PMC passes exist for the headline workload only (profiles/README.md)"
+    elif not os.path.exists(tpath):
+        source = "none: profiles/hbm_traffic.json is not present next to bench.py"
+    else:  # HBM bytes per launch from the builder's PMC passes (profiles/README.md)
         with open(tpath) as f:
             tj = json.load(f)
         if tj.get("workload_key") == traffic_key and tj.get("images_per_launch") == per_launch:
             traffic = tj.get("hbm_bytes_per_launch", {})
             source = "profiles/hbm_traffic.json (builder's rocprofv3 PMC passes on this workload; not re-measured in this run)"
+        else:
+            source = (f"none: profiles/hbm_traffic.json holds {tj.get('workload_key')} at {tj.get('images_per_launch')} images per launch, "
+                      f"this run is {traffic_key} at {per_launch}")
     ent = {}
     for key, name in KERNELS:
         n = prof[key + "_launches"]
@@ -309,27 +373,45 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(tracker, frames, steps, warmup):
-        """W untimed + K timed steps of the resident batch, barrier + synchronize on both sides, max over ranks.
-        Then a short sequential pass (one batch at a time, a synchronize after each) for per-kernel durations that are
-        not stretched by the neighbouring batches' kernels (in the timed region `--depth` batches share the chip)."""
+    def batch_of(tracker, n_batches):
+        """Which resident batch the next step takes: consecutive steps take consecutive batches, and the order is chosen so
+        that consecutive steps of one LANE (every `depth`-th step: a lane = one context with its own mask) differ too --
+        otherwise a lane would filter the same frames every time and its mask would never need clearing."""
+        i, depth = tracker._k, len(tracker.lanes)
+        return (i % n_batches) if depth % n_batches else ((i + i // depth) % n_batches)
+
+    def timed(tracker, batches, steps, warmup):
+        """W untimed + K timed steps rotating through the resident batches, barrier + synchronize on both sides, max over
+        ranks.  Then a short sequential pass (one batch at a time, a synchronize after each) for per-kernel durations that
+        are not stretched by the neighbouring batches' kernels (in the timed region `--depth` batches share the chip).
+        Returns the last output, the elapsed time, the profile, and what the timed region left in every lane's buffers:
+        (batch index, records, outputs) of the last batch each lane ran."""
+        nb = len(batches)
+        lane_batch = {}
+
+        def one():
+            k = batch_of(tracker, nb)
+            lane_batch[tracker._k % len(tracker.lanes)] = k
+            return tracker.step(batches[k])
         for _ in range(warmup):
-            tracker.step(frames)
+            one()
         tracker.synchronize()
         barrier()
         tracker.profile(True)
         t0 = time.perf_counter()
         for _ in range(steps):
-            out = tracker.step(frames)
+            out = one()
         tracker.synchronize()
         barrier()
         elapsed = time.perf_counter() - t0
         tracker.profile(False)
         prof_timed = tracker.profile_read()
+        left = [(k, tracker.lanes[l].records.clone(), {key: v.clone() for key, v in tracker.lanes[l].out.items()})
+                for l, k in sorted(lane_batch.items()) if tracker.lanes[l].out is not None]
         n_seq = max(1, min(steps, 6))
         tracker.profile(True)
         for _ in range(n_seq):
-            out = tracker.step(frames)
+            out = one()
             tracker.synchronize()
         tracker.profile(False)
         prof = tracker.profile_read()
@@ -340,10 +422,13 @@ def main():
             tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else "cuda")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
-        return out, elapsed, prof
+        return out, elapsed, prof, left
 
-    def measure(wl, time_steps, steps, warmup):
-        """Build the scene / tracker / resident batch of one workload and time `steps` steps of it."""
+    def measure(wl, time_steps, steps, warmup, n_batches=None):
+        """Build the scene / tracker / resident batches of one workload and time `steps` steps of it.  Batch k holds, in
+        image slot (camera c, time step t), the frame of time step (t + k * shift) % T_total of the rendered sequence: the
+        same markers seen at other moments, so every slot's content changes from batch to batch."""
+        n_batches = max(1, n_batches or args.batches)
         scene = wl.scene()
         arrays = scene_arrays(scene)
         tracker = BatchTracker(*arrays, wl.width, wl.height, time_steps, world=world, rank=rank, device=local_rank, depth=args.depth,
@@ -351,20 +436,36 @@ def main():
                                collective=args.collective)
         images = tracker.local_image_list()
         frames_host = wl.render(scene, images)
-        frames = torch.from_numpy(frames_host).pin_memory() if args.from_host else torch.from_numpy(frames_host).cuda()
+        t_total = time_steps * world
+        shift = max(1, t_total // n_batches + 1) if n_batches > 1 else 0
+        row = {key: i for i, key in enumerate(images)}
+        batches = []
+        for k in range(n_batches):
+            want = [(c, (t + k * shift) % t_total) for c, t in images]
+            idx = [row.get(key) for key in want]
+            if k == 0:
+                host = frames_host
+            elif all(i is not None for i in idx):
+                host = frames_host[np.asarray(idx)]
+            else:  # a rank that holds only part of a camera's time steps: render the shifted moments
+                host = wl.render(scene, want)
+            batches.append(torch.from_numpy(host).pin_memory() if args.from_host else torch.from_numpy(host).cuda())
+            del host
         torch.cuda.synchronize()
-        out, elapsed, prof = timed(tracker, frames, steps, warmup)
-        return {"scene": scene, "arrays": arrays, "tracker": tracker, "images": images, "frames_host": frames_host, "frames": frames,
-                "out": out, "elapsed": elapsed, "prof": prof, "T": time_steps}
+        out, elapsed, prof, left = timed(tracker, batches, steps, warmup)
+        return {"scene": scene, "arrays": arrays, "tracker": tracker, "images": images, "frames_host": frames_host, "batches": batches,
+                "out": out, "elapsed": elapsed, "prof": prof, "T": time_steps, "left": left, "shift": shift, "n_batches": n_batches}
 
     def status_of(m):
-        n_roots = m["out"]["n"].cpu().numpy()
-        try:
-            check_status(n_roots)
-            ok = bool((m["tracker"].records[:, 0].cpu().numpy() >= 0).all())
-        except RuntimeError:
-            ok = False
-        return ok, n_roots
+        """no capacity code in any time step / image of any batch the timed region left behind"""
+        ok = True
+        for _, rec, o in m["left"]:
+            try:
+                check_status(o["n"].cpu().numpy())
+                ok = ok and bool((rec[:, 0].cpu().numpy() >= 0).all())
+            except RuntimeError:
+                ok = False
+        return ok, m["out"]["n"].cpu().numpy()
 
     def section(wl, m, steps):
         ok, n_roots = status_of(m)
@@ -414,16 +515,42 @@ def main():
         for _ in range(n_eval):
             exp = oracle.ba_residuals(params, C, groups, valid, K, dd)
         dt_cpu = (time.perf_counter() - t0) / n_eval
+        # the resident form (mocap_ba_residuals): image points uploaded once, one launch + one stream wait per evaluation
+        from mocapv2_amd.engine import default_context
+        ctx = default_context()
+        ctx.set_cameras(K, dd, R, tt)
+        prob = ctx.ba_problem(groups, valid)
+        res = prob.residuals(params)
+        n_res = 20 * n_eval
+        t0 = time.perf_counter()
+        for _ in range(n_res):
+            res = prob.residuals(params)
+        dt_res = (time.perf_counter() - t0) / n_res
+        jac_sets = np.tile(params, (1 + len(params), 1))  # a forward-difference Jacobian: 1 + 6 (C - 1) = 91 vectors, one launch
+        jac_sets[1:] += np.eye(len(params)) * 3.45e-4
+        prob.residuals(jac_sets)
+        t0 = time.perf_counter()
+        for _ in range(n_eval):
+            prob.residuals(jac_sets)
+        dt_jac = (time.perf_counter() - t0) / n_eval
         return {"workload": "bundle-adjustment residual vector, 16 cameras x 64 markers (BASELINE.json configs[4], residual part)",
-                "ms_per_evaluation": round(1e3 * dt, 4), "evaluations_per_s": round(1 / dt, 1), "points_per_s": round(M / dt, 1),
-                "includes": "drop-in lib.Helpers call surface: list packing, H2D, triangulate + reproject kernels, D2H",
-                "matches_oracle": bool(got.shape == exp.shape and np.allclose(got, exp, rtol=1e-5, atol=1e-6)),
+                "ms_per_evaluation": round(1e3 * dt_res, 4), "evaluations_per_s": round(1 / dt_res, 1), "points_per_s": round(M / dt_res, 1),
+                "includes": "mocap_ba_residuals: image points resident, parameters in / residuals out through one pinned block, "
+                            "rotvec -> R + triangulation + reprojection + float32 cast in one launch, one stream wait",
+                "matches_oracle": bool(res.shape == exp.shape and np.allclose(res, exp, rtol=2e-5, atol=1e-6)),
+                "jacobian_91_vectors_ms": round(1e3 * dt_jac, 4),
+                "drop_in_lists_ms_per_evaluation": round(1e3 * dt, 4),
+                "drop_in_includes": "lib.Helpers params_to_camera_poses + triangulate_points + calculate_reprojection_errors on host lists: "
+                                    "list packing, H2D, two kernels, D2H per call (what round 2 reported)",
+                "drop_in_matches_oracle": bool(got.shape == exp.shape and np.allclose(got, exp, rtol=2e-5, atol=1e-6)),
                 "cpu_oracle_ms_per_evaluation": round(1e3 * dt_cpu, 4)}
 
     T_STEPS = args.time_steps or main_wl.default_time_steps()
     m = measure(main_wl, T_STEPS, args.steps, args.warmup)
     tracker, out, elapsed, prof = m["tracker"], m["out"], m["elapsed"], m["prof"]
     status_ok, n_roots = status_of(m)
+    if main_wl.spread:
+        status_ok = bool((tracker.records[:, 0].cpu().numpy() >= 0).all())  # crowded rig: given-up time steps are counted, not an error
 
     if rank == 0:
         value = T_STEPS * world * args.steps / elapsed
@@ -441,7 +568,16 @@ def main():
             "config": {"workload": main_wl.name(world),
                        "cameras": main_wl.cameras, "width": main_wl.width, "height": main_wl.height, "markers": main_wl.markers,
                        "time_steps_per_step_per_gpu": T_STEPS, "distortion": args.dist, "background": list(main_wl.background),
+                       "marker_cube_m": 2.4 if main_wl.spread else 1.0, "camera_ring_radius_m": 4.0 if main_wl.spread else 3.0,
+                       "rig_note": ("64 markers are spread over a 2.4 m cube seen from a 4 m ring: in the default 1 m cube the reference's "
+                                    "cartesian expansion (lib/Helpers.py:239-245) exceeds 4 M groups per root in half the time steps, which "
+                                    "oracle and kernel both report as MOCAP_CORR_E_GROUPS (time_steps_without_result counts those left)")
+                       if main_wl.spread else None,
                        "frames_resident_in_hbm": not args.from_host, "batches_in_flight": args.depth,
+                       "resident_batches": m["n_batches"],
+                       "batch_rotation": f"slot (camera, t) of batch k holds the frame of time step (t + {m['shift']} k) mod {T_STEPS * world}: "
+                                         "every image slot changes from one step to the next",
+                       "status_ok": status_ok, "parity_ok": None,
                        "input": "raw Bayer GR frames, gray conversion inside every step" if args.bayer else "gray frames",
                        "parallelism": "single launch, time-major" if world == 1 else f"camera-major blocks x{world} + 1 all-gather per batch",
                        "collective": None if world == 1 else
@@ -460,31 +596,42 @@ def main():
         }
         if args.rehearse_on_one_gpu:
             line["rehearsal"] = "N ranks on one GPU over gloo: a functional check of the multi-rank path, NOT a measurement"
-        ref_out = {k: v.clone() for k, v in out.items()}  # the tracker reuses its output buffers
-        ref_rec = tracker.records.clone()
+        left = m["left"]  # what the timed region left in the lanes' buffers: (batch, records, outputs)
         if world == 1 and args.secondary:
-            os.environ["MOCAP_SKIP_DARK"] = "0"  # same batch, early-out off: every tile runs the full filter
-            out_d, el_d, prof_d = timed(tracker, m["frames"], max(3, args.steps // 3), 2)
-            del os.environ["MOCAP_SKIP_DARK"]
+            # the same batches with the early-out off: every tile runs the full filter (dense kernel); the results must not change
+            for lane in tracker.lanes:
+                lane.ctx.set_tuning("skip_dark", 0)
+            n_d = max(3, args.steps // 3)
+            out_d, el_d, prof_d, left_d = timed(tracker, m["batches"], n_d, 2)
+            for lane in tracker.lanes:
+                lane.ctx.set_tuning("skip_dark", 1)
             roof_d = roofline_of(prof_d, main_wl, len(m["images"]), 1, None)
-            line["without_early_out"] = {"value": round(T_STEPS * max(3, args.steps // 3) / el_d, 2), "unit": "frames/s",
-                                         "ms_per_step": round(1e3 * el_d / max(3, args.steps // 3), 4),
+            by_batch = {k: (rec, o) for k, rec, o in left}
+            same = all(k in by_batch and same_results(rec, o, *by_batch[k]) for k, rec, o in left_d)
+            line["without_early_out"] = {"value": round(T_STEPS * n_d / el_d, 2), "unit": "frames/s",
+                                         "ms_per_step": round(1e3 * el_d / n_d, 4),
                                          "filter_avg_launch_ms": roof_d["avg_launch_ms"], "roofline_frac": roof_d["frac"],
-                                         "same_results": bool(torch.equal(tracker.records, ref_rec) and torch.equal(out_d["n"], ref_out["n"])
-                                                              and torch.equal(out_d["xyz"], ref_out["xyz"]))}
+                                         "same_results": bool(same)}
+            del left_d
         if world == 1 and args.cpu_steps > 0:
-            fps, dt, results = cpu_baseline(main_wl, m["arrays"], m["frames_host"].reshape(T_STEPS, main_wl.cameras, main_wl.height, main_wl.width),
-                                            args.cpu_steps)
+            frames_tc = m["frames_host"].reshape(T_STEPS, main_wl.cameras, main_wl.height, main_wl.width)
+            fps, dt, results = cpu_baseline(main_wl, m["arrays"], frames_tc, args.cpu_steps)
             line["cpu_baseline"] = {"value": round(fps, 3), "unit": "frames/s", "cores": main_wl.cameras, "kind": "port",
                                     "sample": f"{args.cpu_steps} time steps x {main_wl.cameras} cameras of the same workload, "
-                                              f"{dt:.1f} s, thread-per-camera C oracle ({os.cpu_count()} host cpus)"}
-            # parity of the timed batch against the oracle (not timed): every time step of the CPU sample
-            host_out = {k: v.cpu().numpy() for k, v in ref_out.items()}
-            line["parity"] = parity_report([r for r in results if r[0] < T_STEPS][:T_STEPS], ref_rec.cpu().numpy(), host_out,
-                                           main_wl.cameras, main_wl.max_points)
+                                              f"{dt:.1f} s, thread-per-camera C oracle (gcc -O3), {os.cpu_count()} host cpus: {cpu_model()}"}
+            if args.cpu_single_steps > 0:
+                fps1, dt1, _ = cpu_baseline(main_wl, m["arrays"], frames_tc, args.cpu_single_steps, threads=1)
+                line["cpu_baseline"]["single_thread"] = {"value": round(fps1, 3), "unit": "frames/s", "cores": 1,
+                                                         "sample": f"{args.cpu_single_steps} time steps x {main_wl.cameras} cameras, {dt1:.1f} s, one thread"}
+            # parity of what the timed region left behind against the oracle (not timed): every time step of the CPU sample, in
+            # every resident batch
+            batches_host = [(k * m["shift"], rec.cpu().numpy(), {key: v.cpu().numpy() for key, v in o.items()}) for k, rec, o in left]
+            line["parity"] = parity_report(results, batches_host, main_wl.cameras, main_wl.max_points, T_STEPS)
+            line["config"]["parity_ok"] = line["parity"]["ok"]
             line["parity_spot_check"] = line["parity"]["ok"]
+            del batches_host
         # release the main workload before the next ones are built
-        del ref_out, ref_rec
+        del left
         m.clear()
         del tracker, out
         torch.cuda.empty_cache()

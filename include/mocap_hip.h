@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define MOCAP_ABI_VERSION 4
+#define MOCAP_ABI_VERSION 5
 #define MOCAP_API __attribute__((visibility("default")))
 
 enum {
@@ -32,12 +32,13 @@ enum {
 
 /* per-image status written to out_count by the blob kernels when an internal capacity is exceeded */
 enum {
-    MOCAP_BLOB_E_CANDIDATES = -2, /* more than 2048 border start candidates in one image */
+    MOCAP_BLOB_E_CANDIDATES = -2, /* more than 1024 border start candidates in one image */
     MOCAP_BLOB_E_CONTOURS = -3,   /* more than 384 borders or 256 kept contours in one image */
     MOCAP_BLOB_E_STEPS = -4,      /* a border longer than the step limit */
     MOCAP_BLOB_E_DEPTH = -5,      /* a kept contour nested deeper than 8 levels */
-    MOCAP_CORR_E_GROUPS = -2,     /* more than 16 candidates for one (root, camera), > max_groups groups for one root, or
-                                     > max(2 * max_groups, 8192) groups in the whole time step */
+    MOCAP_CORR_E_GROUPS = -2,     /* more than 16 candidates for one (root, camera), > max_groups groups for one root, or more
+                                     groups in the whole time step than its share of the error scratch holds: max(2 * max_groups,
+                                     8192) by default, raised with mocap_set_tuning(ctx, "corr_step_groups", n) */
     MOCAP_CORR_E_TRUNCATED = -3,  /* a camera holds more image points than the P that mocap_correspond was told to read */
     MOCAP_CORR_E_BLOB = -4        /* a camera's point count is negative: its blob stage reported MOCAP_BLOB_E_* */
 };
@@ -74,6 +75,16 @@ MOCAP_API int mocap_ctx_destroy(mocap_ctx_t ctx);
 MOCAP_API int mocap_sync(mocap_ctx_t ctx, void* stream); /* hipStreamSynchronize */
 
 MOCAP_API int mocap_set_blob_params(mocap_ctx_t ctx, const mocap_blob_params* p);
+
+/* Performance switches of one context (the reference has none: its tunables are literals).  None of
+ * them changes a result; they select between equivalent code paths (A/B measurements, tests of the alternative paths) or
+ * size a scratch buffer.  mocap_ctx_create reads each of them ONCE from the environment (MOCAP_<NAME> in capitals; the hot
+ * path never calls getenv), this call changes one for the context afterwards.  Names: skip_dark,
+ * general_filter, dense_boxes, remap_pipeline, cluster, wide_quads_remap, wide_quads_identity, wide_bands, wide_fork,
+ * box_prio, scan_prio, contour_prio, corr_prio, box_stage_bytes, box_timing, contour_timing, scan_wide, excess_base,
+ * probe_debug, contour_boxes, contours_split, corr_threads, corr_step_groups.  (rows, box_blocks_per_cu and base_sel
+ * shape the context at creation: environment only.)  Must not race with a batch call on the same context. */
+MOCAP_API int mocap_set_tuning(mocap_ctx_t ctx, const char* name, int value);
 
 /* cv.undistort(img, K, dist) set-up (lib/ImageOperations.py:38): builds the quantised remap table of `slot`
  * on the device (synchronous).  identity_out (optional) receives 1 when the table is the identity. */
@@ -161,6 +172,16 @@ MOCAP_API int mocap_correspond(mocap_ctx_t ctx, const void* pts_dev, long pt_str
                      double* root_grp_dev, int32_t* root_idx_dev, int32_t* order_dev, int32_t* n_roots_dev,
                      void* stream);
 
+/* The scoring step of find_point_correspondance_and_object_points on its own (lib/Helpers.py:205-220), for one camera
+ * pair: the epipolar line of every root point under Fs[f_index] (cv.computeCorrespondEpilines on the float32 point, :207;
+ * line coefficients normalised in FP64, rounded to float32) and the distance of every candidate point of camera
+ * f_index + 1 to it by the expression of :217, evaluated in FP64 -- the very device functions mocap_correspond scores with.
+ * roots_dev [n_roots][2], cand_dev [n_cand][2] (int32, or float64 when pts_f64) -> dist_dev [n_roots][n_cand] float64;
+ * lines_dev (optional, may be NULL) [n_roots][3] float32 = (a, b, c).  The caller applies the cutoff (< 10, :219).
+ * Requires mocap_set_fundamentals. */
+MOCAP_API int mocap_epipolar_scores(mocap_ctx_t ctx, const void* roots_dev, int n_roots, const void* cand_dev, int n_cand,
+                                    int pts_f64, int f_index, double* dist_dev, float* lines_dev, void* stream);
+
 /* triangulate_point(s) over N groups (lib/Helpers.py:43-99).  pts_dev [N][C][2] float64, valid_dev [N][C]
  * (0 = [None, None]).  compact_k != 0 reproduces the reference's indexing of the intrinsics by position after
  * the None entries are dropped (:59-61).  ok_dev[n] = 0 where the reference returns [None, None, None]. */
@@ -171,6 +192,20 @@ MOCAP_API int mocap_triangulate_batch(mocap_ctx_t ctx, const double* pts_dev, co
 MOCAP_API int mocap_reproject_batch(mocap_ctx_t ctx, const double* pts_dev, const uint8_t* valid_dev, const double* xyz_dev,
                           int N, int C, int compact_k, double* mse_dev, int32_t* ok_dev, void* stream);
 
+/* bundle_adjustment's residual_function (lib/Helpers.py:161-167) with params_to_camera_poses (:145-156) for B parameter
+ * vectors in ONE launch: camera 0 at the origin, cameras 1..C-1 from (rotation vector, t) sextuples
+ * (Rotation.from_rotvec(.).as_matrix() on the device), every group triangulated from its C views (groups holding a
+ * [None, None] are skipped, :93), reprojected into them, per-point MSE cast to float32 (:165); groups and object points are
+ * paired positionally as the reference's zip does (:104).  The image points stay resident: pts_dev [N][C][2] float64 and
+ * valid_dev [N][C] are device buffers the caller uploads once per problem; K and dist come from mocap_set_cameras.
+ * params_host [B][6 (C - 1)], residuals_host [B][N] and counts_host [B] (residuals per vector, <= N) are HOST arrays: the
+ * library hands them over through one pinned block the kernel reads and writes directly, so an evaluation costs one launch
+ * and one stream wait.  Synchronous.  SciPy's least_squares stays the driver, as in the reference; a forward-difference
+ * Jacobian is one call with B = 1 + 6 (C - 1). */
+MOCAP_API int mocap_ba_residuals(mocap_ctx_t ctx, const double* params_host, int B, const double* pts_dev,
+                                 const uint8_t* valid_dev, int N, int C, float* residuals_host, int32_t* counts_host,
+                                 void* stream);
+
 /* The path's one exchange step: with the cameras sharded over GPUs (one process per GPU), every rank
  * contributes the fixed-size centroid records of its images and receives all ranks' records, in rank order, before
  * correspondence -- one ncclAllGather (RCCL over xGMI) per batch.  The reference has no counterpart: its camera
@@ -179,15 +214,22 @@ MOCAP_API int mocap_reproject_batch(mocap_ctx_t ctx, const double* pts_dev, cons
  * do not need it.
  *   mocap_comm_unique_id  rank 0 obtains MOCAP_COMM_ID_BYTES opaque bytes (ncclGetUniqueId) and hands them to the
  *                         other ranks by any host-side means (file, socket, MPI, torch.distributed store ...);
- *   mocap_comm_init       every rank, collectively: creates the context's communicator (ncclCommInitRank) on the
- *                         context's device; one communicator per context = per stream of batches in flight;
+ *   mocap_comm_available  0 when librccl can be loaded in this process (no communication: a local check every rank makes
+ *                         BEFORE any rank enters the collective mocap_comm_init, so that all take the same road);
+ *   mocap_comm_init       every rank, collectively: creates a communicator (ncclCommInitRank) on the context's device;
+ *   mocap_comm_share      local: lets another context of the same rank and device (another batch in flight, with its own
+ *                         HIP stream) use src's communicator -- ONE communicator per rank; the library orders the
+ *                         all-gathers issued through it with an event chain, whatever streams they run on;
  *   mocap_allgather_centroids  asynchronous on `stream`: local_records_dev [ints_per_rank] int32 of every rank
  *                         -> gathered_dev [world][ints_per_rank] on every rank (the records mocap_blob_centroids
  *                         wrote; mocap_correspond then reads them in place through its strides);
- *   mocap_comm_destroy    optional; mocap_ctx_destroy does it too. */
+ *   mocap_comm_destroy    drops the context's reference; the communicator goes with its last user (mocap_ctx_destroy
+ *                         does this too). */
 #define MOCAP_COMM_ID_BYTES 128
 MOCAP_API int mocap_comm_unique_id(void* id_out /*[MOCAP_COMM_ID_BYTES]*/);
+MOCAP_API int mocap_comm_available(void);
 MOCAP_API int mocap_comm_init(mocap_ctx_t ctx, const void* id /*[MOCAP_COMM_ID_BYTES]*/, int rank, int world);
+MOCAP_API int mocap_comm_share(mocap_ctx_t dst, mocap_ctx_t src);
 MOCAP_API int mocap_comm_destroy(mocap_ctx_t ctx);
 MOCAP_API int mocap_allgather_centroids(mocap_ctx_t ctx, const int32_t* local_records_dev, int32_t* gathered_dev,
                                         long ints_per_rank, void* stream);

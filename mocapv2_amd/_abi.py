@@ -4,7 +4,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmocap_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 COMM_ID_BYTES = 128  # MOCAP_COMM_ID_BYTES
 
 
@@ -37,6 +37,7 @@ SIGNATURES = {
     "mocap_ctx_destroy": [_vp],
     "mocap_sync": [_vp, _vp],
     "mocap_set_blob_params": [_vp, C.POINTER(BlobParams)],
+    "mocap_set_tuning": [_vp, C.c_char_p, _i],
     "mocap_set_undistort": [_vp, _i, _dp, _dp, _ip],
     "mocap_set_cameras": [_vp, _i, _dp, _dp, _dp, _dp],
     "mocap_set_fundamentals": [_vp, _i, _dp],
@@ -50,10 +51,14 @@ SIGNATURES = {
     "mocap_demosaic_u8": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "mocap_bayer_gray_u8": [_vp, _vp, _vp, _i, _i, _i, _l, _l, _sz, _sz, _i, _i, _vp],
     "mocap_correspond": [_vp, _vp, _l, _l, _vp, _l, _l, _i, _i, _i, _i, _d, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "mocap_epipolar_scores": [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "mocap_ba_residuals": [_vp, _dp, _i, _vp, _vp, _i, _i, C.POINTER(C.c_float), _ip, _vp],
     "mocap_triangulate_batch": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "mocap_reproject_batch": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "mocap_comm_unique_id": [_vp],
+    "mocap_comm_available": [],
     "mocap_comm_init": [_vp, _vp, _i, _i],
+    "mocap_comm_share": [_vp, _vp],
     "mocap_comm_destroy": [_vp],
     "mocap_allgather_centroids": [_vp, _vp, _vp, _l, _vp],
     "mocap_tile_stats": [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],

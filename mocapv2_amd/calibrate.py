@@ -119,35 +119,27 @@ def extrinsics_from_fundamentals(image_points, Fs, camera_params, ctx=None):
 
 
 # ---- bundle adjustment: residual and Jacobian in batched launches ---------------------------------------------------
-def _params_to_pose(p):
-    from .lib.Helpers import _rotvec_to_matrix
-    return _rotvec_to_matrix(p[0:3]), np.asarray(p[3:6], float)
-
-
-def residuals_batched(image_points, param_sets, camera_params, ctx=None):
+def residuals_batched(image_points, param_sets, camera_params, ctx=None, problem=None):
     """Residual vectors (per-point reprojection MSE, float32 -- reference lib/Helpers.py:161-167) of S parameter
-    vectors at once: S x N groups over 2 S cameras, one triangulation launch and one reprojection launch.  Like the
-    reference's residual, two cameras are assumed (identity + params[0:6])."""
+    vectors at once: ONE launch (mocap_ba_residuals: rotvec -> R, triangulation, reprojection and the float32 cast on
+    the device, one workgroup per parameter vector) over image points that stay resident on the GPU.  Like the
+    reference's residual, two cameras are assumed (identity + params[0:6]).  `problem`: the BAProblem of an earlier call
+    with the same image points (bundle_adjustment keeps one for the whole optimisation)."""
+    if problem is None:
+        problem = ba_problem(image_points, camera_params, ctx)
+    sets = np.array([np.asarray(p, float)[:6] for p in param_sets])
+    return np.stack(problem.residuals(sets))
+
+
+def ba_problem(image_points, camera_params, ctx=None):
+    """Uploads the image points [N, 2, 2] of a two-camera bundle adjustment once (engine.BAProblem) and sets the two
+    cameras' intrinsics in the context."""
     ctx = ctx or default_context()
     ip = np.asarray(image_points, float)
-    N = ip.shape[0]
-    assert ip.shape[1:] == (2, 2), "the reference's residual is hard-wired to two cameras (lib/Helpers.py:162)"
-    S = len(param_sets)
-    assert 2 * S <= 32
-    K, d = _intrinsics(camera_params, 2 * S)
-    R = np.zeros((2 * S, 3, 3))
-    t = np.zeros((2 * S, 3))
-    pts = np.zeros((S * N, 2 * S, 2))
-    valid = np.zeros((S * N, 2 * S), np.uint8)
-    for s, p in enumerate(param_sets):
-        R[2 * s] = np.eye(3)
-        R[2 * s + 1], t[2 * s + 1] = _params_to_pose(np.asarray(p, float))
-        pts[s * N:(s + 1) * N, 2 * s:2 * s + 2] = ip
-        valid[s * N:(s + 1) * N, 2 * s:2 * s + 2] = 1
-    ctx.set_cameras(K, d, R, t)
-    xyz, _ = ctx.triangulate_batch(pts, valid, compact_k=True)
-    mse, _ = ctx.reproject_batch(pts, valid, xyz, compact_k=True)
-    return mse.reshape(S, N).astype(np.float32)
+    assert ip.ndim == 3 and ip.shape[1:] == (2, 2), "the reference's residual is hard-wired to two cameras (lib/Helpers.py:162)"
+    K, d = _intrinsics(camera_params, 2)
+    ctx.set_cameras(K, d, np.stack([np.eye(3)] * 2), np.zeros((2, 3)))
+    return ctx.ba_problem(ip)
 
 
 def forward_difference_steps(x0, f_dtype=np.float32):
@@ -162,7 +154,7 @@ def forward_difference_steps(x0, f_dtype=np.float32):
     return eps ** 0.5 * sign * np.maximum(1.0, np.abs(x0))
 
 
-def residual_and_jacobian(image_points, x0, camera_params, ctx=None):
+def residual_and_jacobian(image_points, x0, camera_params, ctx=None, problem=None):
     """(f0, J) with J exactly what `least_squares(jac='2-point')` derives from the float32 residuals: column i =
     (f(x0 + h_i e_i) - f0) / ((x0 + h_i e_i)_i - x0_i), the subtraction done in float32 as NumPy does for the
     reference's float32 residual vectors."""
@@ -173,7 +165,7 @@ def residual_and_jacobian(image_points, x0, camera_params, ctx=None):
         x1 = x0.copy()
         x1[i] = x0[i] + h[i]
         sets.append(x1)
-    f = residuals_batched(image_points, sets, camera_params, ctx)
+    f = residuals_batched(image_points, sets, camera_params, ctx, problem)
     f0 = f[0]
     J = np.empty((len(f0), len(x0)))
     for i in range(len(x0)):
@@ -198,11 +190,13 @@ def bundle_adjustment(image_points, camera_poses, camera_params, batched_jacobia
         init = np.concatenate([init, Rotation.from_matrix(np.asarray(pose["R"], float)).as_rotvec(),
                                np.asarray(pose["t"], float).flatten()])
 
+    problem = ba_problem(image_points, camera_params, ctx)  # image points resident for the whole optimisation
+
     def fun(x):
-        return residuals_batched(image_points, [x], camera_params, ctx)[0]
+        return residuals_batched(image_points, [x], camera_params, ctx, problem)[0]
 
     def jac(x):
-        return residual_and_jacobian(image_points, x, camera_params, ctx)[1]
+        return residual_and_jacobian(image_points, x, camera_params, ctx, problem)[1]
 
     result = optimize.least_squares(fun, init, jac=jac if batched_jacobian else "2-point", verbose=verbose, loss="linear",
                                     method="trf", ftol=1e-5, xtol=1e-15)

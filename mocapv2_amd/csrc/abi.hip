@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 #include <mutex>
+#include <memory>
 #include <dlfcn.h>
 #include "../../include/mocap_hip.h"
 #include "kernels.h"
@@ -39,10 +40,87 @@ static int fail(int code, const char* fmt, ...)
 
 struct EvPair { hipEvent_t a, b; };
 
+// One RCCL communicator per rank, shared by the rank's contexts (= the batches in flight): RCCL wants the operations of a
+// communicator issued one after the other, so every all-gather waits for the event its predecessor recorded (on whatever
+// stream that one ran) and records it anew.
+struct SharedComm {
+    void* comm = nullptr;      // ncclComm_t
+    int rank = 0, world = 1, device = 0;
+    hipEvent_t last = nullptr; // completion of the most recent all-gather on this communicator
+    bool have_last = false;
+    std::mutex mu;             // issue order = lock order
+};
+
+// Performance switches of a context (A/B measurements, tests of the alternative code paths; none changes a result).  They are
+// read from the environment ONCE, by mocap_ctx_create (MOCAP_<NAME IN CAPITALS>), and can be changed per context afterwards
+// with mocap_set_tuning: the hot path itself never calls getenv.  -1 = "not set" where 0 is a meaningful value.
+struct Tuning {
+    int rows = 68;               // rows per tile, 16..68
+    int general_filter = 0;      // 1 = the dense kernel for everything
+    int skip_dark = 1;           // 0 = no early-out: every tile is filtered
+    int dense_boxes = 0;         // 1 = with skip_dark = 0: the box kernel on whole tiles instead of the dense kernel
+    int remap_pipeline = 1;      // 0 = the dense kernel's per-pixel gather
+    int cluster = 1;             // 0 = no 2x2-tile cluster items
+    int wide_quads_remap = 40, wide_quads_identity = 40; // routing threshold box kernel / row pipeline (1000 = never)
+    int wide_bands = 1;          // row bands of a wide tile, 1..4
+    int wide_fork = 0;           // 1 = the wide tiles on a side stream beside the box kernel
+    int box_prio = 0, scan_prio = 0, contour_prio = 0, corr_prio = 0; // wave priorities
+    int box_stage_bytes = BOX_SCAP; // LDS the box kernel's source staging may use (0 = taps from memory)
+    int box_blocks_per_cu = 0;   // 0 = box_filter_blocks_per_cu()
+    int box_timing = 0, contour_timing = 0; // phase clocks on stderr (synchronous debugging aids)
+    int scan_wide = 1;           // 0 = the scan's 8-byte loads
+    int excess_base = -1;        // >= 0: pins the scan's excess base
+    int base_sel = 1;            // the base a context starts with (0 tight, 1 tolerant)
+    int probe_debug = 0;
+    int contour_boxes = 1;       // 0 = candidates from whole strips
+    int contours_split = 1;      // 0 = the contour stage as one kernel per image
+    int corr_threads = 256;      // threads per time step of the correspondence kernel (64 / 128 / 256)
+    int corr_step_groups = 0;    // candidate groups one time step may hold in all (error scratch per step); 0 = max(2 * max_groups, 8192)
+};
+struct TuneName { const char* name; int Tuning::*field; int lo, hi; };
+static const TuneName kTuneNames[] = {
+    {"rows", &Tuning::rows, 16, 68}, {"general_filter", &Tuning::general_filter, 0, 1}, {"skip_dark", &Tuning::skip_dark, 0, 1},
+    {"dense_boxes", &Tuning::dense_boxes, 0, 1}, {"remap_pipeline", &Tuning::remap_pipeline, 0, 1}, {"cluster", &Tuning::cluster, 0, 1},
+    {"wide_quads_remap", &Tuning::wide_quads_remap, 0, 100000}, {"wide_quads_identity", &Tuning::wide_quads_identity, 0, 100000},
+    {"wide_bands", &Tuning::wide_bands, 1, 4}, {"wide_fork", &Tuning::wide_fork, 0, 1},
+    {"box_prio", &Tuning::box_prio, 0, 1}, {"scan_prio", &Tuning::scan_prio, 0, 3}, {"contour_prio", &Tuning::contour_prio, 0, 3},
+    {"corr_prio", &Tuning::corr_prio, 0, 3}, {"box_stage_bytes", &Tuning::box_stage_bytes, 0, BOX_SCAP},
+    {"box_blocks_per_cu", &Tuning::box_blocks_per_cu, 0, 32}, {"box_timing", &Tuning::box_timing, 0, 1},
+    {"contour_timing", &Tuning::contour_timing, 0, 1}, {"scan_wide", &Tuning::scan_wide, 0, 1}, {"excess_base", &Tuning::excess_base, -1, 254},
+    {"base_sel", &Tuning::base_sel, 0, 1}, {"probe_debug", &Tuning::probe_debug, 0, 1}, {"contour_boxes", &Tuning::contour_boxes, 0, 1},
+    {"contours_split", &Tuning::contours_split, 0, 1}, {"corr_threads", &Tuning::corr_threads, 64, 256},
+    {"corr_step_groups", &Tuning::corr_step_groups, 0, 0x7fffffff},
+};
+static bool tune_set(Tuning& t, const char* name, int v)
+{
+    for (const TuneName& n : kTuneNames)
+        if (!strcmp(n.name, name)) {
+            t.*(n.field) = v < n.lo ? n.lo : (v > n.hi ? n.hi : v);
+            return true;
+        }
+    return false;
+}
+static Tuning tuning_from_env()
+{
+    Tuning t;
+    for (const TuneName& n : kTuneNames) {
+        char env[64] = "MOCAP_";
+        size_t k = strlen(env);
+        for (const char* p = n.name; *p && k + 1 < sizeof(env); p++) env[k++] = (char)((*p >= 'a' && *p <= 'z') ? *p - 32 : *p);
+        env[k] = 0;
+        const char* e = getenv(env);
+        if (e && *e) tune_set(t, n.name, atoi(e));
+    }
+    { const char* e = getenv("MOCAP_WIDE_QUADS"); int r_ = 0, i_ = 0; // "remap,identity"
+      if (e && sscanf(e, "%d,%d", &r_, &i_) == 2) { tune_set(t, "wide_quads_remap", r_); tune_set(t, "wide_quads_identity", i_); } }
+    return t;
+}
+
 struct mocap_ctx {
     int device, W, H, n_slots, wpr;
     int box_grid;             // workgroups of the box kernel: the resident ones (box_filter_blocks_per_cu() per CU)
     mocap_blob_params prm;
+    Tuning tune;
     uint32_t* maps;           // [2][n_slots][H][W]: tap positions, then blend weights (general form)
     uint32_t* map4;           // [n_slots][H][W] (+ 4 words): compact table of the box kernel
     ushort4* srcbox;          // [n_slots][ceil(H/8)][ceil(W/8)]: source box per 8x8 output cell (box kernel)
@@ -58,6 +136,7 @@ struct mocap_ctx {
     int last_images;                       // images of the most recent batch that wrote c->cells
     uint32_t* tile_rows;                   // [2][mask_images][tiles][4] the scan's box per tile (see BoxArgs): two arrays, alternating
     int tile_rows_flip;                    //   per batch: the one the scan widens and settle reads / the one settle empties
+    int tile_rows_hold[2];                 //   images whose boxes each of the two may still hold (batches of varying size)
     uint32_t* cur_box;                     // [mask_images][tiles][4] output region / scan box of the last batch per tile (BoxArgs)
     BoxItem* items; uint32_t* n_items; uint32_t cap_items; // work list of the box kernel
     uint4* wide_tiles; uint32_t cap_wide;                  // list of the tiles with wide boxes (filter_mask_kernel, list form)
@@ -70,7 +149,9 @@ struct mocap_ctx {
     uint32_t* walk_list; uint32_t* walk_count; // contour stage, split form: the batch's border walks (grown with cwork) and their number
     CameraTable* cams; int n_cam, n_F;
     double* scratch; size_t scratch_elems;
-    void* comm; int comm_rank, comm_world; // RCCL communicator of mocap_comm_init (ncclComm_t), else null
+    double* ba_obj; size_t ba_obj_elems;   // object points of mocap_ba_residuals, [B][N][3]
+    void* ba_pinned; size_t ba_pinned_bytes; // its host-side hand-over: parameters in, residuals + counts out (the kernel reads / writes it directly)
+    std::shared_ptr<struct SharedComm> comm; // RCCL communicator of mocap_comm_init / mocap_comm_share, else null
     bool profiling;
     std::vector<EvPair> ev[5];
     std::mutex mu;
@@ -83,8 +164,7 @@ static Tiling tiling(const mocap_ctx* c)
 {
     Tiling t;
     // Rows per tile.  Must be <= 68: settle_tiles_kernel cuts a tile into at most 4 items of BOX_HCAP quad-rows.
-    t.rows = 68;
-    { const char* e = getenv("MOCAP_ROWS"); if (e && atoi(e) >= 16 && atoi(e) <= 68) t.rows = atoi(e); } // A/B switch
+    t.rows = c->tune.rows;
     if (c->H < 4 * 32) t.rows = (c->H + 3) / 4 > 8 ? (c->H + 3) / 4 : 8;
     t.n_cgroups = (c->H + 4 * t.rows - 1) / (4 * t.rows);
     t.n_strips = (c->W + 239) / 240;
@@ -155,18 +235,20 @@ int mocap_ctx_create(int device_id, int width, int height, int n_slots, mocap_ct
     c->prm = mocap_blob_params{5, 5, 255 * 0.85, 500.0, 0.5};
     c->maps = nullptr; c->map4 = nullptr; c->srcbox = nullptr; c->reach = nullptr; c->cflags = nullptr; c->map_flags = nullptr;
     c->mask = nullptr; c->mask_images = 0; c->mask_dirty = false; c->cells = nullptr; c->cells_images = 0; c->last_images = 0;
-    c->tile_rows = nullptr; c->tile_rows_flip = 0; c->cur_box = nullptr; c->items = nullptr; c->n_items = nullptr; c->cap_items = 0; c->wide_tiles = nullptr; c->cap_wide = 0;
+    c->tile_rows = nullptr; c->tile_rows_flip = 0; c->tile_rows_hold[0] = c->tile_rows_hold[1] = 0; c->cur_box = nullptr; c->items = nullptr; c->n_items = nullptr; c->cap_items = 0; c->wide_tiles = nullptr; c->cap_wide = 0;
     c->cells_ext = nullptr; c->cur_box_ext = nullptr; c->cells_ext_images = 0; c->cwork = nullptr; c->cwork_images = 0; c->walk_list = nullptr; c->walk_count = nullptr;
     c->cams = nullptr; c->n_cam = 0; c->n_F = 0; c->scratch = nullptr; c->scratch_elems = 0; c->profiling = false;
-    c->comm = nullptr; c->comm_rank = 0; c->comm_world = 1;
+    c->ba_obj = nullptr; c->ba_obj_elems = 0; c->ba_pinned = nullptr; c->ba_pinned_bytes = 0;
+    c->comm.reset();
     c->side = nullptr; c->ev_fork = nullptr; c->ev_join = nullptr;
-    c->base_sel = 1; { const char* e = getenv("MOCAP_BASE_SEL"); if (e) c->base_sel = atoi(e) != 0; } c->probe_age = 0; c->probe_pending = false; c->probe_dev = nullptr; c->probe_host = nullptr; c->probe_ev = nullptr;
+    c->tune = tuning_from_env();
+    c->base_sel = c->tune.base_sel; c->probe_age = 0; c->probe_pending = false; c->probe_dev = nullptr; c->probe_host = nullptr; c->probe_ev = nullptr;
     {
         hipDeviceProp_t prop;
         c->box_grid = 2048;
         if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) {
             c->box_grid = box_filter_blocks_per_cu() * prop.multiProcessorCount;
-            { const char* e = getenv("MOCAP_BOX_BLOCKS_PER_CU"); if (e && atoi(e) >= 1 && atoi(e) <= 32) c->box_grid = atoi(e) * prop.multiProcessorCount; } // A/B switch
+            if (c->tune.box_blocks_per_cu >= 1) c->box_grid = c->tune.box_blocks_per_cu * prop.multiProcessorCount; // A/B switch
         }
     }
     c->slot_state.assign(n_slots, 0);
@@ -197,7 +279,7 @@ int mocap_ctx_destroy(mocap_ctx_t c)
     if (!c) return MOCAP_OK;
     (void)hipSetDevice(c->device);
     for (auto& v : c->ev) for (auto& p : v) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
-    if (c->comm && g_rccl.lib) { (void)g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
+    (void)mocap_comm_destroy(c);
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -224,6 +306,8 @@ int mocap_ctx_destroy(mocap_ctx_t c)
     if (c->walk_count) (void)hipFree(c->walk_count);
     if (c->cams) (void)hipFree(c->cams);
     if (c->scratch) (void)hipFree(c->scratch);
+    if (c->ba_obj) (void)hipFree(c->ba_obj);
+    if (c->ba_pinned) (void)hipHostFree(c->ba_pinned);
     delete c;
     return MOCAP_OK;
 }
@@ -243,6 +327,16 @@ int mocap_set_blob_params(mocap_ctx_t c, const mocap_blob_params* p)
         return fail(MOCAP_E_UNSUPPORTED, "only the reference's 5x5 blur and 5x5 median are implemented (got %d, %d)", p->ksize, p->median);
     if (!(p->thresh == p->thresh)) return fail(MOCAP_E_INVALID, "thresh is NaN");
     c->prm = *p;
+    return MOCAP_OK;
+}
+
+int mocap_set_tuning(mocap_ctx_t c, const char* name, int value)
+{
+    if (!c || !name) return fail(MOCAP_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!strcmp(name, "rows") || !strcmp(name, "box_blocks_per_cu") || !strcmp(name, "base_sel"))
+        return fail(MOCAP_E_STATE, "tuning '%s' shapes the context's buffers: set MOCAP_%s in the environment before mocap_ctx_create", name, name);
+    if (!tune_set(c->tune, name, value)) return fail(MOCAP_E_INVALID, "unknown tuning name '%s'", name);
     return MOCAP_OK;
 }
 
@@ -460,18 +554,17 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
         if (c->slot_state[sl] == 2) { remap = true; if (sl - slot_base < 64) remap_bits |= 1ull << (sl - slot_base); }
         if (c->slot_state[sl] == 2 && !c->slot_compact[sl]) compact = false;
     }
-    { const char* e = getenv("MOCAP_GENERAL_FILTER"); if (e && atoi(e) != 0) compact = false; } // test switch: the general kernel
+    if (c->tune.general_filter) compact = false; // test switch: the general kernel
     if (cells == c->cells) c->last_images = n_images;
     EvPair p; bool on;
     // dark-tile early-out: largest doubled excess sum 2E (E = sum of max(0, p - base)) per 16x16 block that still proves an
     // all-zero mask:   2E * Wmax < 1024 * taps_min * (2 * thr_mul - 2 * base - 1)     (derivation: blob_filter.hip)
-    int fixed_base = -1;
-    { const char* e = getenv("MOCAP_EXCESS_BASE"); if (e) { fixed_base = atoi(e); if (fixed_base > thr_mul - 1) fixed_base = thr_mul - 1; if (fixed_base > 254) fixed_base = 254; if (fixed_base < 0) fixed_base = 0; } }
+    int fixed_base = c->tune.excess_base;
+    if (fixed_base >= 0) { if (fixed_base > thr_mul - 1) fixed_base = thr_mul - 1; if (fixed_base > 254) fixed_base = 254; if (fixed_base < 0) fixed_base = 0; }
     if (c->probe_pending && hipEventQuery(c->probe_ev) == hipSuccess) { // the last probe's counts have arrived
         unsigned long long n_cur = 0, n_alt = 0;
         for (int i = 0; i < 128; i++) { n_cur += c->probe_host[2 * i]; n_alt += c->probe_host[2 * i + 1]; }
-        static const bool dbg = getenv("MOCAP_PROBE_DEBUG") != nullptr;
-        if (dbg) fprintf(stderr, "[probe] base %d: %llu hot cells, alternative %d: %llu\n", excess_base(thr_mul, c->base_sel), n_cur, excess_base(thr_mul, c->base_sel ^ 1), n_alt);
+        if (c->tune.probe_debug) fprintf(stderr, "[probe] base %d: %llu hot cells, alternative %d: %llu\n", excess_base(thr_mul, c->base_sel), n_cur, excess_base(thr_mul, c->base_sel ^ 1), n_alt);
         // The tight base (sel 0) leaves tighter boxes around the markers for the same number of hot cells (measured: 33k against
         // 45k marked tiles per 3072 images of the benchmark scene), so it is preferred unless the background makes its hot cells
         // explode: use it iff it leaves at most 1.25x the hot cells of the tolerant base.
@@ -500,11 +593,11 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
             allow_cut2 = (int)((per_tap * t5(c->W) * t5(c->H) - 1) / wmax);    // smallest window cut in both
             if (per_tap_alt > 0) allow_alt = (int)((per_tap_alt * t5full(c->W) * t5full(c->H) - 1) / wmax);
         }
-        { const char* e = getenv("MOCAP_SKIP_DARK"); if (e && atoi(e) == 0) allow = -1; }
+        if (!c->tune.skip_dark) allow = -1;
     }
     // every tile has to be filtered anyway: the dense kernel's sliding row pipeline does that with less work per pixel
     // than the box kernel (MOCAP_DENSE_BOXES=1: the box kernel on whole tiles, a test switch)
-    { const char* e = getenv("MOCAP_DENSE_BOXES"); if (allow < 0 && !(e && atoi(e) != 0)) compact = false; }
+    if (allow < 0 && !c->tune.dense_boxes) compact = false;
     if (!compact) {
         // general dense kernel (tiny images, tables beyond the compact format): every tile, every mask byte
         FilterArgs a;
@@ -516,7 +609,7 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
         a.thr_mul = thr_mul;
         a.n_strips = tl.n_strips; a.rows_per_chunk = tl.rows; a.n_cgroups = tl.n_cgroups;
         a.pipelined = c->W >= 4 && (c->W & 3) == 0 && c->H >= 2;
-        { const char* e = getenv("MOCAP_REMAP_PIPELINE"); if (e && atoi(e) == 0) a.pipelined = 0; } // test switch: the per-pixel gather
+        if (!c->tune.remap_pipeline) a.pipelined = 0; // test switch: the per-pixel gather
         if (bayer) { launch_bayer_gray(*bayer, s); HIP_TRY(hipGetLastError()); }
         if (own_mask) c->mask_dirty = true;
         prof_begin(c, 0, s, p, on);
@@ -546,9 +639,8 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
     uint32_t* const tr_cur = c->tile_rows + (c->tile_rows_flip ? tr_words : 0);
     a.tile_rows = tr_cur;
     a.tile_rows_next = c->tile_rows + (c->tile_rows_flip ? 0 : tr_words);
-    c->tile_rows_flip ^= 1;
-    a.cluster = 1;
-    { const char* e = getenv("MOCAP_CLUSTER"); if (e) a.cluster = atoi(e) != 0; } // A/B switch
+    a.n_clear = c->tile_rows_hold[c->tile_rows_flip ^ 1];
+    a.cluster = c->tune.cluster;
     a.cur_box = own_mask ? c->cur_box : c->cur_box_ext;
     a.items = c->items; a.n_items = c->n_items; a.cap_items = c->cap_items;
     a.dense = allow < 0;
@@ -557,15 +649,11 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
     // (~850 cycles per row with the gather).  Measured optimum on the benchmark scenes (8 and 32 markers, both lens models):
     // 38-46 quads; without the routing the 32-marker scene's filter takes 1.77 ms instead of 1.25, the 8-marker scene's
     // 0.53 instead of 0.49.  MOCAP_WIDE_QUADS="remap,identity" overrides (A/B switch; 1000 = never).
-    a.wide_tiles = c->wide_tiles; a.cap_wide = c->cap_wide; a.wide_quads_remap = 40; a.wide_quads_identity = 40;
-    { const char* e = getenv("MOCAP_WIDE_QUADS"); int r_ = 0, i_ = 0; if (e && sscanf(e, "%d,%d", &r_, &i_) == 2) { a.wide_quads_remap = r_; a.wide_quads_identity = i_; } }
-    a.wide_bands = 1; // measured: 2 / 4 bands 0.50 / 0.55 ms against 0.475 (8 markers), 1.33 / 1.58 against 1.22 (32 markers): the kernel is work-bound
-    { const char* e = getenv("MOCAP_WIDE_BANDS"); if (e && atoi(e) >= 1 && atoi(e) <= 4) a.wide_bands = atoi(e); } // A/B switch
+    a.wide_tiles = c->wide_tiles; a.cap_wide = c->cap_wide; a.wide_quads_remap = c->tune.wide_quads_remap; a.wide_quads_identity = c->tune.wide_quads_identity;
+    a.wide_bands = c->tune.wide_bands; // measured: 2 / 4 bands 0.50 / 0.55 ms against 0.475 (8 markers), 1.33 / 1.58 against 1.22 (32 markers): the kernel is work-bound
     if (c->W < 4) a.wide_tiles = nullptr;
-    a.stage_bytes = BOX_SCAP;
-    a.prio = 0;
-    { const char* e = getenv("MOCAP_BOX_PRIO"); if (e) a.prio = atoi(e) != 0; } // A/B switch
-    { const char* e = getenv("MOCAP_BOX_STAGE_BYTES"); if (e && atoi(e) >= 0 && atoi(e) < BOX_SCAP) a.stage_bytes = atoi(e); } // test switch
+    a.stage_bytes = c->tune.box_stage_bytes; // test switch
+    a.prio = c->tune.box_prio;
     a.ext_mask = own_mask ? 0 : 1;
     if ((size_t)n_images * cells_per_image(c) * BOX_MAX_PARTS > (size_t)c->cap_items) return fail(MOCAP_E_STATE, "work list smaller than the batch");
     HIP_TRY(hipMemsetAsync(c->n_items, 0, 1024, s));
@@ -575,14 +663,14 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
         const uint64_t ncells = ncx64 * (uint64_t)((c->H + 7) / 8);
         int wide = (c->W % 16 == 0) && (pitch % 16 == 0) && (image_stride % 16 == 0) && (((uintptr_t)frames & 15) == 0) && ncx64 >= 4;
         if (wide && ncells * (ncx64 / 2) >= (1ull << 32)) wide = 0;
-        { const char* e = getenv("MOCAP_SCAN_WIDE"); if (e && atoi(e) == 0) wide = 0; } // A/B switch
+        if (!c->tune.scan_wide) wide = 0; // A/B switch
         if (wide) ncx64 /= 2; // the wide kernel divides pair indices by the pairs per cell row
         const uint32_t ncx_magic = (ncx64 > 1 && ncells * ncx64 < (1ull << 32)) ? (uint32_t)(((1ull << 32) + ncx64 - 1) / ncx64) : 0u;
         BrightArgs b{(const uint8_t*)frames, image_stride, pitch, c->H, c->W, n_images, cam_mod, ncx_magic, wide, base, allow / 4, allow_cut1 / 4, allow_cut2 / 4,
                      c->reach + (size_t)slot_base * source_cells(c), c->cflags + (size_t)slot_base * source_cells(c),
                      tr_cur, tl.n_cgroups * 4, tl.n_strips, (uint32_t)(((1u << 23) + tl.rows - 1) / tl.rows),
                      mask, own_mask ? 0 : (size_t)n_images * c->H * c->wpr, ((uintptr_t)mask & 15) == 0, nullptr, base_alt, allow_alt / 4, 0};
-        { const char* e = getenv("MOCAP_SCAN_PRIO"); if (e) b.prio = atoi(e); } // A/B switch
+        b.prio = c->tune.scan_prio; // A/B switch
         const bool probe = fixed_base < 0 && !c->probe_pending && allow_alt >= 0 && base_alt != base && !bayer &&
                            (c->probe_age == 0 || c->probe_age >= 32);
         if (probe) {
@@ -612,8 +700,13 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
     launch_settle_tiles(a, s);
     prof_end(c, 4, s, p, on);
     HIP_TRY(hipGetLastError());
+    if (!a.dense) { // only now: settle (queued) has emptied the array the next batch's scan will widen
+        if (n_images > c->tile_rows_hold[c->tile_rows_flip]) c->tile_rows_hold[c->tile_rows_flip] = n_images;
+        c->tile_rows_hold[c->tile_rows_flip ^ 1] = 0;
+        c->tile_rows_flip ^= 1;
+    }
     a.timing = nullptr;
-    static const bool box_timing = getenv("MOCAP_BOX_TIMING") && atoi(getenv("MOCAP_BOX_TIMING")) != 0;
+    const bool box_timing = c->tune.box_timing != 0;
     if (box_timing) { // debugging aid: synchronous, prints the mean duration of the box kernel's phases
         HIP_TRY(hipMalloc(&a.timing, sizeof(uint64_t) * 6 * c->box_grid));
         HIP_TRY(hipMemsetAsync(a.timing, 0, sizeof(uint64_t) * 6 * c->box_grid, s));
@@ -621,7 +714,7 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
     prof_begin(c, 0, s, p, on);
     // MOCAP_WIDE_FORK=1: the wide-tile kernel on a side stream beside the box kernel (fork / join by events).  Measured: the pair takes
     // 0.53 ms instead of 0.49 alone and the three-batch pipeline 310k instead of 319k frames/s, so it is off.
-    const bool fork_wide = getenv("MOCAP_WIDE_FORK") && atoi(getenv("MOCAP_WIDE_FORK")) != 0;
+    const bool fork_wide = c->tune.wide_fork != 0;
     if (a.wide_tiles) { // the tiles with wide boxes: the row pipeline over their list, beside the box kernel (both only read what
                         // settle left and write disjoint tiles): forked onto the context's side stream, joined before the contours
         FilterArgs f;
@@ -639,13 +732,11 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
             HIP_TRY(hipStreamWaitEvent(c->side, c->ev_fork, 0));
             ws = c->side;
         }
-        static const bool skip_wide = getenv("MOCAP_EXPERIMENT_SKIP_WIDE") != nullptr; // timing experiments only
-        if (!skip_wide) launch_filter_tiles(f, remap, c->box_grid / 4 > 0 ? c->box_grid / 4 : 1, ws);
+        launch_filter_tiles(f, remap, c->box_grid / 4 > 0 ? c->box_grid / 4 : 1, ws);
         HIP_TRY(hipGetLastError());
         if (fork_wide) HIP_TRY(hipEventRecord(c->ev_join, c->side));
     }
-    static const bool skip_box = getenv("MOCAP_EXPERIMENT_SKIP_BOX") != nullptr; // timing experiments only: the mask is not written
-    if (!skip_box) launch_box_filter(a, c->box_grid, s);
+    launch_box_filter(a, c->box_grid, s);
     HIP_TRY(hipGetLastError());
     if (a.wide_tiles && fork_wide) HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
     prof_end(c, 0, s, p, on);
@@ -674,9 +765,7 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
 // sparse path ran (the general dense kernel keeps none); MOCAP_CONTOUR_BOXES=0: whole strips (A/B switch, same results)
 static const uint32_t* contour_boxes(mocap_ctx* c)
 {
-    const char* e = getenv("MOCAP_CONTOUR_BOXES");
-    const bool off = e && atoi(e) == 0;
-    return (c->mask_dirty || off) ? nullptr : c->cur_box;
+    return (c->mask_dirty || !c->tune.contour_boxes) ? nullptr : c->cur_box;
 }
 
 static int run_contours(mocap_ctx* c, const uint32_t* mask, const uint32_t* cells, const uint32_t* boxes, int n_images, int32_t* out_xy, long xy_stride,
@@ -705,22 +794,19 @@ static int run_contours(mocap_ctx* c, const uint32_t* mask, const uint32_t* cell
     a.work = c->cwork;
     // The split form (candidates per image -> all walks of the batch, 64 to a wave -> tree per image) is the default;
     // MOCAP_CONTOURS_SPLIT=0 runs the one-kernel-per-image form (A/B switch; same results).
-    const char* es = getenv("MOCAP_CONTOURS_SPLIT");
-    const bool split = !(es && atoi(es) == 0);
+    const bool split = c->tune.contours_split != 0;
     a.walk_list = split ? c->walk_list : nullptr; a.walk_count = c->walk_count;
     a.follow_grid = c->box_grid / 2 > 0 ? c->box_grid / 2 : 1; // 4 one-wave workgroups per CU (33 KB of LDS each)
-    a.prio = 0;
-    { const char* e = getenv("MOCAP_CONTOUR_PRIO"); if (e) a.prio = atoi(e); } // A/B switch (no effect measured)
+    a.prio = c->tune.contour_prio; // A/B switch (no effect measured)
     a.timing = nullptr;
-    static const bool phase_timing = getenv("MOCAP_CONTOUR_TIMING") && atoi(getenv("MOCAP_CONTOUR_TIMING")) != 0;
+    const bool phase_timing = c->tune.contour_timing != 0;
     if (phase_timing) { // debugging aid: synchronous, prints the mean duration of the kernel's phases
         HIP_TRY(hipMalloc(&a.timing, sizeof(uint64_t) * 8 * n_images));
         HIP_TRY(hipMemsetAsync(a.timing, 0, sizeof(uint64_t) * 8 * n_images, s));
     }
     EvPair p; bool on;
-    static const bool skip_contours = getenv("MOCAP_EXPERIMENT_SKIP_CONTOURS") != nullptr; // timing experiments only: results are stale
     prof_begin(c, 1, s, p, on);
-    if (!skip_contours) launch_contours(a, s);
+    launch_contours(a, s);
     prof_end(c, 1, s, p, on);
     HIP_TRY(hipGetLastError());
     if (phase_timing) {
@@ -776,7 +862,7 @@ static int ensure_mask(mocap_ctx* c, int n_images)
         HIP_TRY(hipMalloc(&c->tile_rows, 2 * sizeof(uint32_t) * init.size()));
         HIP_TRY(hipMemcpy(c->tile_rows, init.data(), sizeof(uint32_t) * init.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->tile_rows + init.size(), init.data(), sizeof(uint32_t) * init.size(), hipMemcpyHostToDevice));
-        c->tile_rows_flip = 0;
+        c->tile_rows_flip = 0; c->tile_rows_hold[0] = c->tile_rows_hold[1] = 0;
         for (size_t i = 0; i < init.size(); i++) init[i] = 1u;
         HIP_TRY(hipMalloc(&c->cur_box, sizeof(uint32_t) * init.size()));
         HIP_TRY(hipMemcpy(c->cur_box, init.data(), sizeof(uint32_t) * init.size(), hipMemcpyHostToDevice));
@@ -976,6 +1062,11 @@ int mocap_comm_unique_id(void* id_out)
     return MOCAP_OK;
 }
 
+int mocap_comm_available(void)
+{
+    return load_rccl();
+}
+
 int mocap_comm_init(mocap_ctx_t c, const void* id, int rank, int world)
 {
     if (!c || !id) return fail(MOCAP_E_INVALID, "null argument");
@@ -984,11 +1075,27 @@ int mocap_comm_init(mocap_ctx_t c, const void* id, int rank, int world)
     int rc = load_rccl();
     if (rc) return rc;
     if (set_device(c)) return MOCAP_E_HIP;
+    auto sc = std::make_shared<SharedComm>();
+    HIP_TRY(hipEventCreateWithFlags(&sc->last, hipEventDisableTiming));
     IdBytes idb;
     memcpy(idb.internal, id, sizeof(idb.internal));
-    void* comm = nullptr;
-    RCCL_TRY(g_rccl.CommInitRank(&comm, world, idb, rank));
-    c->comm = comm; c->comm_rank = rank; c->comm_world = world;
+    int r_ = g_rccl.CommInitRank(&sc->comm, world, idb, rank);
+    if (r_ != 0) {
+        (void)hipEventDestroy(sc->last);
+        return fail(MOCAP_E_HIP, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r_));
+    }
+    sc->rank = rank; sc->world = world; sc->device = c->device;
+    c->comm = sc;
+    return MOCAP_OK;
+}
+
+int mocap_comm_share(mocap_ctx_t dst, mocap_ctx_t src)
+{
+    if (!dst || !src) return fail(MOCAP_E_INVALID, "null context");
+    if (!src->comm) return fail(MOCAP_E_STATE, "the source context has no communicator");
+    if (dst->comm) return fail(MOCAP_E_STATE, "the context already has a communicator");
+    if (dst->device != src->device) return fail(MOCAP_E_INVALID, "contexts on different devices cannot share a communicator");
+    dst->comm = src->comm;
     return MOCAP_OK;
 }
 
@@ -996,9 +1103,14 @@ int mocap_comm_destroy(mocap_ctx_t c)
 {
     if (!c) return fail(MOCAP_E_INVALID, "null context");
     if (!c->comm) return MOCAP_OK;
-    if (set_device(c)) return MOCAP_E_HIP;
-    RCCL_TRY(g_rccl.CommDestroy(c->comm));
-    c->comm = nullptr; c->comm_world = 1; c->comm_rank = 0;
+    std::shared_ptr<SharedComm> sc = c->comm;
+    c->comm.reset();
+    if (sc.use_count() > 1) return MOCAP_OK; // other contexts of this rank still use it
+    (void)hipSetDevice(sc->device);
+    if (sc->have_last) (void)hipEventSynchronize(sc->last);
+    (void)hipEventDestroy(sc->last);
+    if (sc->comm && g_rccl.lib) RCCL_TRY(g_rccl.CommDestroy(sc->comm));
+    sc->comm = nullptr;
     return MOCAP_OK;
 }
 
@@ -1006,9 +1118,14 @@ int mocap_allgather_centroids(mocap_ctx_t c, const int32_t* local_records, int32
 {
     if (!c || !local_records || !gathered) return fail(MOCAP_E_INVALID, "null argument");
     if (ints_per_rank < 1) return fail(MOCAP_E_INVALID, "ints_per_rank = %ld", ints_per_rank);
-    if (!c->comm) return fail(MOCAP_E_STATE, "mocap_comm_init was not called for this context");
+    if (!c->comm) return fail(MOCAP_E_STATE, "mocap_comm_init / mocap_comm_share was not called for this context");
     if (set_device(c)) return MOCAP_E_HIP;
-    RCCL_TRY(g_rccl.AllGather(local_records, gathered, (size_t)ints_per_rank, 2 /* ncclInt32 */, c->comm, (hipStream_t)stream));
+    SharedComm& sc = *c->comm;
+    std::lock_guard<std::mutex> lk(sc.mu);
+    if (sc.have_last) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, sc.last, 0)); // after the communicator's previous all-gather
+    RCCL_TRY(g_rccl.AllGather(local_records, gathered, (size_t)ints_per_rank, 2 /* ncclInt32 */, sc.comm, (hipStream_t)stream));
+    HIP_TRY(hipEventRecord(sc.last, (hipStream_t)stream));
+    sc.have_last = true;
     return MOCAP_OK;
 }
 
@@ -1030,6 +1147,7 @@ int mocap_correspond(mocap_ctx_t c, const void* pts, long pt_st, long pt_sc, con
     // error scratch: the groups of one time step lie back to back, so a step needs room for its total, not P x max_groups;
     // a step with more than max(2 * max_groups, 8192) groups in all reports MOCAP_CORR_E_GROUPS
     size_t budget = 2 * (size_t)max_groups > 8192 ? 2 * (size_t)max_groups : 8192;
+    if (c->tune.corr_step_groups > 0) budget = (size_t)c->tune.corr_step_groups; // mocap_set_tuning(ctx, "corr_step_groups", n)
     if (budget > (size_t)P * max_groups) budget = (size_t)P * max_groups;
     if (budget > 0x7fffffff) budget = 0x7fffffff;
     size_t need = (size_t)T * budget;
@@ -1044,14 +1162,57 @@ int mocap_correspond(mocap_ctx_t c, const void* pts, long pt_st, long pt_sc, con
     a.pt_st = pt_st; a.pt_sc = pt_sc; a.cnt_st = cnt_st; a.cnt_sc = cnt_sc;
     a.cutoff = cutoff; a.max_groups = max_groups; a.root_xyz = root_xyz; a.root_err = root_err; a.root_grp = root_grp;
     a.root_idx = root_idx; a.order = order; a.n_roots = n_roots; a.scratch = c->scratch; a.step_budget = (int)budget;
-    a.prio = 0;
-    { const char* e = getenv("MOCAP_CORR_PRIO"); if (e) a.prio = atoi(e); } // A/B switch (no effect measured)
+    a.prio = c->tune.corr_prio; // A/B switch (no effect measured)
+    a.threads = c->tune.corr_threads;
     EvPair p; bool on;
-    static const bool skip_corr = getenv("MOCAP_EXPERIMENT_SKIP_CORR") != nullptr; // timing experiments only
     prof_begin(c, 2, (hipStream_t)stream, p, on);
-    if (!skip_corr) launch_correspond(a, (hipStream_t)stream);
+    launch_correspond(a, (hipStream_t)stream);
     prof_end(c, 2, (hipStream_t)stream, p, on);
     HIP_TRY(hipGetLastError());
+    return MOCAP_OK;
+}
+
+int mocap_epipolar_scores(mocap_ctx_t c, const void* roots, int n_roots, const void* cand, int n_cand, int pts_f64, int f_index,
+                          double* dist, float* lines, void* stream)
+{
+    if (!c || !roots || !cand || !dist) return fail(MOCAP_E_INVALID, "null argument");
+    if (n_roots < 1 || n_cand < 1 || (long long)n_roots * n_cand > 0x7fffffffLL) return fail(MOCAP_E_INVALID, "n_roots=%d n_cand=%d", n_roots, n_cand);
+    if (f_index < 0 || f_index >= c->n_F) return fail(MOCAP_E_STATE, "mocap_set_fundamentals: %d matrices set, index %d asked", c->n_F, f_index);
+    if (set_device(c)) return MOCAP_E_HIP;
+    EpiArgs a{c->cams, roots, cand, n_roots, n_cand, pts_f64, f_index, dist, lines};
+    launch_epipolar_scores(a, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return MOCAP_OK;
+}
+
+int mocap_ba_residuals(mocap_ctx_t c, const double* params_host, int B, const double* pts, const uint8_t* valid, int N, int C,
+                       float* residuals_host, int32_t* counts_host, void* stream)
+{
+    if (!c || !params_host || !pts || !valid || !residuals_host || !counts_host) return fail(MOCAP_E_INVALID, "null argument");
+    if (B < 1 || N < 1 || C < 2 || C > 32 || (long long)B * N > (1LL << 28)) return fail(MOCAP_E_INVALID, "B=%d N=%d C=%d", B, N, C);
+    if (c->n_cam < C) return fail(MOCAP_E_STATE, "mocap_set_cameras: %d cameras set, %d needed (their K and dist are used)", c->n_cam, C);
+    if (set_device(c)) return MOCAP_E_HIP;
+    std::lock_guard<std::mutex> lk(c->mu);
+    const size_t np_ = (size_t)B * 6 * (C - 1), pbytes = (sizeof(double) * np_ + 15) & ~(size_t)15;
+    const size_t rbytes = (sizeof(float) * (size_t)B * N + 15) & ~(size_t)15, need = pbytes + rbytes + sizeof(int32_t) * B;
+    if (need > c->ba_pinned_bytes) {
+        if (c->ba_pinned) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipHostFree(c->ba_pinned)); c->ba_pinned = nullptr; c->ba_pinned_bytes = 0; }
+        HIP_TRY(hipHostMalloc(&c->ba_pinned, need * 2));
+        c->ba_pinned_bytes = need * 2;
+    }
+    if ((size_t)B * N * 3 > c->ba_obj_elems) {
+        if (c->ba_obj) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c->ba_obj)); c->ba_obj = nullptr; c->ba_obj_elems = 0; }
+        HIP_TRY(hipMalloc(&c->ba_obj, sizeof(double) * (size_t)B * N * 3 * 2));
+        c->ba_obj_elems = (size_t)B * N * 3 * 2;
+    }
+    char* const pin = (char*)c->ba_pinned;
+    memcpy(pin, params_host, sizeof(double) * np_);
+    BaArgs a{c->cams, (const double*)pin, pts, valid, N, C, B, c->ba_obj, (float*)(pin + pbytes), (int32_t*)(pin + pbytes + rbytes)};
+    launch_ba_residuals(a, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream)); // the one wait of an evaluation: the kernel has written the pinned block
+    memcpy(residuals_host, a.res, sizeof(float) * (size_t)B * N);
+    memcpy(counts_host, a.counts, sizeof(int32_t) * B);
     return MOCAP_OK;
 }
 

@@ -99,34 +99,40 @@ __global__ __launch_bounds__(256) void settle_tiles_kernel(BoxArgs a)
 {
     const int lane = threadIdx.x & 63;
     const int tiles = a.n_chunks * a.n_strips;
-    const long long total = (long long)tiles * a.cam_mod * a.n_steps;
+    // the grid also covers the images beyond this batch whose boxes an earlier, larger batch may have left in the array the next
+    // batch's scan will widen (n_clear): they are emptied, nothing else happens for them
+    const int n_all = a.n_clear > a.n_images ? a.n_clear : a.n_images;
+    const int steps_all = (n_all + a.cam_mod - 1) / a.cam_mod;
+    const long long total = (long long)tiles * a.cam_mod * steps_all;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     // thread -> (tile, slot, time step), time fastest: the items of one tile of one camera lie together in the list, so
     // the waves that work at the same time share undistort-table lines (matters when every tile is filtered)
     int image = 0, chunk = 0, strip = 0;
     bool valid = i < total;
     if (valid) {
-        const int t = (int)(i % a.n_steps);
-        const long long rest = i / a.n_steps;
+        const int t = (int)(i % steps_all);
+        const long long rest = i / steps_all;
         const int slot = (int)(rest % a.cam_mod), tile = (int)(rest / a.cam_mod);
         image = t * a.cam_mod + slot;
         chunk = tile / a.n_strips; strip = tile - chunk * a.n_strips;
-        valid = image < a.n_images && chunk * a.rows_per_chunk < a.H;
+        valid = chunk * a.rows_per_chunk < a.H;
     }
     const size_t idx = ((size_t)image * a.n_chunks + chunk) * a.n_strips + strip;
+    if (valid && !a.dense && image < n_all) { // the buffer the NEXT batch's scan will widen -- read by the previous batch's settle -- is emptied
+        const uint4 nxt = *(const uint4*)(a.tile_rows_next + 4 * idx);
+        if (nxt.x <= nxt.y) *(uint4*)(a.tile_rows_next + 4 * idx) = make_uint4(0xffffffffu, 0u, 0xffffffffu, 0u);
+    }
+    valid = valid && image < a.n_images;
     const int tile_r0 = chunk * a.rows_per_chunk, tile_r1 = imin(tile_r0 + a.rows_per_chunk, a.H) - 1;
     const int tile_x0 = 240 * strip, tile_x1 = imin(tile_x0 + 239, a.W - 1);
     int bx0 = 0, bx1 = a.W - 1, by0 = 0, by1 = a.H - 1; // the scan's box: where exact pixels are needed / bits can be set
     bool marked = valid;
     uint4 raw = make_uint4(0xffffffffu, 0u, 0xffffffffu, 0u);
     if (valid && !a.dense) {
-        // the scan's boxes of this batch are only read here (neighbouring tiles look at each other's); the buffer the NEXT
-        // batch's scan will widen -- read by the previous batch's settle -- is emptied instead
+        // the scan's boxes of this batch are only read here (neighbouring tiles look at each other's)
         raw = *(const uint4*)(a.tile_rows + 4 * idx);
         marked = raw.x <= raw.y;
         if (marked) { by0 = (int)raw.x; by1 = (int)raw.y; bx0 = (int)raw.z; bx1 = (int)raw.w; }
-        const uint4 nxt = *(const uint4*)(a.tile_rows_next + 4 * idx);
-        if (nxt.x <= nxt.y) *(uint4*)(a.tile_rows_next + 4 * idx) = make_uint4(0xffffffffu, 0u, 0xffffffffu, 0u);
     }
     // output region of the tile: the box clipped to the tile, whole mask bytes
     int ox0 = imax(bx0, tile_x0) & ~7, ox1 = imin(imin(bx1, tile_x1) | 7, tile_x1);
@@ -730,7 +736,8 @@ __global__ __launch_bounds__(64) void box_filter_kernel(BoxArgs a)
 
 void launch_settle_tiles(const BoxArgs& a, hipStream_t s)
 {
-    const long long total = (long long)a.n_chunks * a.n_strips * a.cam_mod * a.n_steps;
+    const int n_all = a.n_clear > a.n_images ? a.n_clear : a.n_images;
+    const long long total = (long long)a.n_chunks * a.n_strips * a.cam_mod * ((n_all + a.cam_mod - 1) / a.cam_mod);
     hipLaunchKernelGGL(settle_tiles_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
 }
 

@@ -398,6 +398,132 @@ __global__ void reproject_kernel(ReprojArgs a)
     a.ok[n] = 1;
 }
 
+// The distance matrix of reference lib/Helpers.py:205-220 for one camera pair: line of root r = cv.computeCorrespondEpilines
+// of the float32 root point under F (:207), distance of candidate p to it by the expression of :217.  One lane per (root,
+// candidate) pair; the same `epiline` / `epi_distance` the correspondence kernel scores with.
+template <typename PT>
+__global__ __launch_bounds__(256) void epipolar_scores_kernel(EpiArgs a)
+{
+    const long w = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= (long)a.n_roots * a.n_cand) return;
+    const int r = (int)(w / a.n_cand), p = (int)(w - (long)r * a.n_cand);
+    double rx, ry, x, y;
+    load_pt<PT>(a.roots, (size_t)r, rx, ry);
+    load_pt<PT>(a.cand, (size_t)p, x, y);
+    float line[3];
+    epiline(a.cams->F[a.f_index], (float)rx, (float)ry, line);
+    a.dist[w] = epi_distance(line, x, y);
+    if (a.lines && p == 0) { a.lines[3 * r] = line[0]; a.lines[3 * r + 1] = line[1]; a.lines[3 * r + 2] = line[2]; }
+}
+
+// scipy Rotation.from_rotvec(v).as_matrix() (reference lib/Helpers.py:152): rotation vector -> unit quaternion -> matrix
+__device__ void rotvec_to_matrix(const double v[3], double Rm[9])
+{
+    const double angle = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    double scale;
+    if (angle <= 1e-3) {
+        const double a2 = angle * angle;
+        scale = 0.5 - a2 / 48 + a2 * a2 / 3840;
+    } else
+        scale = sin(angle / 2) / angle;
+    const double x = scale * v[0], y = scale * v[1], z = scale * v[2], w = cos(angle / 2);
+    const double x2 = x * x, y2 = y * y, z2 = z * z, w2 = w * w;
+    const double xy = x * y, zw = z * w, xz = x * z, yw = y * w, yz = y * z, xw = x * w;
+    Rm[0] = x2 - y2 - z2 + w2; Rm[1] = 2 * (xy - zw);        Rm[2] = 2 * (xz + yw);
+    Rm[3] = 2 * (xy + zw);        Rm[4] = -x2 + y2 - z2 + w2; Rm[5] = 2 * (yz - xw);
+    Rm[6] = 2 * (xz - yw);        Rm[7] = 2 * (yz + xw);        Rm[8] = -x2 - y2 + z2 + w2;
+}
+
+// bundle_adjustment.residual_function (reference lib/Helpers.py:161-167) for B parameter vectors, one workgroup each:
+// params_to_camera_poses (:145-156: camera 0 = identity / zero, cameras 1.. from rotvec + t sextuples) into LDS, then
+// triangulate_points (groups holding a None are skipped, :93), then calculate_reprojection_errors, which pairs groups and
+// object points POSITIONALLY (:104) and drops pairs seen by fewer than two cameras (:127-128), then the float32 cast (:165).
+// Both compactions are block-wide prefix counts, so the residual vector has the reference's length and order.
+__global__ __launch_bounds__(256) void ba_residuals_kernel(BaArgs a)
+{
+    __shared__ double sR[32][9], sT[32][3];
+    __shared__ int s_wave[4], s_base;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C = a.C, N = a.N;
+    const CameraTable* cams = a.cams;
+    if (tid < C) {
+        if (tid == 0) {
+            for (int k = 0; k < 9; k++) sR[0][k] = (k % 4 == 0) ? 1.0 : 0.0;
+            sT[0][0] = sT[0][1] = sT[0][2] = 0.0;
+        } else {
+            const double* p = a.params + (size_t)b * 6 * (C - 1) + 6 * (tid - 1);
+            const double v[3] = {p[0], p[1], p[2]};
+            double Rm[9];
+            rotvec_to_matrix(v, Rm);
+            for (int k = 0; k < 9; k++) sR[tid][k] = Rm[k];
+            sT[tid][0] = p[3]; sT[tid][1] = p[4]; sT[tid][2] = p[5];
+        }
+    }
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    double* const obj = a.obj + (size_t)b * N * 3;
+    // block-wide exclusive prefix of a flag over the 256 threads of one round; every thread calls it
+    auto place = [&](bool flag, int& total) -> int {
+        const uint64_t bal = __ballot(flag);
+        if (lane == 0) s_wave[wave] = __popcll(bal);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wave; w++) off += s_wave[w];
+        total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        return off + __popcll(bal & ((1ull << lane) - 1ull));
+    };
+    for (int n0 = 0; n0 < N; n0 += 256) { // triangulate_points: the groups without a None, in order
+        const int n = n0 + tid;
+        bool full = n < N;
+        if (full)
+            for (int c = 0; c < C; c++) full = full && a.valid[(size_t)n * C + c] != 0;
+        int total;
+        const int o = place(full, total);
+        if (full) {
+            DltAcc acc;
+            acc.clear();
+            for (int c = 0; c < C; c++)
+                acc.add(cams->K[c], sR[c], sT[c], a.pts[((size_t)n * C + c) * 2], a.pts[((size_t)n * C + c) * 2 + 1]);
+            double X[3];
+            acc.solve(X);
+            obj[3 * o] = X[0]; obj[3 * o + 1] = X[1]; obj[3 * o + 2] = X[2];
+        }
+        __syncthreads();
+        if (tid == 0) s_base += total;
+        __syncthreads();
+    }
+    const int nobj = s_base;
+    __threadfence_block(); // the object points are read back by other threads of this workgroup
+    __syncthreads();
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int n0 = 0; n0 < nobj; n0 += 256) { // zip(groups, object points): group n with object point n
+        const int n = n0 + tid;
+        bool has = n < nobj;
+        double mse = 0.0;
+        if (has) {
+            const float Xf[3] = {(float)obj[3 * n], (float)obj[3 * n + 1], (float)obj[3 * n + 2]};
+            double e[64];
+            int m = 0;
+            for (int c = 0; c < C; c++) {
+                if (!a.valid[(size_t)n * C + c]) continue;
+                reproj_sq(cams->K[m], cams->dist[m], sR[c], sT[c], Xf, a.pts[((size_t)n * C + c) * 2], a.pts[((size_t)n * C + c) * 2 + 1],
+                          e[2 * m], e[2 * m + 1]); // intrinsics by position after the None entries are dropped (:121-123,137-138)
+                m++;
+            }
+            has = m > 1;
+            if (has) mse = np_block_sum(e, 2 * m) / (double)(2 * m);
+        }
+        int total;
+        const int o = place(has, total);
+        if (has) a.res[(size_t)b * N + o] = (float)mse;
+        __syncthreads();
+        if (tid == 0) s_base += total;
+        __syncthreads();
+    }
+    if (tid == 0) a.counts[b] = s_base;
+}
+
 size_t correspond_smem_bytes(int P, int C)
 {
     return (size_t)P * C + (size_t)P * C * MAXM + 8 + sizeof(int) * (3 * (size_t)P + 2);
@@ -408,12 +534,22 @@ void launch_correspond(const CorrArgs& a, hipStream_t s)
     size_t sm = correspond_smem_bytes(a.P, a.C);
     // threads per time step (MOCAP_CORR_THREADS: A/B switch; one wave per step measured 0.064 against 0.051 ms alone and the
     // same in the three-batch pipeline)
-    static const int env_threads = getenv("MOCAP_CORR_THREADS") ? atoi(getenv("MOCAP_CORR_THREADS")) : 0;
-    const int threads = (env_threads == 64 || env_threads == 128 || env_threads == 256) ? env_threads : 256;
+    const int threads = (a.threads == 64 || a.threads == 128) ? a.threads : 256;
     if (a.pts_f64)
         hipLaunchKernelGGL(correspond_kernel<double>, dim3(a.T), dim3(threads), sm, s, a);
     else
         hipLaunchKernelGGL(correspond_kernel<int32_t>, dim3(a.T), dim3(threads), sm, s, a);
+}
+void launch_epipolar_scores(const EpiArgs& a, hipStream_t s)
+{
+    const long n = (long)a.n_roots * a.n_cand;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (a.pts_f64) hipLaunchKernelGGL(epipolar_scores_kernel<double>, dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(epipolar_scores_kernel<int32_t>, dim3(blocks), dim3(256), 0, s, a);
+}
+void launch_ba_residuals(const BaArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(ba_residuals_kernel, dim3(a.B), dim3(256), 0, s, a);
 }
 void launch_triangulate(const TriArgs& a, hipStream_t s)
 {

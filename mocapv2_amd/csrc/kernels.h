@@ -51,6 +51,7 @@ struct BoxArgs {
     uint32_t* tile_rows;        // [n_images][n_chunks][n_strips][4]: the scan's boxes of this batch (first / last row, first / last
                                 //   column; (0xffffffff, 0) = none), read-only for settle
     uint32_t* tile_rows_next;   // the same array for the next batch (the two alternate): emptied by settle
+    int n_clear;                // images whose boxes tile_rows_next may still hold (an earlier, larger batch): emptied too
     int cluster;                // 1 = a box spanning tiles that all hold it becomes one item (A/B switch)
     uint32_t* cur_box;          // [n_images][n_chunks][n_strips][4]: words 0-1 the tile's output region of this batch
                                 //   (x0 | x1 << 16, y0 | y1 << 16; x0 > x1 = none) = what the mask may hold there; words 2-3 the
@@ -198,6 +199,7 @@ struct CorrArgs {
     int32_t* order;            // [T][P]  argsort(root_err)
     int32_t* n_roots;          // [T]  (<0 = error)
     int prio;                  // wave priority (s_setprio 0..3), see ContourArgs
+    int threads;               // threads per time step: 64 / 128 / 256 (A/B switch; one wave per step measured 0.064 against 0.051 ms)
     double* scratch;           // [T][step_budget] per-group errors, the groups of a time step back to back in root order
     int step_budget;           // groups per time step the scratch holds
 };
@@ -222,10 +224,32 @@ struct ReprojArgs {
     int32_t* ok;               // [N]
 };
 
+struct EpiArgs {
+    const CameraTable* cams;
+    const void* roots;         // [n_roots][2] camera-0 points (int32 or float64)
+    const void* cand;          // [n_cand][2] points of the other camera
+    int n_roots, n_cand, pts_f64, f_index;
+    double* dist;              // [n_roots][n_cand]
+    float* lines;              // optional [n_roots][3]
+};
+
+struct BaArgs {
+    const CameraTable* cams;   // K and dist of cameras 0..C-1 (R, t come from the parameters)
+    const double* params;      // [B][6 (C - 1)] rotvec + t of cameras 1..C-1, device-accessible (pinned host memory is fine)
+    const double* pts;         // [N][C][2]
+    const uint8_t* valid;      // [N][C]
+    int N, C, B;
+    double* obj;               // scratch [B][N][3]
+    float* res;                // [B][N], the first counts[b] entries of row b are the residual vector
+    int32_t* counts;           // [B]
+};
+
 enum { CORR_ERR_GROUPS = -2, CORR_ERR_TRUNCATED = -3, CORR_ERR_BLOB = -4 };
 
 void launch_correspond(const CorrArgs& a, hipStream_t s);
 size_t correspond_smem_bytes(int P, int C);
+void launch_epipolar_scores(const EpiArgs& a, hipStream_t s);
+void launch_ba_residuals(const BaArgs& a, hipStream_t s);
 void launch_triangulate(const TriArgs& a, hipStream_t s);
 void launch_reproject(const ReprojArgs& a, hipStream_t s);
 

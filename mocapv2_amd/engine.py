@@ -71,6 +71,10 @@ class MocapContext:
         p = _abi.BlobParams(ksize, median, thresh, min_area, min_circ)
         _abi.check(self.lib.mocap_set_blob_params(self._h, C.byref(p)))
 
+    def set_tuning(self, name, value):
+        """One performance switch of this context (mocap_set_tuning; names in include/mocap_hip.h).  None changes a result."""
+        _abi.check(self.lib.mocap_set_tuning(self._h, name.encode(), int(value)))
+
     def set_undistort(self, slot, K, dist):
         K, Kp = _dbl(K, 9)
         d, dp = _dbl(dist, 5)
@@ -259,6 +263,21 @@ class MocapContext:
                                              _ptr(out["root"]), _ptr(out["order"]), _ptr(out["n"]), _stream()))
         return out
 
+    def epipolar_scores(self, roots, cand, f_index=0, with_lines=False):
+        """The scoring step of the correspondence search for one camera pair (reference lib/Helpers.py:205-220): roots [R, 2]
+        camera-0 points, cand [N, 2] points of camera f_index + 1 (host arrays, integer or float) -> distances [R, N] float64
+        (and the float32 lines [R, 3]) as host arrays.  Requires set_fundamentals."""
+        roots, cand = np.asarray(roots), np.asarray(cand)
+        f64 = not (roots.dtype.kind in "iu" and cand.dtype.kind in "iu")
+        dt = np.float64 if f64 else np.int32
+        d_r = torch.from_numpy(np.ascontiguousarray(roots, dt).reshape(-1, 2)).to(self.device)
+        d_c = torch.from_numpy(np.ascontiguousarray(cand, dt).reshape(-1, 2)).to(self.device)
+        dist = torch.empty((d_r.shape[0], d_c.shape[0]), dtype=torch.float64, device=self.device)
+        lines = torch.empty((d_r.shape[0], 3), dtype=torch.float32, device=self.device) if with_lines else None
+        _abi.check(self.lib.mocap_epipolar_scores(self._h, _ptr(d_r), d_r.shape[0], _ptr(d_c), d_c.shape[0], int(f64), int(f_index),
+                                                  _ptr(dist), _ptr(lines), _stream()))
+        return (dist.cpu().numpy(), lines.cpu().numpy()) if with_lines else dist.cpu().numpy()
+
     def triangulate_batch(self, pts, valid, compact_k=True):
         """pts [N, C, 2] float64 host array, valid [N, C] -> (xyz [N,3], ok [N]) host arrays."""
         pts = np.ascontiguousarray(pts, np.float64)
@@ -283,6 +302,10 @@ class MocapContext:
                                                   _ptr(mse), _ptr(ok), _stream()))
         return mse.cpu().numpy(), ok.cpu().numpy()
 
+    def ba_problem(self, pts, valid=None):
+        """Bundle-adjustment residuals with the image points resident on the GPU (see BAProblem)."""
+        return BAProblem(self, pts, valid)
+
     # ---- the exchange step (one all-gather of centroid records, RCCL over xGMI) -----------------------------------
     def comm_init(self, unique_id, rank, world):
         """Collective over all ranks: create this context's RCCL communicator from the bytes rank 0 got from
@@ -290,6 +313,16 @@ class MocapContext:
         buf = (C.c_char * _abi.COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
         _abi.check(self.lib.mocap_comm_init(self._h, C.cast(buf, C.c_void_p), int(rank), int(world)))
         self.comm_world = int(world)
+
+    def comm_share(self, src):
+        """Local: use the communicator of `src` (another context of this rank on the same GPU) -- one communicator per rank,
+        whatever the number of batches in flight; the library orders the all-gathers issued through it."""
+        _abi.check(self.lib.mocap_comm_share(self._h, src._h))
+        self.comm_world = src.comm_world
+
+    def comm_destroy(self):
+        _abi.check(self.lib.mocap_comm_destroy(self._h))
+        self.comm_world = 1
 
     def allgather_centroids(self, local, out=None):
         """local: this rank's centroid records (int32, contiguous, on this GPU) -> [world * len(local), ...] on every
@@ -320,6 +353,47 @@ class MocapContext:
         return {"filter_ms": ms[0], "filter_launches": n[0], "contour_ms": ms[1], "contour_launches": n[1],
                 "corr_ms": ms[2], "corr_launches": n[2], "scan_ms": ms[3], "scan_launches": n[3],
                 "settle_ms": ms[4], "settle_launches": n[4]}
+
+
+class BAProblem:
+    """The residual function of the reference's bundle adjustment (lib/Helpers.py:161-167) with everything that does not
+    change between evaluations kept on the GPU: image points [N, C, 2] and validity [N, C] are uploaded once, the
+    intrinsics live in the context's camera table (set_cameras), and an evaluation is one C-ABI call (mocap_ba_residuals:
+    one launch -- rotvec -> R, triangulation, reprojection, float32 cast on the device -- and one stream wait)."""
+
+    def __init__(self, ctx, pts, valid=None):
+        pts = np.ascontiguousarray(pts, np.float64)
+        assert pts.ndim == 3 and pts.shape[2] == 2, pts.shape
+        self.ctx, (self.N, self.C) = ctx, pts.shape[:2]
+        valid = np.ones((self.N, self.C), np.uint8) if valid is None else np.ascontiguousarray(valid, np.uint8).reshape(self.N, self.C)
+        self.d_pts = torch.from_numpy(pts).to(ctx.device)
+        self.d_valid = torch.from_numpy(valid).to(ctx.device)
+        self._res = np.empty((1, self.N), np.float32)
+        self._cnt = np.empty(1, np.int32)
+
+    def residuals(self, params):
+        """params: one parameter vector [6 (C - 1)] -> float32 residual vector, or a batch [B, 6 (C - 1)] -> list of
+        residual vectors (a vector is shorter than N only when groups hold [None, None] entries, as in the reference)."""
+        p = np.ascontiguousarray(params, np.float64)
+        single = p.ndim == 1
+        p = p.reshape(-1, 6 * (self.C - 1))
+        B = p.shape[0]
+        if self._res.shape[0] < B:
+            self._res = np.empty((B, self.N), np.float32)
+            self._cnt = np.empty(B, np.int32)
+        ctx = self.ctx
+        _abi.check(ctx.lib.mocap_ba_residuals(ctx._h, p.ctypes.data_as(C.POINTER(C.c_double)), B, _ptr(self.d_pts), _ptr(self.d_valid),
+                                              self.N, self.C, self._res.ctypes.data_as(C.POINTER(C.c_float)),
+                                              self._cnt.ctypes.data_as(C.POINTER(C.c_int)), _stream()))
+        if single:
+            return self._res[0, :self._cnt[0]].copy()
+        return [self._res[b, :self._cnt[b]].copy() for b in range(B)]
+
+
+def comm_available():
+    """Local check, no communication: can this process load RCCL (mocap_comm_available)?  Raises MocapError when not."""
+    _abi.check(_abi.load().mocap_comm_available())
+    return True
 
 
 def comm_unique_id():

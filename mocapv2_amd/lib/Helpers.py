@@ -155,12 +155,25 @@ def params_to_camera_poses(params, num_cameras=2):
 def bundle_adjustment(image_points, camera_poses):
     """reference :158-176.  The residual vector (triangulate every point, reproject, per-point MSE as float32) is
     evaluated on the GPU; the trust-region driver is SciPy's, as in the reference.  Two cameras are assumed inside
-    the residual, exactly as the reference hard-codes (:162,174)."""
+    the residual, exactly as the reference hard-codes (:162,174).  The image points are uploaded once and stay resident
+    (engine.BAProblem): an evaluation is one launch -- rotvec -> R, triangulation, reprojection and the float32 cast all
+    on the device -- and one D2H of N floats."""
     from scipy import optimize
     from scipy.spatial.transform import Rotation
 
+    read_camera_params()
+    groups = [list(g) for g in image_points]
+    problem = None
+    if len(groups) and all(len(g) == 2 for g in groups):
+        pts, valid = _pack_groups(groups, 2)
+        ctx = default_context()
+        _sync_cameras(ctx, params_to_camera_poses(np.zeros(6), 2))  # K and dist of cameras 0 and 1 (poses come from the parameters)
+        problem = ctx.ba_problem(pts, valid)
+
     def residual_function(params):
-        poses = params_to_camera_poses(params, 2)
+        if problem is not None:
+            return problem.residuals(np.asarray(params, float)[:6])
+        poses = params_to_camera_poses(params, 2)  # groups of another width: the reference's own call chain
         object_points = triangulate_points(image_points, poses)
         errors = calculate_reprojection_errors(image_points, object_points, poses)
         return errors.astype(np.float32)

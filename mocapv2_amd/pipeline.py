@@ -55,9 +55,88 @@ def allgather_records(local, world, group=None, force=False):
     return out
 
 
+def negotiate_rccl(world, rank, prepare, unique_id, comm_init, share, destroy, release, dist=None, group=None, flag_device="cpu"):
+    """Set up the RCCL exchange on every rank or on none: True when all ranks hold a communicator, False when all must take
+    the torch.distributed road instead.  A rank that fails never leaves its peers inside a collective it does not enter:
+      1. `prepare()` -- everything that can fail locally (librccl loadable, buffers allocated) -- runs BEFORE any collective,
+         and its outcome is agreed on (all-reduce MIN) before any rank goes on;
+      2. rank 0's `unique_id()` travels in ONE broadcast that every rank enters whatever happened (zeros = failed), and the
+         outcome is agreed on again;
+      3. only then every rank calls `comm_init(uid)` (ncclCommInitRank: collective inside RCCL, all ranks are in it), and the
+         outcome is agreed on a third time; ranks that did get a communicator `destroy()` it when a peer did not;
+      4. `share()` (local) hands the communicator to the rank's other batches in flight.
+    `dist`: torch.distributed (or a stand-in with broadcast / all_reduce / ReduceOp / get_global_rank) when world > 1, else None.
+    The callables are injected so that the agreement logic is tested with gloo on CPUs (tests/test_pipeline_sharding.py)."""
+    import sys
+    from . import _abi
+
+    def say(what, e):
+        print(f"[mocapv2_amd] rank {rank}: {what} failed ({e}); exchanging through torch.distributed instead", file=sys.stderr)
+
+    def agree(ok):
+        if dist is None:
+            return ok
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=flag_device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        return bool(flag.item())
+
+    try:
+        prepare()
+        ok = True
+    except Exception as e:  # noqa: BLE001
+        say("preparing the RCCL exchange", e)
+        ok = False
+    if not agree(ok):
+        release()
+        return False
+    uid = None
+    if dist is None:
+        try:
+            uid = unique_id()
+        except Exception as e:  # noqa: BLE001
+            say("mocap_comm_unique_id", e)
+    else:
+        box = torch.zeros(_abi.COMM_ID_BYTES, dtype=torch.uint8, device=flag_device)
+        if rank == 0:
+            try:
+                box.copy_(torch.frombuffer(bytearray(unique_id()), dtype=torch.uint8))
+            except Exception as e:  # noqa: BLE001 -- the broadcast below still runs (every rank is waiting in it) and carries zeros
+                say("mocap_comm_unique_id", e)
+        dist.broadcast(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        raw = bytes(box.cpu().numpy().tobytes())
+        uid = raw if any(raw) else None
+    if not agree(uid is not None):
+        release()
+        return False
+    have = False
+    try:
+        comm_init(uid)
+        have = True
+    except Exception as e:  # noqa: BLE001
+        say("mocap_comm_init", e)
+    if not agree(have):
+        if have:
+            destroy()
+        release()
+        return False
+    try:
+        share()
+        shared = True
+    except Exception as e:  # noqa: BLE001
+        say("mocap_comm_share", e)
+        shared = False
+    if not agree(shared):
+        destroy()
+        release()
+        return False
+    return True
+
+
 # per-time-step status codes of the correspondence kernel (include/mocap_hip.h MOCAP_CORR_E_*)
 CORR_STATUS = {
-    -2: "more candidate groups than the correspondence kernel's capacity (MOCAP_CORR_E_GROUPS)",
+    -2: "more candidate groups than the correspondence kernel's capacity (MOCAP_CORR_E_GROUPS): more than 16 candidates for "
+        "one (root, camera), more than max_groups groups for one root (raise max_groups), or more groups in the whole time "
+        "step than max(2 * max_groups, 8192) (raise it with MocapContext.set_tuning('corr_step_groups', n))",
     -3: "a camera holds more image points than the tracker's max_points (MOCAP_CORR_E_TRUNCATED): raise max_points",
     -4: "a camera's blob stage exceeded an internal capacity (MOCAP_CORR_E_BLOB; its record count holds the MOCAP_BLOB_E_* code)",
 }
@@ -103,8 +182,9 @@ class BatchTracker:
                  max_points=32, max_groups=4096, depth=1, bayer_pattern=None, gray_shift=GRAY_SHIFT, collective="auto",
                  force_collective=False):
         """collective: how the centroid records are exchanged when world > 1 --
-             "rccl"  mocap_allgather_centroids: ncclAllGather called by the library on the batch's own HIP stream, one
-                     communicator per batch in flight (its unique id travels through torch.distributed once, at set-up);
+             "rccl"  mocap_allgather_centroids: ncclAllGather called by the library on the batch's own HIP stream; ONE
+                     communicator per rank, shared by the batches in flight (the library chains their all-gathers with
+                     an event); its unique id travels through torch.distributed once, at set-up (negotiate_rccl);
              "torch" torch.distributed (all_gather_into_tensor on nccl = RCCL, or gloo through the host);
              "auto"  "rccl" when the process group's backend is nccl, else "torch".
            force_collective: run the exchange even with world == 1 (a one-rank all-gather; tests)."""
@@ -154,45 +234,33 @@ class BatchTracker:
         if collective == "torch":
             return "torch"
         assert collective == "rccl", collective
-        from .engine import comm_unique_id
-        from . import _abi
+        from .engine import comm_available, comm_unique_id
         dev = self.lanes[0].ctx.device
-        ok = True
-        for lane in self.lanes:  # same order on every rank: communicator creation is collective
-            try:
-                if self.world == 1:
-                    uid = comm_unique_id()
-                else:
-                    on_gpu = dist.get_backend(self.group) == "nccl"
-                    box = torch.zeros(_abi.COMM_ID_BYTES, dtype=torch.uint8, device=dev if on_gpu else "cpu")
-                    if self.rank == 0:
-                        try:
-                            box.copy_(torch.frombuffer(bytearray(comm_unique_id()), dtype=torch.uint8))
-                        except Exception as e:  # noqa: BLE001 -- the broadcast below still runs (every rank is waiting in it) and carries zeros
-                            import sys
-                            print(f"[mocapv2_amd] rank 0: mocap_comm_unique_id failed ({e})", file=sys.stderr)
-                    dist.broadcast(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
-                    uid = bytes(box.cpu().numpy().tobytes())
-                    if not any(uid):
-                        raise RuntimeError("rank 0 could not create a communicator id")
-                lane.ctx.comm_init(uid, self.rank, self.world)
+        on_gpu = have_pg and dist.get_backend(self.group) == "nccl"
+        flag_dev = dev if on_gpu else "cpu"
+        first = self.lanes[0].ctx
+
+        def prepare():  # local: RCCL loadable here, room for every lane's gathered records
+            comm_available()
+            for lane in self.lanes:
                 lane.gathered = torch.empty((self.world * self.per, self.rec_ints), dtype=torch.int32, device=dev)
-            except Exception as e:  # noqa: BLE001 -- e.g. librccl not loadable: say so, and let every rank take the same road
-                import sys
-                print(f"[mocapv2_amd] rank {self.rank}: mocap_comm_init failed ({e}); exchanging through torch.distributed instead",
-                      file=sys.stderr)
-                ok = False
-                break
-        if self.world > 1 and have_pg:  # all ranks must agree on the transport
-            on_gpu = dist.get_backend(self.group) == "nccl"
-            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if on_gpu else "cpu")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
-            ok = bool(flag.item())
-        if not ok:
+
+        def release():
             for lane in self.lanes:
                 lane.gathered = None
-            return "torch"
-        return "rccl"
+
+        def share():    # local: the other batches in flight use the same communicator
+            for lane in self.lanes[1:]:
+                lane.ctx.comm_share(first)
+
+        def destroy():
+            for lane in self.lanes:
+                lane.ctx.comm_destroy()
+
+        ok = negotiate_rccl(self.world, self.rank, prepare=prepare, unique_id=comm_unique_id,
+                            comm_init=lambda uid: first.comm_init(uid, self.rank, self.world), share=share, destroy=destroy,
+                            release=release, dist=dist if (self.world > 1 and have_pg) else None, group=self.group, flag_device=flag_dev)
+        return "rccl" if ok else "torch"
 
     # the buffers of the batch most recently submitted
     @property

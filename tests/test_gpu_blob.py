@@ -268,12 +268,8 @@ def test_context_mask_stays_consistent_across_batches(torch_cuda, scale):
     batches.append(dark_frames(rng, 4, H, W, n_discs=6, salt=0.0))
     seen = 0
     for b, frames in enumerate(batches):
-        if b == 4:
-            os.environ["MOCAP_SKIP_DARK"] = "0"
-        try:
-            xy, cnt = ctx.record_views(ctx.blob_centroids(torch.from_numpy(frames).cuda()))
-        finally:
-            os.environ.pop("MOCAP_SKIP_DARK", None)
+        ctx.set_tuning("skip_dark", 0 if b == 4 else 1)  # one batch with the early-out off, on the live context
+        xy, cnt = ctx.record_views(ctx.blob_centroids(torch.from_numpy(frames).cuda()))
         xy, cnt = xy.cpu().numpy(), cnt.cpu().numpy()
         for i in range(len(frames)):
             exp = oracle.find_dot(frames[i], sc.K, sc.dist)
@@ -281,6 +277,47 @@ def test_context_mask_stays_consistent_across_batches(torch_cuda, scale):
             assert xy[i, :cnt[i]].tolist() == exp, (b, i)
             seen += len(exp)
     assert seen > 10
+
+
+@pytest.mark.parametrize("scale", [0.0, 1.0])
+def test_batches_of_varying_size_on_one_context(torch_cuda, scale):
+    """Alternating n_images on one context (what BatchTracker.extract does per camera segment when world > 1): the boxes an
+    earlier, larger batch left in the scan's alternate array for the images beyond a smaller batch must not survive into
+    the next large one.  Results equal the oracle's, and the early-out resolves as many tiles in the last large batch as a
+    fresh context does for the same frames (stale boxes would only cost tiles, never exactness)."""
+    torch = torch_cuda
+    from mocapv2_amd.engine import MocapContext
+    W, H = 960, 540
+    sc = Scene(1, width=W, height=H, dist=np.array(MILD_DIST) * scale)
+    rng = np.random.default_rng(31)
+    big = [dark_frames(rng, 6, H, W, n_discs=5, salt=0.0) for _ in range(4)]
+    sizes = [6, 6, 2, 1, 6, 3, 6]
+    ctx = MocapContext(W, H, n_slots=1)
+    ctx.set_undistort(0, sc.K, sc.dist)
+    stats = None
+    for b, n in enumerate(sizes):
+        frames = big[b % 4][:n]
+        xy, cnt = ctx.record_views(ctx.blob_centroids(torch.from_numpy(frames).cuda()))
+        xy, cnt = xy.cpu().numpy(), cnt.cpu().numpy()
+        for i in range(n):
+            exp = oracle.find_dot(frames[i], sc.K, sc.dist)
+            assert cnt[i] == len(exp) and xy[i, :cnt[i]].tolist() == exp, (b, i)
+        stats = ctx.tile_stats()
+    fresh = MocapContext(W, H, n_slots=1)
+    fresh.set_undistort(0, sc.K, sc.dist)
+    fresh.blob_centroids(torch.from_numpy(big[(len(sizes) - 1) % 4][:sizes[-1]]).cuda())
+    assert stats == fresh.tile_stats() and stats[1] > 0.5 * stats[0], (stats, fresh.tile_stats())
+
+
+def test_set_tuning_rejects_unknown_names(torch_cuda):
+    from mocapv2_amd._abi import MocapError
+    from mocapv2_amd.engine import MocapContext
+    ctx = MocapContext(64, 64)
+    ctx.set_tuning("wide_bands", 3)
+    with pytest.raises(MocapError):
+        ctx.set_tuning("experiment_skip_box", 1)  # the work-skipping switches of round 2 are gone
+    with pytest.raises(MocapError):
+        ctx.set_tuning("rows", 32)  # shapes the context's buffers: environment only, before mocap_ctx_create
 
 
 def test_mixed_identity_and_remapped_cameras_in_one_batch(torch_cuda):

@@ -129,3 +129,43 @@ def test_dense_correspond_rejects_counts_beyond_capacity():
     out = ctx.correspond(torch.from_numpy(pts).cuda(), torch.from_numpy(cnt).cuda())
     n = out["n"].cpu().numpy()
     assert n[0] == 5 and n[1] == -3 and n[2] == -4 and n[3] >= 0
+
+
+def test_many_roots_of_moderate_group_counts_and_the_step_budget():
+    """A time step whose roots each stay far below max_groups but whose groups add up beyond the default per-step share of the
+    error scratch (max(2 * max_groups, 8192)): reported as MOCAP_CORR_E_GROUPS with the default, answered -- equal to the
+    oracle, which has no such limit (like the reference, lib/Helpers.py:239-245) -- once corr_step_groups is raised."""
+    import torch
+    import oracle
+    from mocapv2_amd.engine import MocapContext
+    C, P = 4, 24
+    sc = Scene(C, dist=ZERO_DIST)
+    K, dist = np.stack([sc.K] * C), np.stack([sc.dist] * C)
+    R, t = np.stack([p["R"] for p in sc.poses]), np.stack([p["t"] for p in sc.poses])
+    F = np.stack(sc.Fs)
+    # three groups of 8 camera-0 roots a few pixels apart; in every other camera 8 points along each group's epipolar line:
+    # every root sees 8 candidates per camera -> 8^3 = 512 groups (far below max_groups), 24 roots -> 12 288 in the time step
+    pts = np.zeros((1, C, P, 2), np.int32)
+    cnt = np.full((1, C), P, np.int32)
+    for g in range(3):
+        for k in range(8):
+            pts[0, 0, 8 * g + k] = (500 + 400 * g + k // 2, 300 + 200 * g + k % 2)
+    for i in range(1, C):
+        for g in range(3):
+            a, b, c = oracle.epiline(F[i - 1], *pts[0, 0, 8 * g + 3]).astype(float)
+            d = a * 960 + b * 540 + c
+            for m in range(8):
+                pts[0, i, 8 * g + m] = np.round([960 - a * d - b * 40 * (m - 3.5), 540 - b * d + a * 40 * (m - 3.5)])
+    ref = oracle.correspond(pts[0].astype(float), cnt[0], K, dist, R, t, F)
+    ctx = MocapContext(1, 1)
+    ctx.set_cameras(K, dist, R, t)
+    ctx.set_fundamentals(F)
+    d_pts, d_cnt = torch.from_numpy(pts).cuda(), torch.from_numpy(cnt).cuda()
+    n = int(ctx.correspond(d_pts, d_cnt, max_groups=2048)["n"].cpu()[0])
+    assert n == -2  # every root below max_groups, the step's total above max(2 * 2048, 8192)
+    ctx.set_tuning("corr_step_groups", 1 << 18)
+    out = {k: v.cpu().numpy() for k, v in ctx.correspond(d_pts, d_cnt, max_groups=2048).items()}
+    k = int(out["n"][0])
+    assert k == len(ref["root"]) and k > 0
+    assert np.array_equal(out["grp"][0, :k], ref["groups"]) and np.abs(out["xyz"][0, :k] - ref["xyz"]).max() < 1e-7
+    assert np.array_equal(out["order"][0, :k], ref["order"])

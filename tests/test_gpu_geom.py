@@ -111,6 +111,51 @@ def test_ba_residual_vector(helpers):
         assert e.shape == r.shape and np.allclose(e, r, rtol=2e-5, atol=1e-6)
 
 
+def test_resident_ba_residuals_match_the_reference_fixture_and_the_oracle():
+    """mocap_ba_residuals (image points resident, rotvec -> R / triangulation / reprojection / float32 cast in one launch):
+    the reference-generated residual vectors of tests/golden/ba_residuals.npz (lib/Helpers.py:161-167 run by
+    oracle/gen_golden.py), one vector at a time and all of them as one batch; then 16 cameras x 64 points with [None, None]
+    holes -- groups with a hole are not triangulated (:93) and the zip pairs what is left positionally (:104) -- against
+    the oracle.  Tolerance: the residuals are float32 (rtol 2e-5: one float32 ulp of the MSE after the FP64 chain)."""
+    from mocapv2_amd.engine import MocapContext
+    g = load("ba_residuals")
+    ctx = MocapContext(1, 1)
+    ctx.set_cameras(g["K"], g["dist"], np.stack([np.eye(3)] * 2), np.zeros((2, 3)))
+    prob = ctx.ba_problem(g["image_points"])
+    for x, r in zip(g["params"], g["residuals"]):
+        e = prob.residuals(x)
+        assert e.dtype == np.float32 and e.shape == r.shape and np.allclose(e, r, rtol=2e-5, atol=1e-6)
+    batch = prob.residuals(np.stack(g["params"]))
+    for e, r in zip(batch, g["residuals"]):
+        assert np.allclose(e, r, rtol=2e-5, atol=1e-6)
+    # 16 cameras, 64 points, holes
+    C, M = 16, 64
+    sc = Scene(C, 3840, 2160, dist=MILD_DIST, radius=4.0)
+    K, dist = np.stack([sc.K] * C), np.stack([sc.dist] * C)
+    R, t = np.stack([p["R"] for p in sc.poses]), np.stack([p["t"] for p in sc.poses])
+    rng = np.random.default_rng(8)
+    cents = sc.centroids(sc.markers(rng, M, extent=1.2), rng, jitter=0.3)
+    pts = np.stack([np.stack([cents[c][m] for c in range(C)]) for m in range(M)]).astype(float)
+    from scipy.spatial.transform import Rotation
+    base = []
+    for c in range(1, C):
+        Rrel = R[c] @ R[0].T
+        base += list(Rotation.from_matrix(Rrel).as_rotvec()) + list(t[c] - Rrel @ t[0])
+    sets = np.array(base) + rng.normal(0, 1e-3, (5, 6 * (C - 1)))
+    ctx.set_cameras(K, dist, R, t)
+    for holes in (0, 9):
+        valid = np.ones((M, C), np.uint8)
+        for _ in range(holes):
+            valid[rng.integers(M), rng.integers(C)] = 0
+        valid[3, :] = 0 if holes else 1      # a group nobody sees
+        valid[7, 1:] = 0 if holes else 1     # a group seen by one camera only
+        prob = ctx.ba_problem(pts, valid)
+        got = prob.residuals(sets)
+        for x, e in zip(sets, got):
+            exp = oracle.ba_residuals(x, C, pts, valid, K, dist)
+            assert e.shape == exp.shape and len(exp) > 40 and np.allclose(e, exp, rtol=2e-5, atol=1e-6), holes
+
+
 @pytest.mark.parametrize("C,M,T", [(2, 5, 4), (6, 8, 16), (6, 32, 8), (8, 16, 4)])
 def test_batched_correspond_matches_oracle(C, M, T):
     import torch

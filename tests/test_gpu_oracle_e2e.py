@@ -1,0 +1,190 @@
+"""Frame -> 3-D parity of the batched layers against the CPU oracle (never against another HIP call):
+BatchTracker at BASELINE.json configs[2] size, ReplayTracker per time step, and the configs[3] layout (8 cameras, one per
+rank, camera-major blocks + gathered records) emulated on one GPU.  Reference: RealtimeTracking_FLIR.py:95-143,157-209
+(the loops), lib/ImageOperations.py:33-78 (_find_dot), lib/Helpers.py:178-280 (correspondence + triangulation)."""
+import numpy as np
+import pytest
+
+import oracle
+from mocapv2_amd.synth import MILD_DIST, Scene
+
+pytestmark = pytest.mark.gpu
+
+TOL_XYZ = 1e-7  # world units = 1e-4 mm (BASELINE.json)
+
+
+def oracle_step(frames_c, K, dist, R, t, F, max_groups=1 << 22):
+    """One time step through the oracle: frames_c [C, H, W] -> (image point lists per camera, correspondence result or None
+    when the reference's cartesian expansion exceeds max_groups)."""
+    C = len(frames_c)
+    lists = [oracle.find_dot(frames_c[c], K[c], dist[c]) for c in range(C)]
+    P = max(1, max(len(l) for l in lists))
+    pts = np.zeros((C, P, 2))
+    cnt = np.zeros(C, np.int32)
+    for c, l in enumerate(lists):
+        cnt[c] = len(l)
+        if l:
+            pts[c, :len(l)] = l
+    try:
+        res = oracle.correspond(pts, cnt, K, dist, R, t, F, max_groups=max_groups)
+    except RuntimeError:
+        res = None
+    return lists, res
+
+
+def assert_records_equal(records, i, exp, where):
+    n = int(records[i, 0])
+    assert n == len(exp), (where, n, len(exp))
+    assert records[i, 2:2 + 2 * n].reshape(-1, 2).tolist() == [list(p) for p in exp], where
+
+
+def assert_step_equal(out, s, ref, where):
+    """out: host arrays of MocapContext.correspond; ref: oracle.correspond's dict"""
+    k = int(out["n"][s])
+    assert k == len(ref["root"]), (where, k, len(ref["root"]))
+    if k == 0:
+        return 0
+    assert np.array_equal(out["root"][s, :k], ref["root"]), where
+    assert np.array_equal(out["grp"][s, :k], ref["groups"]), where            # image points / marker indices: bit-exact
+    assert np.abs(out["xyz"][s, :k] - ref["xyz"]).max() < TOL_XYZ, where      # 3-D: 1e-4 mm
+    assert np.array_equal(out["order"][s, :k], ref["order"]), where
+    return k
+
+
+def test_batch_tracker_configs2_frames_match_oracle():
+    """BASELINE.json configs[2]: 6 cameras x 1920x1080, 32 markers, frames -> centroids -> correspondence -> DLT in one
+    BatchTracker.step, against oracle.find_dot + oracle.correspond.  Time step 1 holds two markers 3 cm apart: their discs
+    merge into one long-bordered blob in every camera (the case the border-following stage pays most for)."""
+    import torch
+    from mocapv2_amd.pipeline import BatchTracker, scene_arrays
+    C, T, M, W, H = 6, 2, 32, 1920, 1080
+    sc = Scene(C, W, H, dist=MILD_DIST)
+    K, dist, R, t, F = scene_arrays(sc)
+    frames = np.empty((T, C, H, W), np.uint8)
+    for s in range(T):
+        rng = np.random.default_rng(4200 + s)
+        mk = sc.markers(rng, M)
+        if s == 1:
+            mk[1] = mk[0] + np.array([0.03, 0.0, 0.0])
+        for c in range(C):
+            frames[s, c] = sc.render(np.random.default_rng((4200 + s) * 64 + c), mk, c, radius_range=(16.0, 22.0), salt=0.001)
+    max_groups = 4096
+    trk = BatchTracker(K, dist, R, t, F, W, H, T, max_points=2 * M, max_groups=max_groups)
+    out = trk.step(torch.from_numpy(frames.reshape(T * C, H, W)).cuda())
+    torch.cuda.synchronize()
+    rec = trk.records.cpu().numpy()
+    out = {k: v.cpu().numpy() for k, v in out.items()}
+    merged = False
+    points = 0
+    for s in range(T):
+        lists, ref = oracle_step(frames[s], K, dist, R, t, F, max_groups=max_groups)
+        for c in range(C):
+            assert_records_equal(rec, s * C + c, lists[c], (s, c))
+            merged |= s == 1 and len(lists[c]) < M
+        if ref is None:  # the reference's expansion beyond max_groups: the kernel must give the step up too
+            assert out["n"][s] == -2, s
+            continue
+        points += assert_step_equal(out, s, ref, s)
+    assert merged and points >= 8  # the merged pair was seen as one blob, and the steps produced 3-D points (a root needs a
+    # match in every other camera to be triangulated: about a third of 32 markers are, lib/Helpers.py:93)
+
+
+def test_replay_tracker_matches_oracle_per_time_step():
+    """ReplayTracker.run against the oracle per time step: object points = the obj_count + 1 best roots
+    (lib/Helpers.py:274-279), image points of all surviving roots, and the msgpack message with the previous point
+    repeated when a time step yields nothing (RealtimeTracking_FLIR.py:181-188)."""
+    from mocapv2_amd.pipeline import scene_arrays
+    from mocapv2_amd.replay import ReplayTracker, tracker_message
+    C, T, W, H = 3, 7, 640, 360
+    sc = Scene(C, W, H, dist=MILD_DIST)
+    K, dist, R, t, F = scene_arrays(sc)
+    n_markers = [8, 8, 0, 3, 8, 1, 8]  # more roots than obj_count + 1, none, fewer than obj_count, a single one
+    frames = np.empty((T, C, H, W), np.uint8)
+    for s in range(T):
+        rng = np.random.default_rng(900 + s)
+        mk = sc.markers(rng, max(1, n_markers[s]), extent=0.4)[:n_markers[s]]
+        for c in range(C):
+            frames[s, c] = sc.render(np.random.default_rng(9000 + 10 * s + c), mk, c, radius_range=(14.0, 17.0), salt=0.001)
+    obj_count = 4
+    got = list(ReplayTracker(K, dist, R, t, F, W, H, batch=4, obj_count=obj_count).run(frames))  # 7 steps: one padded batch
+    assert len(got) == T
+    point = [0, 0, 0, 0, 0, 0, 0, 0]  # RealtimeTracking_FLIR.py:171
+    sizes = []
+    for s in range(T):
+        lists, ref = oracle_step(frames[s], K, dist, R, t, F)
+        if len(ref["root"]) == 0:
+            obj, img = np.array([]), np.array([])
+        else:
+            obj, img = oracle.select_objects(ref, obj_count)
+        assert got[s]["object_points"].shape == obj.shape, (s, got[s]["object_points"].shape, obj.shape)
+        assert got[s]["image_points"].shape == img.shape, s
+        if len(obj):
+            assert np.abs(got[s]["object_points"] - obj).max() < TOL_XYZ, s
+            assert np.array_equal(got[s]["image_points"], img.astype(np.int64)), s
+            point = [0, 0, 0, 0] + list(got[s]["object_points"][0])
+            assert np.abs(np.array(point[4:]) - obj[0]).max() < TOL_XYZ
+        assert got[s]["message"] == tracker_message(point), s
+        sizes.append(len(obj))
+    assert sizes[0] == obj_count + 1 and sizes[2] == 0 and 0 < sizes[3] <= 3, sizes
+    assert got[2]["message"] == got[1]["message"]  # nothing found: the previous message again
+
+
+def test_eight_cameras_one_per_rank_layout_matches_oracle():
+    """BASELINE.json configs[3]'s layout on one GPU: 8 cameras, world = 8, every 'rank' extracts the centroids of its
+    camera-major block (one whole camera, slot_base launches), the all-gather is replaced by the concatenation it produces,
+    every rank triangulates its own slice of the time steps through the strided reads of the gathered records -- and every
+    record and every time step is compared with the oracle."""
+    import torch
+    from mocapv2_amd.pipeline import BatchTracker, scene_arrays
+    C, T, W, H, world = 8, 1, 640, 360, 8
+    sc = Scene(C, W, H, dist=MILD_DIST)
+    K, dist, R, t, F = scene_arrays(sc)
+    t_total = T * world
+    markers = [sc.markers(np.random.default_rng(300 + s), 6, extent=0.5) for s in range(t_total)]
+
+    def frame(c, s):
+        return sc.render(np.random.default_rng(3000 + 10 * s + c), markers[s], c, radius_range=(14.0, 17.0), salt=0.001)
+
+    trackers = [BatchTracker(K, dist, R, t, F, W, H, T, world=world, rank=r) for r in range(world)]
+    recs = []
+    for r, trk in enumerate(trackers):
+        images = trk.local_image_list()
+        assert {c for c, _ in images} == {r} and len(images) == t_total  # one camera per rank, all its time steps
+        fr = np.stack([frame(c, s) for c, s in images])
+        rec = trk.extract(torch.from_numpy(fr).cuda()).clone()
+        host = rec.cpu().numpy()
+        for i, (c, s) in enumerate(images):
+            assert_records_equal(host, i, oracle.find_dot(fr[i], K[c], dist[c]), (r, c, s))
+        recs.append(rec)
+    gathered = torch.cat(recs, dim=0)  # rank order = camera-major order: what ncclAllGather leaves on every rank
+    points = 0
+    for r, trk in enumerate(trackers):
+        out = {k: v.cpu().numpy() for k, v in trk.triangulate(gathered).items()}
+        for j in range(T):
+            s = r * T + j
+            lists, ref = oracle_step(np.stack([frame(c, s) for c in range(C)]), K, dist, R, t, F)
+            points += assert_step_equal(out, j, ref, (r, s))
+    assert points >= 4 * t_total
+
+
+def test_epipolar_scores_k2_bundled_pairs():
+    """K2: the reference's 54 captured 2-camera correspondences under jsons/fundamentals.json[0], scored
+    by the kernel's own epiline / distance functions through the C-ABI (mocap_epipolar_scores): equal to the fixture the
+    reference produced (tests/golden/k1_bundled.npz:epi_dist), bit for bit, and all below the 10 px cutoff
+    (lib/Helpers.py:205-220)."""
+    import os
+    from mocapv2_amd.engine import MocapContext
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "k1_bundled.npz"))
+    ctx = MocapContext(64, 64)
+    ctx.set_fundamentals(g["F"][:1])
+    p0, p1 = g["image_points"][:, 0], g["image_points"][:, 1]
+    assert np.array_equal(p0, np.round(p0)) and np.array_equal(p1, np.round(p1))  # the captured centroids are integers
+    for roots, cand in ((p0.astype(np.int64), p1.astype(np.int64)), (p0, p1)):  # the int32 and the float64 point paths
+        d, lines = ctx.epipolar_scores(roots, cand, 0, with_lines=True)
+        assert d.shape == (54, 54)
+        assert np.array_equal(np.diagonal(d), g["epi_dist"])
+        assert np.diagonal(d).max() < 10.0
+        for r in (0, 17, 53):  # whole rows and the float32 lines against the oracle's restatement
+            line = oracle.epiline(g["F"][0], p0[r, 0], p0[r, 1])
+            assert np.array_equal(lines[r], line)
+            assert np.array_equal(d[r], [oracle.epi_distance(line, x, y) for x, y in p1])
