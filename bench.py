@@ -335,8 +335,14 @@ def roofline_of(prof, wl, n_images, n_launch_groups, traffic_key):
     return roof
 
 
-def kernel_ms(prof):
-    n = prof["steps"]
+def kernel_ms(prof, timed_region=False):
+    """mean kernel time per step (HIP events on the launch streams): of the sequential pass, or of the timed region itself, where
+    `--depth` batches share the chip and every kernel is stretched by its neighbours"""
+    if timed_region:
+        prof = prof["timed_region"]
+        n = max(1, prof["scan_launches"] or prof["filter_launches"])
+    else:
+        n = prof["steps"]
     return {"scan": round(prof["scan_ms"] / n, 4), "settle": round(prof["settle_ms"] / n, 4), "filter": round(prof["filter_ms"] / n, 4),
             "contours": round(prof["contour_ms"] / n, 4), "correspond": round(prof["corr_ms"] / n, 4)}
 
@@ -473,7 +479,7 @@ def main():
         return {"workload": wl.name(world), "value": round(T * world * steps / el, 2), "unit": "frames/s", "ms_per_step": round(1e3 * el / steps, 4),
                 "time_steps_per_step": T, "steps": steps, "images_per_step": len(m["images"]),
                 "roofline": roofline_of(prof, wl, len(m["images"]), 1 if world == 1 else len(m["tracker"].segs), None),
-                "kernel_ms_per_step": kernel_ms(prof), "status_ok": ok, "points_per_frame": float(np.maximum(n_roots, 0).mean()),
+                "kernel_ms_per_step": kernel_ms(prof), "kernel_ms_per_step_in_timed_region": kernel_ms(prof, True), "status_ok": ok, "points_per_frame": float(np.maximum(n_roots, 0).mean()),
                 "dark_tile_early_out": {"tiles_per_step": prof["tiles"], "tiles_resolved_without_filtering": prof["tiles_skipped"]}}
 
     def ba_residual_section(n_eval=50):
@@ -585,6 +591,7 @@ def main():
                         else ("torch.distributed over gloo (one-GPU rehearsal)" if args.rehearse_on_one_gpu else "torch.distributed all_gather_into_tensor (RCCL)"))},
             "roofline": roof,
             "kernel_ms_per_step": kernel_ms(prof),
+            "kernel_ms_per_step_in_timed_region": kernel_ms(prof, True),
             "status_ok": status_ok,
             "time_steps_without_result": int((n_roots < 0).sum()),  # capacity codes (MOCAP_CORR_E_*): e.g. the reference's cartesian
                                                                     # expansion beyond max_groups in a crowded rig (configs[4])

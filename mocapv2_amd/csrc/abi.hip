@@ -69,6 +69,7 @@ struct Tuning {
     int box_blocks_per_cu = 0;   // 0 = box_filter_blocks_per_cu()
     int box_timing = 0, contour_timing = 0; // phase clocks on stderr (synchronous debugging aids)
     int scan_wide = 1;           // 0 = the scan's 8-byte loads
+    int scan_blocks_per_cu = 0;  // > 0: the scan as a persistent pass of that many workgroups per CU (0 = one workgroup per block)
     int excess_base = -1;        // >= 0: pins the scan's excess base
     int base_sel = 1;            // the base a context starts with (0 tight, 1 tolerant)
     int probe_debug = 0;
@@ -86,7 +87,7 @@ static const TuneName kTuneNames[] = {
     {"box_prio", &Tuning::box_prio, 0, 1}, {"scan_prio", &Tuning::scan_prio, 0, 3}, {"contour_prio", &Tuning::contour_prio, 0, 3},
     {"corr_prio", &Tuning::corr_prio, 0, 3}, {"box_stage_bytes", &Tuning::box_stage_bytes, 0, BOX_SCAP},
     {"box_blocks_per_cu", &Tuning::box_blocks_per_cu, 0, 32}, {"box_timing", &Tuning::box_timing, 0, 1},
-    {"contour_timing", &Tuning::contour_timing, 0, 1}, {"scan_wide", &Tuning::scan_wide, 0, 1}, {"excess_base", &Tuning::excess_base, -1, 254},
+    {"contour_timing", &Tuning::contour_timing, 0, 1}, {"scan_wide", &Tuning::scan_wide, 0, 1}, {"scan_blocks_per_cu", &Tuning::scan_blocks_per_cu, 0, 64}, {"excess_base", &Tuning::excess_base, -1, 254},
     {"base_sel", &Tuning::base_sel, 0, 1}, {"probe_debug", &Tuning::probe_debug, 0, 1}, {"contour_boxes", &Tuning::contour_boxes, 0, 1},
     {"contours_split", &Tuning::contours_split, 0, 1}, {"corr_threads", &Tuning::corr_threads, 64, 256},
     {"corr_step_groups", &Tuning::corr_step_groups, 0, 0x7fffffff},
@@ -119,6 +120,7 @@ static Tuning tuning_from_env()
 struct mocap_ctx {
     int device, W, H, n_slots, wpr;
     int box_grid;             // workgroups of the box kernel: the resident ones (box_filter_blocks_per_cu() per CU)
+    int n_cu;                 // compute units of the device
     mocap_blob_params prm;
     Tuning tune;
     uint32_t* maps;           // [2][n_slots][H][W]: tap positions, then blend weights (general form)
@@ -146,7 +148,8 @@ struct mocap_ctx {
     int base_sel; int probe_age; bool probe_pending; uint32_t* probe_dev; uint32_t* probe_host; hipEvent_t probe_ev;
     uint32_t* cells_ext; uint32_t* cur_box_ext; size_t cells_ext_images; // the same for caller-owned masks (mocap_filter_mask)
     void* cwork; size_t cwork_images;      // contour kernel workspace, contour_work_bytes() per image
-    uint32_t* walk_list; uint32_t* walk_count; // contour stage, split form: the batch's border walks (grown with cwork) and their number
+    uint64_t* walk_list; uint64_t* link_list; uint32_t* walk_count; // contour stage, split form: the batch's border walks / link walks
+                                                                    //   (grown with cwork) and their counters
     CameraTable* cams; int n_cam, n_F;
     double* scratch; size_t scratch_elems;
     double* ba_obj; size_t ba_obj_elems;   // object points of mocap_ba_residuals, [B][N][3]
@@ -236,7 +239,7 @@ int mocap_ctx_create(int device_id, int width, int height, int n_slots, mocap_ct
     c->maps = nullptr; c->map4 = nullptr; c->srcbox = nullptr; c->reach = nullptr; c->cflags = nullptr; c->map_flags = nullptr;
     c->mask = nullptr; c->mask_images = 0; c->mask_dirty = false; c->cells = nullptr; c->cells_images = 0; c->last_images = 0;
     c->tile_rows = nullptr; c->tile_rows_flip = 0; c->tile_rows_hold[0] = c->tile_rows_hold[1] = 0; c->cur_box = nullptr; c->items = nullptr; c->n_items = nullptr; c->cap_items = 0; c->wide_tiles = nullptr; c->cap_wide = 0;
-    c->cells_ext = nullptr; c->cur_box_ext = nullptr; c->cells_ext_images = 0; c->cwork = nullptr; c->cwork_images = 0; c->walk_list = nullptr; c->walk_count = nullptr;
+    c->cells_ext = nullptr; c->cur_box_ext = nullptr; c->cells_ext_images = 0; c->cwork = nullptr; c->cwork_images = 0; c->walk_list = nullptr; c->link_list = nullptr; c->walk_count = nullptr;
     c->cams = nullptr; c->n_cam = 0; c->n_F = 0; c->scratch = nullptr; c->scratch_elems = 0; c->profiling = false;
     c->ba_obj = nullptr; c->ba_obj_elems = 0; c->ba_pinned = nullptr; c->ba_pinned_bytes = 0;
     c->comm.reset();
@@ -245,9 +248,10 @@ int mocap_ctx_create(int device_id, int width, int height, int n_slots, mocap_ct
     c->base_sel = c->tune.base_sel; c->probe_age = 0; c->probe_pending = false; c->probe_dev = nullptr; c->probe_host = nullptr; c->probe_ev = nullptr;
     {
         hipDeviceProp_t prop;
-        c->box_grid = 2048;
+        c->box_grid = 2048; c->n_cu = 256;
         if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) {
             c->box_grid = box_filter_blocks_per_cu() * prop.multiProcessorCount;
+            c->n_cu = prop.multiProcessorCount;
             if (c->tune.box_blocks_per_cu >= 1) c->box_grid = c->tune.box_blocks_per_cu * prop.multiProcessorCount; // A/B switch
         }
     }
@@ -303,6 +307,7 @@ int mocap_ctx_destroy(mocap_ctx_t c)
     if (c->tile_rows) (void)hipFree(c->tile_rows);
     if (c->cwork) (void)hipFree(c->cwork);
     if (c->walk_list) (void)hipFree(c->walk_list);
+    if (c->link_list) (void)hipFree(c->link_list);
     if (c->walk_count) (void)hipFree(c->walk_count);
     if (c->cams) (void)hipFree(c->cams);
     if (c->scratch) (void)hipFree(c->scratch);
@@ -671,6 +676,7 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
                      tr_cur, tl.n_cgroups * 4, tl.n_strips, (uint32_t)(((1u << 23) + tl.rows - 1) / tl.rows),
                      mask, own_mask ? 0 : (size_t)n_images * c->H * c->wpr, ((uintptr_t)mask & 15) == 0, nullptr, base_alt, allow_alt / 4, 0};
         b.prio = c->tune.scan_prio; // A/B switch
+        b.max_blocks = c->tune.scan_blocks_per_cu * c->n_cu; b.blocks_x = 0;
         const bool probe = fixed_base < 0 && !c->probe_pending && allow_alt >= 0 && base_alt != base && !bayer &&
                            (c->probe_age == 0 || c->probe_age >= 32);
         if (probe) {
@@ -786,8 +792,10 @@ static int run_contours(mocap_ctx* c, const uint32_t* mask, const uint32_t* cell
         std::lock_guard<std::mutex> lk(c->mu);
         if (c->cwork) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c->cwork)); c->cwork = nullptr; c->cwork_images = 0; }
         if (c->walk_list) { HIP_TRY(hipFree(c->walk_list)); c->walk_list = nullptr; }
+        if (c->link_list) { HIP_TRY(hipFree(c->link_list)); c->link_list = nullptr; }
         HIP_TRY(hipMalloc(&c->cwork, contour_work_bytes() * (size_t)n_images));
         HIP_TRY(hipMalloc(&c->walk_list, contour_walk_bytes() * (size_t)n_images));
+        HIP_TRY(hipMalloc(&c->link_list, contour_link_bytes() * (size_t)n_images));
         if (!c->walk_count) HIP_TRY(hipMalloc(&c->walk_count, 256));
         c->cwork_images = n_images;
     }
@@ -795,8 +803,10 @@ static int run_contours(mocap_ctx* c, const uint32_t* mask, const uint32_t* cell
     // The split form (candidates per image -> all walks of the batch, 64 to a wave -> tree per image) is the default;
     // MOCAP_CONTOURS_SPLIT=0 runs the one-kernel-per-image form (A/B switch; same results).
     const bool split = c->tune.contours_split != 0;
-    a.walk_list = split ? c->walk_list : nullptr; a.walk_count = c->walk_count;
-    a.follow_grid = c->box_grid / 2 > 0 ? c->box_grid / 2 : 1; // 4 one-wave workgroups per CU (33 KB of LDS each)
+    a.walk_list = split ? c->walk_list : nullptr; a.link_list = c->link_list; a.walk_count = c->walk_count;
+    a.follow_grid = c->n_cu * 4;  // 4 one-wave workgroups per CU (33 KB of LDS each): persistent, they refill their lanes from the list
+    a.follow_grid2 = c->n_cu;     // the link walks are few
+    a.follow_list = 0; a.tree_pass = 0;
     a.prio = c->tune.contour_prio; // A/B switch (no effect measured)
     a.timing = nullptr;
     const bool phase_timing = c->tune.contour_timing != 0;

@@ -38,6 +38,7 @@ constexpr int MAXR = 384;   // borders per image
 constexpr int MAXK = 256;   // kept contours per image
 constexpr int MAXD = 8;     // nesting depth of a kept contour
 constexpr int MAXCELL = 4096; // occupancy cells (strip x 8 rows) scanned per image
+constexpr int MAXA = 64;    // links per image whose owner has to be found by a walk that are handed to the packed second pass
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // lane L receives lane L - 1's / L + 1's value (0 at the ends of the wave and from lanes that are switched off)
@@ -274,17 +275,30 @@ constexpr int NWIN = 16; // candidates per image whose mask window is staged in 
 struct ContourWork {
     ContourRec recs[MAXR];
     int32_t kept_path[MAXK][MAXD];
-    // hand-over between the three kernels of the split form (candidates -> follow -> order)
+    // hand-over between the kernels of the split form (candidates -> follow -> tree [-> follow the ambiguous links -> tree])
     int32_t st_ncand;        // candidates of the image, or -1: the candidates kernel reported an error for it
     int32_t st_nrec;         // borders recorded by the follow kernel (atomic)
     int32_t st_err;          // follow kernel: 1 = a walk ran into the step limit
-    int32_t st_pad;
-    uint32_t cand[MAXC];
+    int32_t st_pending;      // tree kernel, first pass: links left to the second follow pass (0 = the image is finished)
     int32_t rkey[MAXR];
     int16_t rsx[MAXR], rsy[MAXR];
     int16_t rbox[MAXR][4];
     uint8_t rhole[MAXR], rkept[MAXR];
+    int16_t rlink[MAXR];     // first tree pass -> second: the links found so far (-2 = waits for its walk)
+    int32_t link_key[MAXR];  // second follow pass: discovery key of the border that owns border c's link crack
+    uint8_t link_type[MAXR]; //   and its kind (1 = hole border)
 };
+
+// One entry of the batch-wide walk lists (64 bits): x | y << 15 | kind << 30 | image << 32 | border << 52.
+//   kind 0 / 1: a candidate start of an outer / a hole border at scan position (x, y) (contour_candidates_kernel);
+//   kind 2 / 3: the link of border `border` of the image: follow the border through pixel (x, y) whose West (2) / East (3)
+//               neighbour is background, to learn which border it is (tree kernel, first pass).
+__device__ __forceinline__ uint64_t walk_entry(int image, int x, int y, int kind, int border = 0)
+{
+    return (uint64_t)(uint32_t)x | ((uint64_t)(uint32_t)y << 15) | ((uint64_t)(uint32_t)kind << 30) | ((uint64_t)(uint32_t)image << 32) |
+           ((uint64_t)(uint32_t)border << 52);
+}
+constexpr int MAX_SPLIT_IMAGES = 1 << 20; // image field of a walk entry
 
 // MODE 0: the whole job for one image (candidates, walks, tree).  MODE 1 / MODE 2: the first and the last part of the split
 // form -- candidates only (handed to contour_follow_kernel through the workspace and the batch-wide walk list) / tree only
@@ -325,10 +339,14 @@ __device__ __forceinline__ void contours_body(const ContourArgs& a)
     auto stamp = [&](int i) { if (tick && tid == 0) tick[i] = wall_clock64(); };
     stamp(0);
     __syncthreads();
+    __shared__ uint64_t amb[MAXA]; // MODE 2, first pass: the links left to the second follow pass
+    __shared__ int n_amb;
+    const bool second_pass = MODE == 2 && a.tree_pass == 2;
     if constexpr (MODE == 2) {
         // the records of the follow kernel: counts, then the small per-border fields into LDS
         if (work.st_ncand < 0) return; // the candidates kernel has reported this image's error
-        if (tid == 0) { nrec = work.st_nrec; err = work.st_err; }
+        if (second_pass && work.st_pending <= 0) return; // finished by the first pass
+        if (tid == 0) { nrec = work.st_nrec; err = work.st_err; n_amb = 0; }
         __syncthreads();
         if (nrec > MAXR || err) {
             if (tid == 0) { *out_count = err ? BLOB_ERR_STEPS : BLOB_ERR_CONTOURS; if (a.dbg_count) a.dbg_count[image] = 0; }
@@ -337,7 +355,7 @@ __device__ __forceinline__ void contours_body(const ContourArgs& a)
         for (int c = tid; c < nrec; c += NTHREADS) {
             rkey[c] = work.rkey[c]; rsx[c] = work.rsx[c]; rsy[c] = work.rsy[c];
             rhole[c] = work.rhole[c]; rkept[c] = work.rkept[c];
-            rlink[c] = -1; rparent[c] = -1;
+            rlink[c] = second_pass ? work.rlink[c] : (int16_t)-1; rparent[c] = -1;
             rbox[c][0] = work.rbox[c][0]; rbox[c][1] = work.rbox[c][1]; rbox[c][2] = work.rbox[c][2]; rbox[c][3] = work.rbox[c][3];
         }
         __syncthreads();
@@ -501,17 +519,17 @@ __device__ __forceinline__ void contours_body(const ContourArgs& a)
     }
     }
     if constexpr (MODE == 1) {
-        // hand the candidates over: into the image's workspace, and one entry each (image << 10 | index) into the batch's walk list
+        // hand the candidates over: one self-contained entry each into the batch's walk list
         __shared__ uint32_t wbase;
         const int nc1 = ncand;
         if (tid == 0) {
-            work.st_ncand = nc1; work.st_nrec = 0; work.st_err = 0;
-            wbase = nc1 ? atomicAdd(a.walk_count, (uint32_t)nc1) : 0u;
+            work.st_ncand = nc1; work.st_nrec = 0; work.st_err = 0; work.st_pending = 0;
+            wbase = nc1 ? atomicAdd(&a.walk_count[0], (uint32_t)nc1) : 0u;
         }
         __syncthreads();
         for (int c = tid; c < nc1; c += NTHREADS) {
-            work.cand[c] = cand[c];
-            a.walk_list[wbase + (uint32_t)c] = ((uint32_t)image << 10) | (uint32_t)c;
+            const uint32_t v = cand[c];
+            a.walk_list[wbase + (uint32_t)c] = walk_entry(image, (int)(v & 0x7fffu), (int)(v >> 16), (int)((v >> 15) & 1u));
         }
         return;
     }
@@ -571,7 +589,19 @@ __device__ __forceinline__ void contours_body(const ContourArgs& a)
     //   hole border : left end of the foreground run holding the start pixel     -> its West crack
     // One wave per border (wave-uniform control flow).
     const int nr = nrec;
-    for (int c = wv; c < nr; c += NWAVES) {
+    if (second_pass) {
+        // the links the first pass left open: the second follow pass has identified the border each of their cracks belongs to
+        for (int c = tid; c < nr; c += NTHREADS) {
+            if (rlink[c] != -2) continue;
+            const int lkey = work.link_key[c], ltype = work.link_type[c];
+            int found = -2;
+            for (int j = 0; j < nr; j++)
+                if (rkey[j] == lkey && rhole[j] == ltype) { found = j; break; }
+            if (found == -2) atomicMax(&err, 2);
+            rlink[c] = (int16_t)found;
+        }
+    }
+    for (int c = wv; c < nr && !second_pass; c += NWAVES) {
         const int r_is_hole = rhole[c], r_sx = rsx[c], y = rsy[c];
         // hole: nearest background pixel at/left of the start; outer: nearest foreground pixel left of it.
         // The words of the row up to that column are examined 64 at a time, one per lane, right to left.
@@ -607,6 +637,16 @@ __device__ __forceinline__ void contours_body(const ContourArgs& a)
             }
             if (hits == 1) found = which;
         }
+        if (MODE == 2 && found == -2) {
+            // split form: the walk joins the batch's second packed follow pass (one lane there, not a whole wave here)
+            int slot = 0;
+            if (lane == 0) slot = atomicAdd(&n_amb, 1);
+            slot = uni(slot);
+            if (slot < MAXA) {
+                if (lane == 0) { amb[slot] = walk_entry(image, qx, y, r_is_hole ? 2 : 3, c); rlink[c] = -2; }
+                continue;
+            }
+        }
         if (found == -2) {
             Trace T; // every lane walks the same border (uniform arguments): rare path
             follow(M, qx, y, r_is_hole ? 4 : 0, -1, -1, a.max_steps, T, diag_len);
@@ -630,6 +670,17 @@ __device__ __forceinline__ void contours_body(const ContourArgs& a)
     if (err) {
         if (tid == 0) { *out_count = err == 1 ? BLOB_ERR_STEPS : BLOB_ERR_CONTOURS; if (a.dbg_count) a.dbg_count[image] = 0; }
         return;
+    }
+    if constexpr (MODE == 2) {
+        if (!second_pass && n_amb > 0) { // hand the open links to the second follow pass; this image is finished by the second tree pass
+            __shared__ uint32_t lbase;
+            const int na = n_amb < MAXA ? n_amb : MAXA;
+            if (tid == 0) { lbase = atomicAdd(&a.walk_count[2], (uint32_t)na); work.st_pending = na; }
+            __syncthreads();
+            for (int i = tid; i < na; i += NTHREADS) a.link_list[lbase + (uint32_t)i] = amb[i];
+            for (int c = tid; c < nr; c += NTHREADS) work.rlink[c] = rlink[c];
+            return;
+        }
     }
 
     // ---- phase C2: parents (Suzuki's table: same kind -> the link's parent, else the link itself) -----------
@@ -694,81 +745,241 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a) { con
 // (capping the candidates kernel at 72 registers for 7 workgroups per CU instead of 5 spills 13 of them: 325 k against 337 k frames/s)
 __global__ __launch_bounds__(NTHREADS) void contour_candidates_kernel(ContourArgs a) { contours_body<1>(a); }
 
-// The walks of the whole batch, one lane each, 64 to a wave whatever image they belong to: an image of a sparse IR frame has
-// a handful of borders, so the per-image kernel's walking wave runs its ~150 instructions per border step for 8 busy lanes;
-// here every lane of a wave follows a border, and the batch needs 1/3 - 1/4 of the wave instructions.  One wave per
-// workgroup; a wave takes 64 consecutive entries of the walk list at a time.  The 64 mask windows (64 rows x 64 columns from
-// one row above each start) are staged in LDS first, row-major over the wave's windows (bank-conflict-free for lanes at
-// different rows).  A raster-first walk becomes a record of its image: slot by an atomic on the image's counter.
+// The walks of the whole batch, one lane each, whatever image they belong to: an image of a sparse IR frame has a handful of
+// borders, so a per-image kernel's walking wave runs its ~150 instructions per border step for 8 busy lanes; here every lane
+// of a wave follows a border.  The waves are PERSISTENT and refill their lanes: every FOLLOW_K steps a wave looks at its
+// lanes; those whose walk has ended store their record (one round of atomics and stores for all of them), and when enough
+// lanes are idle the wave takes that many new entries from the batch-wide list (one atomic on its head), stages their mask
+// windows (64 rows x 64 columns from one row above each start, in LDS, row-major over the lanes: bank-conflict-free for
+// lanes at different rows) and starts them -- so a wave's instruction stream is shared by ~64 live walks most of the time,
+// instead of running on for the one long border of a merged pair of markers while its other 63 lanes wait.
+// The walk is `follow` above cut into resumable steps: same neighbour search, same vertex rule, same sums.
+constexpr int FOLLOW_K = 16;      // steps between two looks at the lanes
+constexpr int FOLLOW_REFILL = 16; // idle lanes that make a refill worth its three dependent memory round trips
+
+struct Walk { // one lane's walk
+    const uint32_t* mw;  // mask of its image
+    uint64_t rU, rM, rD; // the three 64-column mask rows around the current pixel
+    int64_t a00, a10, a01;
+    double diag, pend;
+    int sx, sy, i1x, i1y, x, y, x0, s, prev_s, run, first_len, axis, npts, steps, min_fg, min_ebg, bx0, bx1, by0, by1;
+    int abort_lt, key;
+    uint32_t n, meta;    // meta: kind | border << 2 | image << 11 (kind 0 outer / 1 hole candidate, 2 / 3 link walks)
+    bool abort_on_fg, staged;
+    int status;          // 0 closed, 1 aborted, 2 step limit
+};
+
 __global__ __launch_bounds__(64) void contour_follow_kernel(ContourArgs a)
 {
-    __shared__ uint64_t win[64][64]; // [row of the window][lane = candidate of the wave]
+    __shared__ uint64_t win[64][64]; // [row of the window][lane]
     __shared__ double diag_len[64];
     const int lane = threadIdx.x;
     diag_len[lane] = run_length(1, lane);
-    const uint32_t total = *a.walk_count;
+    const uint64_t* const list = a.follow_list ? a.link_list : a.walk_list;
+    const uint32_t total = a.walk_count[2 * a.follow_list];
+    uint32_t* const head = &a.walk_count[2 * a.follow_list + 1];
     ContourWork* const works = (ContourWork*)a.work;
-    const size_t image_words = (size_t)a.H * a.words_per_row;
-    for (uint32_t base = blockIdx.x * 64u; base < total; base += gridDim.x * 64u) {
-        const int n_here = uni((int)(total - base < 64u ? total - base : 64u));
-        const bool has = lane < n_here;
-        const uint32_t e = has ? a.walk_list[base + (uint32_t)lane] : a.walk_list[base];
-        const int image = (int)(e >> 10), ci = (int)(e & 1023u);
-        ContourWork& work = works[image];
-        const uint32_t v = work.cand[ci];
-        const int is_hole = (int)((v >> 15) & 1u), x = (int)(v & 0x7fffu), y = (int)(v >> 16);
-        const int sx = x - is_hole;
-        __syncthreads(); // (one wave) the previous round's window reads are done
-#pragma unroll 8
-        for (int c = 0; c < n_here; c++) {
-            const int img_c = __builtin_amdgcn_readlane(image, c), sx_c = __builtin_amdgcn_readlane(sx, c), sy_c = __builtin_amdgcn_readlane(y, c);
-            const Mask Mc{a.mask + (size_t)img_c * image_words, a.words_per_row, a.H, a.W, a.W + 1};
-            win[lane][c] = row64(Mc, sy_c - 1 + lane, sx_c - 31);
-        }
-        __syncthreads();
-        if (has) {
-            const Mask M{a.mask + (size_t)image * image_words, a.words_per_row, a.H, a.W, a.W + 1};
-            const int key = y * M.RS + x;
-            Trace T;
-            if (!is_hole) follow<64>(M, x, y, 4, key, -1, a.max_steps, T, diag_len, &win[0][lane]);
-            else follow<64>(M, x - 1, y, 0, -1, key, a.max_steps, T, diag_len, &win[0][lane]);
-            if (T.status == 2) atomicMax(&work.st_err, 1);
-            if (T.status == 0) {
+    const uint32_t image_words = (uint32_t)a.H * (uint32_t)a.words_per_row;
+    const int RS = a.W + 1;
+    Walk w;
+    w.mw = a.mask; w.staged = false; w.status = 0; w.meta = 0; w.n = 0; w.s = 0;
+    bool active = false, finished = false; // finished: the walk has ended, its record is not stored yet
+    bool drained = false;                  // (wave-uniform) the list has no more entries
+    __syncthreads();
+    auto mask_of = [&]() { return Mask{w.mw, a.words_per_row, a.H, a.W, RS}; };
+    auto fetch = [&](int yy) -> uint64_t {
+        const unsigned r = (unsigned)(yy - (w.sy - 1));
+        if (w.staged && r < 64u) return win[r][lane];
+        return row64(mask_of(), yy, w.x0);
+    };
+    auto nbr8 = [&]() -> uint32_t {
+        const int c = w.x - w.x0 - 1; // column x-1 at bit 0
+        const uint32_t up = (uint32_t)(w.rU >> c) & 7u, mid = (uint32_t)(w.rM >> c) & 7u, dn = (uint32_t)(w.rD >> c) & 7u;
+        const uint32_t up_rev = (0x73516240u >> (4u * up)) & 7u; // bit order NE, N, NW = columns x+1, x, x-1
+        return (mid >> 2) | (up_rev << 1) | ((mid & 1u) << 4) | (dn << 5);
+    };
+    for (;;) {
+        // ---- the lanes whose walk has ended store their results (all of them in one round) ----
+        if (finished) {
+            const int kind = (int)(w.meta & 3u), image = (int)(w.meta >> 11), border = (int)((w.meta >> 2) & 511u);
+            ContourWork& work = works[image];
+            if (w.status == 2) atomicMax(&work.st_err, 1);
+            if (kind >= 2) { // a link walk: which border is this?
+                if (w.status == 0) {
+                    const int ltype = w.a00 > 0 ? 1 : 0; // hole borders run the other way round
+                    work.link_key[border] = ltype ? w.min_ebg : w.min_fg;
+                    work.link_type[border] = (uint8_t)ltype;
+                } else atomicMax(&work.st_err, 1);
+            } else if (w.status == 0) {
                 const int slot = atomicAdd(&work.st_nrec, 1);
                 if (slot < MAXR) {
                     ContourRec r;
-                    r.key = key; r.is_hole = is_hole;
-                    r.sx = sx; r.sy = y;
-                    r.npts = T.npts; r.steps = T.steps;
-                    r.a00 = T.a00; r.a10 = T.a10; r.a01 = T.a01;
-                    r.area = fabs((double)T.a00 * 0.5);
-                    r.perimeter = T.npts > 1 ? T.per : 0.0;
+                    r.key = w.key; r.is_hole = kind;
+                    r.sx = w.sx; r.sy = w.sy;
+                    r.npts = w.npts; r.steps = w.steps;
+                    r.a00 = w.a00; r.a10 = w.a10; r.a01 = w.a01;
+                    r.area = fabs((double)w.a00 * 0.5);
+                    r.perimeter = w.npts > 1 ? (double)w.axis + w.diag : 0.0;
                     r.link = -1; r.parent = -1; r.order = -1;
                     select_contour(r, a.min_area, a.min_circ);
                     work.recs[slot] = r;
-                    work.rkey[slot] = key; work.rsx[slot] = (int16_t)sx; work.rsy[slot] = (int16_t)y;
-                    work.rhole[slot] = (uint8_t)is_hole; work.rkept[slot] = (uint8_t)r.kept;
-                    work.rbox[slot][0] = (int16_t)T.bx0; work.rbox[slot][1] = (int16_t)T.by0;
-                    work.rbox[slot][2] = (int16_t)T.bx1; work.rbox[slot][3] = (int16_t)T.by1;
+                    work.rkey[slot] = w.key; work.rsx[slot] = (int16_t)w.sx; work.rsy[slot] = (int16_t)w.sy;
+                    work.rhole[slot] = (uint8_t)kind; work.rkept[slot] = (uint8_t)r.kept;
+                    work.rbox[slot][0] = (int16_t)w.bx0; work.rbox[slot][1] = (int16_t)w.by0;
+                    work.rbox[slot][2] = (int16_t)w.bx1; work.rbox[slot][3] = (int16_t)w.by1;
                 }
             }
+            finished = false;
+        }
+        // ---- refill ----
+        const uint64_t busy = __ballot(active);
+        const int n_idle = 64 - __popcll(busy);
+        if (!drained && (n_idle >= FOLLOW_REFILL || busy == 0)) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(head, (uint32_t)n_idle);
+            base = (uint32_t)uni((int)base);
+            const int n_new = base < total ? (int)(total - base < (uint32_t)n_idle ? total - base : (uint32_t)n_idle) : 0;
+            drained = n_new < n_idle;
+            const int rank = __popcll(~busy & ((1ull << lane) - 1ull)); // this lane's number among the idle ones
+            const bool take = !active && rank < n_new;
+            uint64_t e = 0;
+            if (take) e = list[base + (uint32_t)rank];
+            const int ex = (int)(e & 0x7fffu), ey = (int)((e >> 15) & 0x7fffu), kind = (int)((e >> 30) & 3u);
+            const int image = (int)((e >> 32) & 0xfffffu), border = (int)((e >> 52) & 511u);
+            const int sx = ex - (kind == 1 ? 1 : 0); // a hole candidate's border pixel lies left of its scan position
+            // the windows of the new walks: lane = row, one new walk per round (all rounds' loads are independent)
+            for (uint64_t todo = __ballot(take); todo; todo &= todo - 1) {
+                const int c = __ffsll((long long)todo) - 1;
+                const int img_c = __builtin_amdgcn_readlane(image, c), sx_c = __builtin_amdgcn_readlane(sx, c), sy_c = __builtin_amdgcn_readlane(ey, c);
+                const Mask Mc{a.mask + (size_t)img_c * image_words, a.words_per_row, a.H, a.W, RS};
+                win[lane][c] = row64(Mc, sy_c - 1 + lane, sx_c - 31);
+            }
+            __syncthreads(); // (one wave) the windows are in LDS before any lane reads its own
+            if (take) {
+                w.mw = a.mask + (size_t)image * image_words;
+                w.meta = (uint32_t)kind | ((uint32_t)border << 2) | ((uint32_t)image << 11);
+                w.sx = sx; w.sy = ey; w.x = sx; w.y = ey; w.x0 = sx - 31; w.staged = true;
+                w.key = ey * RS + ex;
+                const int first = (kind == 0 || kind == 2) ? 4 : 0; // the neighbour known to be background: W (outer start) / E
+                w.abort_on_fg = kind == 0;
+                w.abort_lt = kind <= 1 ? w.key : -1;  // link walks run all the way round
+                w.a00 = w.a10 = w.a01 = 0; w.npts = 0; w.steps = 0;
+                w.min_fg = ey * RS + sx; w.min_ebg = 0x7fffffff;
+                w.bx0 = w.bx1 = sx; w.by0 = w.by1 = ey;
+                w.rU = fetch(ey - 1); w.rM = fetch(ey); w.rD = fetch(ey + 1);
+                w.n = nbr8();
+                int s = first;
+                do {
+                    s = (s - 1) & 7;
+                } while (!((w.n >> s) & 1u) && s != first);
+                w.status = 0;
+                if (s == first) { // isolated pixel: one vertex, zero area, zero perimeter
+                    w.npts = 1; w.min_ebg = ey * RS + sx + 1; w.axis = 0; w.diag = 0.0;
+                    finished = true;
+                } else {
+                    w.s = s;
+                    w.i1x = sx + dir_dx(s); w.i1y = ey + dir_dy(s);
+                    w.prev_s = s ^ 4; w.run = 0; w.first_len = 0; w.axis = 0; w.diag = 0.0; w.pend = 0.0;
+                    active = true;
+                }
+            }
+        }
+        if (__ballot(active || finished) == 0) break; // nothing in flight (and nothing left in the list, or the refill would have run)
+        // ---- FOLLOW_K steps of every live walk ----
+        for (int k = 0; k < FOLLOW_K; k++) {
+            if (active) {
+                const int s_end = w.s;
+                // first occupied neighbour counter-clockwise from s_end+1
+                const uint32_t rot = ((w.n | (w.n << 8)) >> (s_end + 1)) & 0xffu;
+                const int s = (s_end + __ffs((int)rot)) & 7;
+                const int r = w.y * RS + w.x;
+                const bool east_bg = (unsigned)(s - 1) < (unsigned)s_end; // the East neighbour was examined and is background
+                const int re = east_bg ? r + 1 : 0x7fffffff;
+                w.min_ebg = re < w.min_ebg ? re : w.min_ebg;
+                w.min_fg = r < w.min_fg ? r : w.min_fg;
+                // (x,y) is a CHAIN_APPROX_SIMPLE vertex when the direction changes: close the run that ends here
+                const bool vertex = s != w.prev_s;
+                const bool open_start = vertex && w.npts == 0 && w.steps > 0; // the start was not a vertex: its run is closed at the end
+                w.first_len = open_start ? w.run : w.first_len;
+                const int kk = (vertex && !open_start) ? w.run : 0;
+                const bool odd = (w.prev_s & 1) != 0;
+                w.axis += odd ? 0 : kk;
+                w.diag += w.pend;
+                const int kd = odd ? kk : 0;                                  // diag_len[0] = 0
+                w.pend = diag_len[kd < 63 ? kd : 63];
+                if (kd > 63) w.pend = run_length(1, kd);                      // (a diagonal run longer than the table: rare)
+                w.npts += vertex ? 1 : 0;
+                w.prev_s = s;
+                w.run = vertex ? 1 : w.run + 1;
+                const int dx = dir_dx(s), dy = dir_dy(s);
+                const int nx = w.x + dx, ny = w.y + dy;
+                const int cross = w.x * dy - dx * w.y; // x*ny - nx*y
+                w.a00 += cross;
+                w.a10 += (int64_t)cross * (2 * w.x + dx);
+                w.a01 += (int64_t)cross * (2 * w.y + dy);
+                w.steps++;
+                const bool aborted = (w.abort_on_fg ? r : re) < w.abort_lt;
+                const bool closed = nx == w.sx && ny == w.sy && w.x == w.i1x && w.y == w.i1y;
+                if (aborted || closed || w.steps > a.max_steps) {
+                    w.status = aborted ? 1 : (closed ? 0 : 2);
+                    active = false;
+                    finished = !aborted || (w.meta & 3u) >= 2; // an aborted candidate leaves nothing behind
+                    if (w.status == 0) { // the run that arrives at the start, merged with the run that left it when the start is not a vertex
+                        w.diag += w.pend;
+                        const int kc = w.run + w.first_len;
+                        if (w.prev_s & 1) w.diag += kc < 64 ? diag_len[kc] : run_length(1, kc);
+                        else w.axis += kc;
+                    }
+                } else {
+                    w.bx0 = nx < w.bx0 ? nx : w.bx0; w.bx1 = nx > w.bx1 ? nx : w.bx1;
+                    w.by0 = ny < w.by0 ? ny : w.by0; w.by1 = ny > w.by1 ? ny : w.by1;
+                    // move, keeping the three cached rows around the current pixel
+                    const int lx = nx - w.x0;
+                    if (lx < 1 || lx > 62) { // left the window: re-centre it on the new pixel (rare), or return to the staged one
+                        const int wl = nx - (w.sx - 31); // column of the new pixel in the staged window
+                        w.staged = wl >= 1 && wl <= 62;
+                        w.x0 = w.staged ? w.sx - 31 : nx - 31;
+                        w.rU = fetch(ny - 1); w.rM = fetch(ny); w.rD = fetch(ny + 1);
+                    } else {
+                        const uint64_t nw = fetch(ny + dy); // (dy = 0: the middle row again, unused)
+                        const uint64_t oU = w.rU, oM = w.rM, oD = w.rD;
+                        w.rU = dy > 0 ? oM : (dy < 0 ? nw : oU);
+                        w.rM = dy > 0 ? oD : (dy < 0 ? oU : oM);
+                        w.rD = dy > 0 ? nw : (dy < 0 ? oM : oD);
+                    }
+                    w.x = nx; w.y = ny;
+                    w.s = (s + 4) & 7;
+                    w.n = nbr8();
+                }
+            }
+            if (__ballot(active) == 0) break;
         }
     }
 }
 
 size_t contour_work_bytes() { return sizeof(ContourWork); }
-size_t contour_walk_bytes() { return sizeof(uint32_t) * MAXC; }
+size_t contour_walk_bytes() { return sizeof(uint64_t) * MAXC; }  // candidates of one image in the batch's walk list
+size_t contour_link_bytes() { return sizeof(uint64_t) * MAXA; }  // links of one image handed to the second follow pass
 
-void launch_contours(const ContourArgs& a, hipStream_t s)
+void launch_contours(const ContourArgs& a_, hipStream_t s)
 {
-    if (a.walk_list && !a.timing && a.n_images < (1 << 22)) {
-        (void)hipMemsetAsync(a.walk_count, 0, sizeof(uint32_t), s);
+    if (a_.walk_list && !a_.timing && a_.n_images < MAX_SPLIT_IMAGES) {
+        // candidates per image -> every walk of the batch -> tree per image; the (few) links whose owner only a walk can tell go
+        // through a second, equally packed, follow pass, and the second tree pass finishes the images that waited for them
+        ContourArgs a = a_;
+        (void)hipMemsetAsync(a.walk_count, 0, 4 * sizeof(uint32_t), s);
         hipLaunchKernelGGL(contour_candidates_kernel, dim3(a.n_images), dim3(NTHREADS), 0, s, a);
+        a.follow_list = 0;
         hipLaunchKernelGGL(contour_follow_kernel, dim3(a.follow_grid), dim3(64), 0, s, a);
+        a.tree_pass = 1;
+        hipLaunchKernelGGL(contours_kernel<2>, dim3(a.n_images), dim3(NTHREADS), 0, s, a);
+        a.follow_list = 1;
+        hipLaunchKernelGGL(contour_follow_kernel, dim3(a.follow_grid2), dim3(64), 0, s, a);
+        a.tree_pass = 2;
         hipLaunchKernelGGL(contours_kernel<2>, dim3(a.n_images), dim3(NTHREADS), 0, s, a);
         return;
     }
-    hipLaunchKernelGGL(contours_kernel<0>, dim3(a.n_images), dim3(NTHREADS), 0, s, a);
+    hipLaunchKernelGGL(contours_kernel<0>, dim3(a_.n_images), dim3(NTHREADS), 0, s, a_);
 }
 
 } // namespace mocap

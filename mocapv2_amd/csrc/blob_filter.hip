@@ -214,21 +214,18 @@ __device__ __forceinline__ uint4 load_once16(const uint8_t* p)
 // WIDE (W, pitch, image stride and base multiples of 16): the two cells of a thread are neighbours in one cell row and
 // come in with one 16-byte load per image row (8 loads of 16 B instead of 16 of 8 B per thread).
 // FULL (H a multiple of 8, wide only): every cell has its 8 rows, no row clamping and no per-row validity test.
-template <bool WIDE, bool FULL = false>
-__global__ __launch_bounds__(256) void bright_cells_kernel(BrightArgs a)
+// One block of 256 threads of the pass: block `bx` of image `image` (the kernel below deals these to the workgroups).
+template <bool WIDE, bool FULL>
+__device__ __forceinline__ void bright_cells_block(const BrightArgs& a, const int bx, const int image)
 {
-    if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
-    else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
-    else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
     const int ncx = (a.W + 7) >> 3, ncy = (a.H + 7) >> 3, n = ncx * ncy;
-    const int image = blockIdx.y;
     const uint8_t* __restrict__ img = a.src + (size_t)image * a.image_stride;
     uint2 v[2][8];
     int ci[2], cr[2];
     uint32_t sh[2];
     if (WIDE) {
         const int half = ncx >> 1, np = half * ncy; // cell pairs (ncx is even)
-        int p = blockIdx.x * 256 + threadIdx.x;
+        int p = bx * 256 + threadIdx.x;
         p = p < np ? p : np - 1; // threads past the end recount the last pair (and mark the same tiles again)
         const int row = (int)__umulhi((uint32_t)p, a.ncx_magic), cxp = p - row * half; // ncx_magic: for ncx / 2 here
         cr[0] = cr[1] = row;
@@ -251,7 +248,7 @@ __global__ __launch_bounds__(256) void bright_cells_kernel(BrightArgs a)
             }
         }
     } else {
-        const int i0 = blockIdx.x * 512 + threadIdx.x;
+        const int i0 = bx * 512 + threadIdx.x;
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             int i = i0 + 256 * u;
@@ -300,16 +297,33 @@ __global__ __launch_bounds__(256) void bright_cells_kernel(BrightArgs a)
             }
             const int n_cur = __popcll(__ballot((int)acc > a.hot)), n_alt = __popcll(__ballot((int)acc2 > a.hot_alt));
             if ((threadIdx.x & 63) == 0) {
-                atomicAdd(&a.probe[2 * (blockIdx.x & 127)], (uint32_t)n_cur);
-                atomicAdd(&a.probe[2 * (blockIdx.x & 127) + 1], (uint32_t)n_alt);
+                atomicAdd(&a.probe[2 * (bx & 127)], (uint32_t)n_cur);
+                atomicAdd(&a.probe[2 * (bx & 127) + 1], (uint32_t)n_alt);
             }
         }
+    }
+}
+
+// The grid is one-dimensional: workgroup b takes the blocks b, b + gridDim.x, ... of the batch's blocks_x * n_images blocks
+// (block -> image = block / blocks_x).  Launched with as many workgroups as blocks it is the plain form (every workgroup one
+// block); launched with a fixed number per CU it is a persistent pass that never holds more than that many wave slots and
+// registers of a SIMD, whatever the batch size (BrightArgs::blocks_x, launch_bright_cells).
+template <bool WIDE, bool FULL = false>
+__global__ __launch_bounds__(256) void bright_cells_kernel(BrightArgs a)
+{
+    if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
+    else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
+    const uint32_t total = (uint32_t)a.blocks_x * (uint32_t)a.n_images;
+    for (uint32_t vb = blockIdx.x; vb < total; vb += gridDim.x) {
+        const uint32_t image = vb / (uint32_t)a.blocks_x;
+        bright_cells_block<WIDE, FULL>(a, (int)(vb - image * (uint32_t)a.blocks_x), (int)image);
     }
     if (a.mask_words) {
         // caller-owned masks: clear them on the side (16 bytes per thread and round), the filter kernel then only
         // writes the tiles it filters.  The context's own mask needs no clearing (see the filter kernel).
-        const size_t nthreads = (size_t)gridDim.x * gridDim.y * 256;
-        const size_t g = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+        const size_t nthreads = (size_t)gridDim.x * 256;
+        const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
         if (a.mask_aligned16) {
             const size_t quads = a.mask_words >> 2;
             for (size_t q = g; q < quads; q += nthreads) ((uint4*)a.mask)[q] = make_uint4(0u, 0u, 0u, 0u);
@@ -849,12 +863,18 @@ void launch_filter_tiles(const FilterArgs& a, bool remap, int blocks, hipStream_
     else
         hipLaunchKernelGGL((filter_mask_kernel<false, false, false, true>), dim3(blocks), dim3(256), 0, s, a);
 }
-void launch_bright_cells(const BrightArgs& a, hipStream_t s)
+void launch_bright_cells(const BrightArgs& a_, hipStream_t s)
 {
+    BrightArgs a = a_;
     const int n = ((a.W + 7) >> 3) * ((a.H + 7) >> 3);
-    if (a.wide && a.H % 8 == 0) hipLaunchKernelGGL((bright_cells_kernel<true, true>), dim3((n / 2 + 255) / 256, a.n_images), dim3(256), 0, s, a);
-    else if (a.wide) hipLaunchKernelGGL(bright_cells_kernel<true>, dim3((n / 2 + 255) / 256, a.n_images), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(bright_cells_kernel<false>, dim3((n + 511) / 512, a.n_images), dim3(256), 0, s, a);
+    a.blocks_x = a.wide ? (n / 2 + 255) / 256 : (n + 511) / 512;
+    const long long total = (long long)a.blocks_x * a.n_images;
+    long long grid = total;
+    if (a.max_blocks > 0 && a.max_blocks < grid) grid = a.max_blocks; // persistent form: a fixed number of workgroups
+    if (grid > 0x7fffffffLL) grid = 0x7fffffffLL;
+    if (a.wide && a.H % 8 == 0) hipLaunchKernelGGL((bright_cells_kernel<true, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    else if (a.wide) hipLaunchKernelGGL(bright_cells_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(bright_cells_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, a);
 }
 void launch_undistort_map(const MapArgs& m, hipStream_t s)
 {

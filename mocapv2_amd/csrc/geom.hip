@@ -169,6 +169,20 @@ struct DltAcc {
 #pragma unroll
             for (int k = 0; k < 4; k++) B[j][k] += r0[j] * r0[k] + r1[j] * r1[k];
     }
+    // the same two rows from a projection matrix formed beforehand (the identical sums, formed once per camera)
+    __device__ void add_rows(const double* P, double x, double y)
+    {
+        double r0[4], r1[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            r0[k] = y * P[8 + k] - P[4 + k];
+            r1[k] = P[k] - x * P[8 + k];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) B[j][k] += r0[j] * r0[k] + r1[j] * r1[k];
+    }
     __device__ void solve(double X[3])
     {
         double v[4];
@@ -206,33 +220,88 @@ __device__ __forceinline__ void load_pt(const void* base, size_t idx, double& x,
 
 } // namespace
 
+// LDS plan of correspond_kernel (dynamic shared memory), the same on host and device
+struct CorrLds {
+    int cam, F, pts, errs, rerr, ints, nm, midx, total; // byte offsets
+    int stage_pts, err_cap;
+};
+__host__ __device__ inline CorrLds corr_lds_plan(int P, int C)
+{
+    CorrLds L;
+    int o = 0;
+    L.cam = o; o += C * 38 * 8;                 // per camera: projection matrix P = K [R|t] (12), K (9), dist (5), R (9), t (3)
+    L.F = o; o += (C > 1 ? C - 1 : 0) * 9 * 8;
+    L.stage_pts = C * P <= 2048;                // all image points of the time step in LDS (32 KB at most)
+    L.pts = o; o += L.stage_pts ? C * P * 16 : 0;
+    L.err_cap = 1024;                           // per-group errors in LDS when the time step has no more groups than this
+    L.errs = o; o += L.err_cap * 8;
+    L.rerr = o; o += P * 8;
+    L.ints = o; o += (3 * P + 2 + 32) * 4;      // G[P], goff[P + 1], slot[P], counts[32]
+    L.nm = o; o += P * C;
+    L.midx = o; o += P * C * MAXM;
+    L.total = (o + 15) & ~15;
+    return L;
+}
+
+// One workgroup per time step.  Everything the step needs -- the cameras' image points, the camera table (with the
+// projection matrices K [R|t] formed once instead of once per group and camera), the fundamental matrices -- comes in with
+// ONE round of global loads into LDS; all scoring, triangulation and ranking then runs from LDS and registers, and the
+// results leave with one round of stores.  (The first version loaded points and matrices where it used them: ~100 dependent
+// global round trips per time step, 47 us alone but 552 us beside the other batches' streaming scans, whose queued loads every
+// one of those round trips waits behind.)
 template <typename PT>
 __global__ __launch_bounds__(256) void correspond_kernel(CorrArgs a)
 {
-    extern __shared__ unsigned char smem[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
     else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
     else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
-    const int C = a.C, P = a.P, t = blockIdx.x, tid = threadIdx.x;
-    // LDS carve: nm[P][C] (u8), midx[P][C][MAXM] (u8), G[P] (int), goff[P+1] (int), slot[P] (int)
-    uint8_t* nm = smem;
-    uint8_t* midx = nm + P * C;
-    int* G = (int*)(((uintptr_t)(midx + (size_t)P * C * MAXM) + 7) & ~(uintptr_t)7);
+    const int C = a.C, P = a.P, t = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
+    const CorrLds L = corr_lds_plan(P, C);
+    double (*cam)[38] = (double (*)[38])(smem + L.cam);
+    double (*Fm)[9] = (double (*)[9])(smem + L.F);
+    double* spts = (double*)(smem + L.pts);
+    double* serr = (double*)(smem + L.errs);
+    double* rerr = (double*)(smem + L.rerr);
+    int* G = (int*)(smem + L.ints);
     int* goff = G + P;
     int* slot = goff + P + 1;
+    int* scnt = slot + P;
+    uint8_t* nm = smem + L.nm;
+    uint8_t* midx = smem + L.midx;
     __shared__ int s_err, s_nout;
 
     const CameraTable* cams = a.cams;
-    auto cnt = [&](int c) { return a.counts[(size_t)t * a.cnt_st + (size_t)c * a.cnt_sc]; };
     // element offset (in points) of camera c's list; strides are given in scalars, a point is 2 scalars
     auto pbase = [&](int c) { return ((size_t)t * a.pt_st + (size_t)c * a.pt_sc) / 2; };
+    // ---- the one round of loads: counts, points (every slot up to P: the address does not depend on the count), cameras ----
     if (tid == 0) { s_err = 0; s_nout = 0; }
+    if (tid < C) scnt[tid] = a.counts[(size_t)t * a.cnt_st + (size_t)tid * a.cnt_sc];
+    if (L.stage_pts)
+        for (int w = tid; w < C * P; w += nth) {
+            const int c = w / P, p = w - c * P;
+            double x, y;
+            load_pt<PT>(a.pts, pbase(c) + p, x, y);
+            spts[2 * w] = x; spts[2 * w + 1] = y;
+        }
+    for (int w = tid; w < C * 26; w += nth) {
+        const int c = w / 26, k = w - c * 26;
+        cam[c][12 + k] = k < 9 ? cams->K[c][k] : (k < 14 ? cams->dist[c][k - 9] : (k < 23 ? cams->R[c][k - 14] : cams->t[c][k - 23]));
+    }
+    for (int w = tid; w < (C - 1) * 9; w += nth) Fm[w / 9][w % 9] = cams->F[w / 9][w % 9];
     __syncthreads();
+    for (int w = tid; w < C * 12; w += nth) { // P = K @ [R|t], the sums in the order of reference lib/Helpers.py:58-62 (as DltAcc::add forms them)
+        const int c = w / 12, r = (w % 12) / 4, cc = w % 4;
+        const double* K = &cam[c][12]; const double* R = &cam[c][26]; const double* tt = &cam[c][35];
+        double sum = 0;
+        for (int k = 0; k < 3; k++) sum += K[3 * r + k] * (cc < 3 ? R[3 * k + cc] : tt[k]);
+        cam[c][4 * r + cc] = sum;
+    }
     // A camera whose count does not fit the P points read here, or whose blob stage reported a capacity error (negative
     // count), fails the time step: the reference has no such limits (lib/Helpers.py:191,203-245), so a shortened list
     // must never pass for a result.  s_err: 1 = groups, 2 = more than P points, 3 = negative count.
     if (tid < C) {
-        const int n = cnt(tid);
+        const int n = scnt[tid];
         if (n < 0) atomicMax(&s_err, 3);
         else if (n > P) atomicMax(&s_err, 2);
     }
@@ -241,21 +310,25 @@ __global__ __launch_bounds__(256) void correspond_kernel(CorrArgs a)
         if (tid == 0) a.n_roots[t] = s_err == 3 ? CORR_ERR_BLOB : CORR_ERR_TRUNCATED;
         return;
     }
-    const int n0 = cnt(0);
+    auto getp = [&](int c, int p, double& x, double& y) {
+        if (L.stage_pts) { x = spts[2 * (c * P + p)]; y = spts[2 * (c * P + p) + 1]; }
+        else load_pt<PT>(a.pts, pbase(c) + p, x, y);
+    };
+    const int n0 = scnt[0];
 
     // ---- phase 1: per (root, camera) candidate lists, sorted by distance to the epipolar line -----------
-    for (int w = tid; w < n0 * (C - 1); w += blockDim.x) {
+    for (int w = tid; w < n0 * (C - 1); w += nth) {
         int j = w / (C - 1), i = 1 + w % (C - 1);
         double rx, ry;
-        load_pt<PT>(a.pts, pbase(0) + j, rx, ry);
+        getp(0, j, rx, ry);
         float line[3];
-        epiline(cams->F[i - 1], (float)rx, (float)ry, line);
+        epiline(Fm[i - 1], (float)rx, (float)ry, line);
         double md[MAXM];
-        int mi[MAXM], k = 0, ni = cnt(i);
+        int mi[MAXM], k = 0, ni = scnt[i];
         bool over = false;
         for (int p = 0; p < ni; p++) {
             double x, y;
-            load_pt<PT>(a.pts, pbase(i) + p, x, y);
+            getp(i, p, x, y);
             double d = epi_distance(line, x, y);
             if (d < a.cutoff) {
                 if (k == MAXM) { over = true; break; }
@@ -270,7 +343,7 @@ __global__ __launch_bounds__(256) void correspond_kernel(CorrArgs a)
     }
     __syncthreads();
     // ---- group counts and offsets ---------------------------------------------------------------------------
-    for (int j = tid; j < n0; j += blockDim.x) {
+    for (int j = tid; j < n0; j += nth) {
         long g = C >= 2 ? 1 : 0;
         for (int i = 1; i < C; i++) {
             g *= nm[j * C + i];
@@ -296,7 +369,9 @@ __global__ __launch_bounds__(256) void correspond_kernel(CorrArgs a)
     }
     // ---- phase 2: one candidate group per lane: DLT + reprojection error --------------------------------
     const int total = goff[n0];
-    for (int w = tid; w < total; w += blockDim.x) {
+    const bool err_in_lds = total <= L.err_cap;
+    double* const errs = err_in_lds ? serr : a.scratch + (size_t)t * a.step_budget;
+    for (int w = tid; w < total; w += nth) {
         int lo = 0, hi = n0 - 1; // root owning flat group index w
         while (lo < hi) {
             int mid = (lo + hi + 1) >> 1;
@@ -305,24 +380,24 @@ __global__ __launch_bounds__(256) void correspond_kernel(CorrArgs a)
         while (G[lo] == 0) lo++; // skip dead roots sharing the offset
         int j = lo, g = w - goff[j], rem = g;
         double gx[32], gy[32];
-        load_pt<PT>(a.pts, pbase(0) + j, gx[0], gy[0]);
+        getp(0, j, gx[0], gy[0]);
         DltAcc acc;
         acc.clear();
-        acc.add(cams->K[0], cams->R[0], cams->t[0], gx[0], gy[0]);
+        acc.add_rows(cam[0], gx[0], gy[0]);
         for (int i = 1; i < C; i++) { // camera 1 is the fastest-varying digit (reference lib/Helpers.py:239-245)
             int n_i = nm[j * C + i], dgt = rem % n_i;
             rem /= n_i;
             int p = midx[((size_t)j * C + i) * MAXM + dgt];
-            load_pt<PT>(a.pts, pbase(i) + p, gx[i], gy[i]);
-            acc.add(cams->K[i], cams->R[i], cams->t[i], gx[i], gy[i]);
+            getp(i, p, gx[i], gy[i]);
+            acc.add_rows(cam[i], gx[i], gy[i]);
         }
         double X[3];
         acc.solve(X);
         float Xf[3] = {(float)X[0], (float)X[1], (float)X[2]};
         double e[64];
-        for (int i = 0; i < C; i++) reproj_sq(cams->K[i], cams->dist[i], cams->R[i], cams->t[i], Xf, gx[i], gy[i], e[2 * i], e[2 * i + 1]);
+        for (int i = 0; i < C; i++) reproj_sq(&cam[i][12], &cam[i][21], &cam[i][26], &cam[i][35], Xf, gx[i], gy[i], e[2 * i], e[2 * i + 1]);
         double mse = np_block_sum(e, 2 * C) / (double)(2 * C);
-        a.scratch[(size_t)t * a.step_budget + goff[j] + g] = mse;
+        errs[goff[j] + g] = mse;
         if (g == 0) {
             int o = slot[j];
             size_t ro = (size_t)t * P + o;
@@ -331,22 +406,22 @@ __global__ __launch_bounds__(256) void correspond_kernel(CorrArgs a)
             a.root_idx[ro] = j;
         }
     }
-    __syncthreads(); // scratch is read back by other lanes of this workgroup
+    __syncthreads(); // the errors are read back by other lanes of this workgroup
     __threadfence_block();
     // ---- phase 3: per-root mean over its groups (NumPy pairwise order), then argsort ---------------------
-    for (int j = tid; j < n0; j += blockDim.x) {
+    for (int j = tid; j < n0; j += nth) {
         if (G[j] == 0) continue;
-        const double* e = a.scratch + (size_t)t * a.step_budget + goff[j];
-        a.root_err[(size_t)t * P + slot[j]] = np_pairwise_sum(e, G[j]) / (double)G[j];
+        const double m = np_pairwise_sum(errs + goff[j], G[j]) / (double)G[j];
+        rerr[slot[j]] = m;
+        a.root_err[(size_t)t * P + slot[j]] = m;
     }
     __syncthreads();
-    __threadfence_block();
     const int nout = s_nout;
-    for (int o = tid; o < nout; o += blockDim.x) {
-        double eo = a.root_err[(size_t)t * P + o];
+    for (int o = tid; o < nout; o += nth) {
+        double eo = rerr[o];
         int rank = 0;
         for (int q = 0; q < nout; q++) {
-            double eq = a.root_err[(size_t)t * P + q];
+            double eq = rerr[q];
             rank += (eq < eo) || (eq == eo && q < o);
         }
         a.order[(size_t)t * P + rank] = o;
@@ -524,10 +599,7 @@ __global__ __launch_bounds__(256) void ba_residuals_kernel(BaArgs a)
     if (tid == 0) a.counts[b] = s_base;
 }
 
-size_t correspond_smem_bytes(int P, int C)
-{
-    return (size_t)P * C + (size_t)P * C * MAXM + 8 + sizeof(int) * (3 * (size_t)P + 2);
-}
+size_t correspond_smem_bytes(int P, int C) { return (size_t)corr_lds_plan(P, C).total; }
 
 void launch_correspond(const CorrArgs& a, hipStream_t s)
 {

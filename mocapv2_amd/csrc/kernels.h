@@ -114,9 +114,14 @@ struct ContourArgs {
     uint64_t* timing;      // optional [n_images][8] phase clock (debugging aid), else null
     void* work;            // [n_images] per-image workspace of contour_work_bytes() each
     int prio;              // wave priority (s_setprio 0..3): the walks are serial chains, cheap to favour and costly to delay
-    uint32_t* walk_list;   // split form: [n_images * contour_walk_bytes() / 4] entries image << 10 | candidate, or null = one kernel per image
-    uint32_t* walk_count;  // split form: number of entries (zeroed by launch_contours)
+    uint64_t* walk_list;   // split form: [n_images * contour_walk_bytes() / 8] candidate walks of the batch (blob_contours.hip: walk_entry), or
+                           //   null = one kernel per image
+    uint64_t* link_list;   // split form: [n_images * contour_link_bytes() / 8] link walks of the batch (second follow pass)
+    uint32_t* walk_count;  // split form: [4] entries in walk_list, its head, entries in link_list, its head (zeroed by launch_contours)
     int follow_grid;       // split form: workgroups (waves) of the follow kernel
+    int follow_grid2;      //   ... of its second pass (the link walks: few)
+    int follow_list;       // set by launch_contours: 0 = the follow kernel works through walk_list, 1 = through link_list
+    int tree_pass;         // set by launch_contours: 1 / 2 = first / second pass of the tree kernel
 };
 
 enum { BLOB_ERR_CANDIDATES = -2, BLOB_ERR_CONTOURS = -3, BLOB_ERR_STEPS = -4, BLOB_ERR_DEPTH = -5 };
@@ -140,6 +145,8 @@ struct BrightArgs {
     // base `base_alt` / threshold `hot_alt`, into probe[2 * (block & 127) + 0 / 1]: the host compares the sums and switches
     uint32_t* probe; int base_alt, hot_alt;
     int prio;                     // wave priority of the scan (s_setprio): its few instructions are loads that keep HBM busy
+    int max_blocks;               // > 0: launch at most this many workgroups, each looping over the batch's blocks (persistent form)
+    int blocks_x;                 // blocks of 256 threads per image (set by launch_bright_cells)
 };
 void launch_bright_cells(const BrightArgs& a, hipStream_t s);
 // set-up statistics of an undistort table, for the dark-tile bound: stats[0] = largest total blend weight any source
@@ -154,6 +161,7 @@ void launch_undistort_map(const MapArgs& m, hipStream_t s);
 void launch_contours(const ContourArgs& a, hipStream_t s);
 size_t contour_work_bytes();
 size_t contour_walk_bytes(); // walk list bytes per image (split form of the contour stage)
+size_t contour_link_bytes(); // link list bytes per image
 void launch_box_blur(const uint8_t* src, uint8_t* dst, int H, int W, int sp, int dp, int ksize, hipStream_t s);
 void launch_undistort(const uint8_t* src, uint8_t* dst, int H, int W, int sp, int dp, const uint32_t* map, const uint32_t* mapw,
                       hipStream_t s);

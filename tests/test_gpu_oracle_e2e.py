@@ -102,10 +102,10 @@ def test_replay_tracker_matches_oracle_per_time_step():
     frames = np.empty((T, C, H, W), np.uint8)
     for s in range(T):
         rng = np.random.default_rng(900 + s)
-        mk = sc.markers(rng, max(1, n_markers[s]), extent=0.4)[:n_markers[s]]
+        mk = sc.markers(rng, max(1, n_markers[s]), extent=0.9)[:n_markers[s]]
         for c in range(C):
             frames[s, c] = sc.render(np.random.default_rng(9000 + 10 * s + c), mk, c, radius_range=(14.0, 17.0), salt=0.001)
-    obj_count = 4
+    obj_count = 2  # the scene gives 3, 3, 0, 1, 6, 1, 2 triangulated roots: kept whole, kept whole, none, fewer than obj_count, cut to 3, ...
     got = list(ReplayTracker(K, dist, R, t, F, W, H, batch=4, obj_count=obj_count).run(frames))  # 7 steps: one padded batch
     assert len(got) == T
     point = [0, 0, 0, 0, 0, 0, 0, 0]  # RealtimeTracking_FLIR.py:171
@@ -125,7 +125,7 @@ def test_replay_tracker_matches_oracle_per_time_step():
             assert np.abs(np.array(point[4:]) - obj[0]).max() < TOL_XYZ
         assert got[s]["message"] == tracker_message(point), s
         sizes.append(len(obj))
-    assert sizes[0] == obj_count + 1 and sizes[2] == 0 and 0 < sizes[3] <= 3, sizes
+    assert sizes == [3, 3, 0, 1, 3, 1, 2], sizes
     assert got[2]["message"] == got[1]["message"]  # nothing found: the previous message again
 
 
@@ -136,14 +136,14 @@ def test_eight_cameras_one_per_rank_layout_matches_oracle():
     record and every time step is compared with the oracle."""
     import torch
     from mocapv2_amd.pipeline import BatchTracker, scene_arrays
-    C, T, W, H, world = 8, 1, 640, 360, 8
+    C, T, W, H, world = 8, 1, 1280, 720, 8
     sc = Scene(C, W, H, dist=MILD_DIST)
     K, dist, R, t, F = scene_arrays(sc)
     t_total = T * world
-    markers = [sc.markers(np.random.default_rng(300 + s), 6, extent=0.5) for s in range(t_total)]
+    markers = [sc.markers(np.random.default_rng(300 + s), 5, extent=0.8) for s in range(t_total)]
 
     def frame(c, s):
-        return sc.render(np.random.default_rng(3000 + 10 * s + c), markers[s], c, radius_range=(14.0, 17.0), salt=0.001)
+        return sc.render(np.random.default_rng(3000 + 10 * s + c), markers[s], c, radius_range=(17.0, 20.0), salt=0.001)
 
     trackers = [BatchTracker(K, dist, R, t, F, W, H, T, world=world, rank=r) for r in range(world)]
     recs = []
@@ -164,7 +164,7 @@ def test_eight_cameras_one_per_rank_layout_matches_oracle():
             s = r * T + j
             lists, ref = oracle_step(np.stack([frame(c, s) for c in range(C)]), K, dist, R, t, F)
             points += assert_step_equal(out, j, ref, (r, s))
-    assert points >= 4 * t_total
+    assert points >= 3 * t_total  # (the oracle gives 35 triangulated roots for these 8 time steps)
 
 
 def test_epipolar_scores_k2_bundled_pairs():
