@@ -67,7 +67,7 @@ struct Tuning {
     int box_prio = 0, scan_prio = 0, contour_prio = 0, corr_prio = 0; // wave priorities
     int box_stage_bytes = BOX_SCAP; // LDS the box kernel's source staging may use (0 = taps from memory)
     int box_blocks_per_cu = 0;   // 0 = box_filter_blocks_per_cu()
-    int box_timing = 0, contour_timing = 0; // phase clocks on stderr (synchronous debugging aids)
+    int box_timing = 0, contour_timing = 0, follow_timing = 0; // phase clocks on stderr (synchronous debugging aids)
     int scan_wide = 1;           // 0 = the scan's 8-byte loads
     int scan_blocks_per_cu = 0;  // > 0: the scan as a persistent pass of that many workgroups per CU (0 = one workgroup per block)
     int excess_base = -1;        // >= 0: pins the scan's excess base
@@ -87,7 +87,7 @@ static const TuneName kTuneNames[] = {
     {"box_prio", &Tuning::box_prio, 0, 1}, {"scan_prio", &Tuning::scan_prio, 0, 3}, {"contour_prio", &Tuning::contour_prio, 0, 3},
     {"corr_prio", &Tuning::corr_prio, 0, 3}, {"box_stage_bytes", &Tuning::box_stage_bytes, 0, BOX_SCAP},
     {"box_blocks_per_cu", &Tuning::box_blocks_per_cu, 0, 32}, {"box_timing", &Tuning::box_timing, 0, 1},
-    {"contour_timing", &Tuning::contour_timing, 0, 1}, {"scan_wide", &Tuning::scan_wide, 0, 1}, {"scan_blocks_per_cu", &Tuning::scan_blocks_per_cu, 0, 64}, {"excess_base", &Tuning::excess_base, -1, 254},
+    {"contour_timing", &Tuning::contour_timing, 0, 1}, {"follow_timing", &Tuning::follow_timing, 0, 1}, {"scan_wide", &Tuning::scan_wide, 0, 1}, {"scan_blocks_per_cu", &Tuning::scan_blocks_per_cu, 0, 64}, {"excess_base", &Tuning::excess_base, -1, 254},
     {"base_sel", &Tuning::base_sel, 0, 1}, {"probe_debug", &Tuning::probe_debug, 0, 1}, {"contour_boxes", &Tuning::contour_boxes, 0, 1},
     {"contours_split", &Tuning::contours_split, 0, 1}, {"corr_threads", &Tuning::corr_threads, 64, 256},
     {"corr_step_groups", &Tuning::corr_step_groups, 0, 0x7fffffff},
@@ -806,7 +806,11 @@ static int run_contours(mocap_ctx* c, const uint32_t* mask, const uint32_t* cell
     a.walk_list = split ? c->walk_list : nullptr; a.link_list = c->link_list; a.walk_count = c->walk_count;
     a.follow_grid = c->n_cu * 4;  // 4 one-wave workgroups per CU (33 KB of LDS each): persistent, they refill their lanes from the list
     a.follow_grid2 = c->n_cu;     // the link walks are few
-    a.follow_list = 0; a.tree_pass = 0;
+    a.follow_list = 0; a.tree_pass = 0; a.follow_dbg = nullptr;
+    if (c->tune.follow_timing && split) {
+        HIP_TRY(hipMalloc(&a.follow_dbg, sizeof(uint64_t) * 8 * a.follow_grid));
+        HIP_TRY(hipMemsetAsync(a.follow_dbg, 0, sizeof(uint64_t) * 8 * a.follow_grid, s));
+    }
     a.prio = c->tune.contour_prio; // A/B switch (no effect measured)
     a.timing = nullptr;
     const bool phase_timing = c->tune.contour_timing != 0;
@@ -819,6 +823,25 @@ static int run_contours(mocap_ctx* c, const uint32_t* mask, const uint32_t* cell
     launch_contours(a, s);
     prof_end(c, 1, s, p, on);
     HIP_TRY(hipGetLastError());
+    if (a.follow_dbg) {
+        std::vector<uint64_t> t((size_t)8 * a.follow_grid);
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipMemcpy(t.data(), a.follow_dbg, sizeof(uint64_t) * t.size(), hipMemcpyDeviceToHost));
+        (void)hipFree(a.follow_dbg);
+        double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mx[3] = {0, 0, 0}, mxsteps = 0; int used = 0;
+        for (int b = 0; b < a.follow_grid; b++) {
+            if (t[8 * b + 5] == 0) continue;
+            used++;
+            for (int i = 0; i < 8; i++) sum[i] += (double)t[8 * b + i];
+            for (int i = 0; i < 3; i++) mx[i] = (double)t[8 * b + i] > mx[i] ? (double)t[8 * b + i] : mx[i];
+            mxsteps = (double)t[8 * b + 3] > mxsteps ? (double)t[8 * b + 3] : mxsteps;
+        }
+        const double u = used ? used : 1;
+        fprintf(stderr, "[follow] %d of %d waves had work | per wave (mean / max us): store %.1f / %.1f, refill %.1f / %.1f, walk %.1f / %.1f | wave steps %.0f (max %.0f), "
+                        "lanes alive per step %.1f, walks %.1f, refills %.1f | us per wave step %.3f\n",
+                used, a.follow_grid, sum[0] / u / 100, mx[0] / 100, sum[1] / u / 100, mx[1] / 100, sum[2] / u / 100, mx[2] / 100, sum[3] / u, mxsteps,
+                sum[3] > 0 ? sum[4] / sum[3] : 0.0, sum[5] / u, sum[6] / u, sum[3] > 0 ? sum[2] / 100 / sum[3] : 0.0);
+    }
     if (phase_timing) {
         std::vector<uint64_t> t((size_t)8 * n_images);
         HIP_TRY(hipStreamSynchronize(s));

@@ -758,14 +758,14 @@ constexpr int FOLLOW_K = 16;      // steps between two looks at the lanes
 constexpr int FOLLOW_REFILL = 16; // idle lanes that make a refill worth its three dependent memory round trips
 
 struct Walk { // one lane's walk
-    const uint32_t* mw;  // mask of its image
     uint64_t rU, rM, rD; // the three 64-column mask rows around the current pixel
     int64_t a00, a10, a01;
     double diag, pend;
-    int sx, sy, i1x, i1y, x, y, x0, s, prev_s, run, first_len, axis, npts, steps, min_fg, min_ebg, bx0, bx1, by0, by1;
+    int sx, sy, i1x, i1y, x, y, s, prev_s, run, first_len, axis, npts, steps, min_fg, min_ebg, bx0, bx1, by0, by1;
+    int wx0, wy0;        // the lane's window in LDS: columns wx0 .. wx0 + 63, rows wy0 .. wy0 + 63 of its image's mask
     int abort_lt, key;
     uint32_t n, meta;    // meta: kind | border << 2 | image << 11 (kind 0 outer / 1 hole candidate, 2 / 3 link walks)
-    bool abort_on_fg, staged;
+    bool abort_on_fg;
     int status;          // 0 closed, 1 aborted, 2 step limit
 };
 
@@ -782,18 +782,20 @@ __global__ __launch_bounds__(64) void contour_follow_kernel(ContourArgs a)
     const uint32_t image_words = (uint32_t)a.H * (uint32_t)a.words_per_row;
     const int RS = a.W + 1;
     Walk w;
-    w.mw = a.mask; w.staged = false; w.status = 0; w.meta = 0; w.n = 0; w.s = 0;
-    bool active = false, finished = false; // finished: the walk has ended, its record is not stored yet
+    w.status = 0; w.meta = 0; w.n = 0; w.s = 0; w.x = 0; w.y = 0; w.wx0 = 0; w.wy0 = 0;
+    // A lane is idle, or holds a walk that is running, or paused (its next pixel lies at the edge of its window: it waits for
+    // the next look at the lanes, where the window is staged anew around it), or finished (its record is not stored yet).
+    bool active = false, paused = false, finished = false;
     bool drained = false;                  // (wave-uniform) the list has no more entries
+    // optional phase clock (follow_timing = 1, a debugging aid): per wave, 100 MHz ticks in store / refill / walk, wave steps, lane steps, walks, refills
+    uint64_t tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool clk = a.follow_dbg != nullptr && a.follow_list == 0;
+    uint64_t t_prev = clk ? wall_clock64() : 0;
+    auto lap = [&](int i) { if (clk) { const uint64_t t = wall_clock64(); tk[i] += t - t_prev; t_prev = t; } };
     __syncthreads();
-    auto mask_of = [&]() { return Mask{w.mw, a.words_per_row, a.H, a.W, RS}; };
-    auto fetch = [&](int yy) -> uint64_t {
-        const unsigned r = (unsigned)(yy - (w.sy - 1));
-        if (w.staged && r < 64u) return win[r][lane];
-        return row64(mask_of(), yy, w.x0);
-    };
+    auto fetch = [&](int yy) -> uint64_t { return win[(yy - w.wy0) & 63][lane]; }; // the row is inside the window (see the pause rule)
     auto nbr8 = [&]() -> uint32_t {
-        const int c = w.x - w.x0 - 1; // column x-1 at bit 0
+        const int c = w.x - w.wx0 - 1; // column x-1 at bit 0
         const uint32_t up = (uint32_t)(w.rU >> c) & 7u, mid = (uint32_t)(w.rM >> c) & 7u, dn = (uint32_t)(w.rD >> c) & 7u;
         const uint32_t up_rev = (0x73516240u >> (4u * up)) & 7u; // bit order NE, N, NW = columns x+1, x, x-1
         return (mid >> 2) | (up_rev << 1) | ((mid & 1u) << 4) | (dn << 5);
@@ -831,34 +833,64 @@ __global__ __launch_bounds__(64) void contour_follow_kernel(ContourArgs a)
             }
             finished = false;
         }
-        // ---- refill ----
+        lap(0);
+        // ---- refill: new walks for the idle lanes; new windows for them and for the paused walks ----
         const uint64_t busy = __ballot(active);
         const int n_idle = 64 - __popcll(busy);
+        bool take = false;
+        int kind = 0, ex = 0, border = 0;
         if (!drained && (n_idle >= FOLLOW_REFILL || busy == 0)) {
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(head, (uint32_t)n_idle);
             base = (uint32_t)uni((int)base);
             const int n_new = base < total ? (int)(total - base < (uint32_t)n_idle ? total - base : (uint32_t)n_idle) : 0;
             drained = n_new < n_idle;
+            if (clk) { tk[5] += (uint64_t)n_new; tk[6]++; }
             const int rank = __popcll(~busy & ((1ull << lane) - 1ull)); // this lane's number among the idle ones
-            const bool take = !active && rank < n_new;
+            take = !active && rank < n_new;
             uint64_t e = 0;
             if (take) e = list[base + (uint32_t)rank];
-            const int ex = (int)(e & 0x7fffu), ey = (int)((e >> 15) & 0x7fffu), kind = (int)((e >> 30) & 3u);
-            const int image = (int)((e >> 32) & 0xfffffu), border = (int)((e >> 52) & 511u);
-            const int sx = ex - (kind == 1 ? 1 : 0); // a hole candidate's border pixel lies left of its scan position
-            // the windows of the new walks: lane = row, one new walk per round (all rounds' loads are independent)
-            for (uint64_t todo = __ballot(take); todo; todo &= todo - 1) {
-                const int c = __ffsll((long long)todo) - 1;
-                const int img_c = __builtin_amdgcn_readlane(image, c), sx_c = __builtin_amdgcn_readlane(sx, c), sy_c = __builtin_amdgcn_readlane(ey, c);
-                const Mask Mc{a.mask + (size_t)img_c * image_words, a.words_per_row, a.H, a.W, RS};
-                win[lane][c] = row64(Mc, sy_c - 1 + lane, sx_c - 31);
+            ex = (int)(e & 0x7fffu); kind = (int)((e >> 30) & 3u); border = (int)((e >> 52) & 511u);
+            if (take) {
+                const int ey = (int)((e >> 15) & 0x7fffu);
+                const int sx = ex - (kind == 1 ? 1 : 0); // a hole candidate's border pixel lies left of its scan position
+                w.meta = (uint32_t)kind | ((uint32_t)border << 2) | ((uint32_t)((e >> 32) & 0xfffffu) << 11);
+                w.sx = sx; w.sy = ey; w.x = sx; w.y = ey;
+                w.wx0 = sx - 31; w.wy0 = ey - 1; // the walk starts at its border's topmost row: the window reaches down from there
+            }
+        }
+        if (paused) { w.wx0 = w.x - 31; w.wy0 = w.y - 31; } // anew around the current pixel
+        const uint64_t stage = __ballot(take || paused);
+        if (stage) {
+            // lane = row of the window, eight windows per round so that their 24 loads are in flight together
+            const int image = (int)(w.meta >> 11);
+            for (uint64_t todo = stage; todo;) {
+                int cs[8];
+                uint64_t rows[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    cs[j] = todo ? __ffsll((long long)todo) - 1 : -1;
+                    todo &= todo - 1; // (0 & anything = 0)
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int c = cs[j] < 0 ? cs[0] : cs[j]; // a short last round repeats its first window (not stored)
+                    const int img_c = __builtin_amdgcn_readlane(image, c), x0_c = __builtin_amdgcn_readlane(w.wx0, c), y0_c = __builtin_amdgcn_readlane(w.wy0, c);
+                    const Mask Mc{a.mask + (size_t)img_c * image_words, a.words_per_row, a.H, a.W, RS};
+                    rows[j] = row64(Mc, y0_c + lane, x0_c);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    if (cs[j] >= 0) win[lane][cs[j]] = rows[j];
             }
             __syncthreads(); // (one wave) the windows are in LDS before any lane reads its own
+            if (take || paused) {
+                w.rU = fetch(w.y - 1); w.rM = fetch(w.y); w.rD = fetch(w.y + 1);
+                w.n = nbr8();
+                paused = false;
+            }
             if (take) {
-                w.mw = a.mask + (size_t)image * image_words;
-                w.meta = (uint32_t)kind | ((uint32_t)border << 2) | ((uint32_t)image << 11);
-                w.sx = sx; w.sy = ey; w.x = sx; w.y = ey; w.x0 = sx - 31; w.staged = true;
+                const int sx = w.sx, ey = w.sy;
                 w.key = ey * RS + ex;
                 const int first = (kind == 0 || kind == 2) ? 4 : 0; // the neighbour known to be background: W (outer start) / E
                 w.abort_on_fg = kind == 0;
@@ -866,8 +898,6 @@ __global__ __launch_bounds__(64) void contour_follow_kernel(ContourArgs a)
                 w.a00 = w.a10 = w.a01 = 0; w.npts = 0; w.steps = 0;
                 w.min_fg = ey * RS + sx; w.min_ebg = 0x7fffffff;
                 w.bx0 = w.bx1 = sx; w.by0 = w.by1 = ey;
-                w.rU = fetch(ey - 1); w.rM = fetch(ey); w.rD = fetch(ey + 1);
-                w.n = nbr8();
                 int s = first;
                 do {
                     s = (s - 1) & 7;
@@ -884,10 +914,11 @@ __global__ __launch_bounds__(64) void contour_follow_kernel(ContourArgs a)
                 }
             }
         }
+        lap(1);
         if (__ballot(active || finished) == 0) break; // nothing in flight (and nothing left in the list, or the refill would have run)
-        // ---- FOLLOW_K steps of every live walk ----
+        // ---- FOLLOW_K steps of every running walk ----
         for (int k = 0; k < FOLLOW_K; k++) {
-            if (active) {
+            if (active && !paused) {
                 const int s_end = w.s;
                 // first occupied neighbour counter-clockwise from s_end+1
                 const uint32_t rot = ((w.n | (w.n << 8)) >> (s_end + 1)) & 0xffu;
@@ -933,28 +964,27 @@ __global__ __launch_bounds__(64) void contour_follow_kernel(ContourArgs a)
                 } else {
                     w.bx0 = nx < w.bx0 ? nx : w.bx0; w.bx1 = nx > w.bx1 ? nx : w.bx1;
                     w.by0 = ny < w.by0 ? ny : w.by0; w.by1 = ny > w.by1 ? ny : w.by1;
-                    // move, keeping the three cached rows around the current pixel
-                    const int lx = nx - w.x0;
-                    if (lx < 1 || lx > 62) { // left the window: re-centre it on the new pixel (rare), or return to the staged one
-                        const int wl = nx - (w.sx - 31); // column of the new pixel in the staged window
-                        w.staged = wl >= 1 && wl <= 62;
-                        w.x0 = w.staged ? w.sx - 31 : nx - 31;
-                        w.rU = fetch(ny - 1); w.rM = fetch(ny); w.rD = fetch(ny + 1);
-                    } else {
-                        const uint64_t nw = fetch(ny + dy); // (dy = 0: the middle row again, unused)
-                        const uint64_t oU = w.rU, oM = w.rM, oD = w.rD;
-                        w.rU = dy > 0 ? oM : (dy < 0 ? nw : oU);
-                        w.rM = dy > 0 ? oD : (dy < 0 ? oU : oM);
-                        w.rD = dy > 0 ? nw : (dy < 0 ? oM : oD);
-                    }
+                    // move.  The three rows around the new pixel and its left / right neighbour columns must lie inside the window:
+                    // a walk that steps onto the window's rim pauses until its window is staged anew (no global load in this loop).
+                    const int lx = nx - w.wx0, ly = ny - w.wy0;
+                    paused = lx < 1 || lx > 62 || ly < 1 || ly > 62;
+                    const uint64_t nw = fetch(ny + dy); // (dy = 0: the middle row again, unused; a paused lane reads some row of its own window)
+                    const uint64_t oU = w.rU, oM = w.rM, oD = w.rD;
+                    w.rU = dy > 0 ? oM : (dy < 0 ? nw : oU);
+                    w.rM = dy > 0 ? oD : (dy < 0 ? oU : oM);
+                    w.rD = dy > 0 ? nw : (dy < 0 ? oM : oD);
                     w.x = nx; w.y = ny;
                     w.s = (s + 4) & 7;
-                    w.n = nbr8();
+                    w.n = nbr8(); // (garbage while paused: recomputed with the new window)
                 }
             }
-            if (__ballot(active) == 0) break;
+            if (clk) { tk[3]++; tk[4] += (uint64_t)__popcll(__ballot(active && !paused)); }
+            if (__ballot(active && !paused) == 0) break;
         }
+        lap(2);
     }
+    if (clk && lane == 0)
+        for (int i = 0; i < 8; i++) a.follow_dbg[(size_t)blockIdx.x * 8 + i] = tk[i];
 }
 
 size_t contour_work_bytes() { return sizeof(ContourWork); }
