@@ -90,6 +90,21 @@ MOCAP_API int mocap_set_tuning(mocap_ctx_t ctx, const char* name, int value);
  * on the device (synchronous).  identity_out (optional) receives 1 when the table is the identity. */
 MOCAP_API int mocap_set_undistort(mocap_ctx_t ctx, int slot, const double K[9], const double dist[5], int* identity_out);
 
+/* What mocap_set_undistort found out about a slot's table -- and with it, which road the slot's images take in
+ * mocap_blob_centroids.  The sparse road (one streaming pass that proves most of a dark IR frame's mask zero, then the
+ * filter on the marked tiles only) needs (a) a provable early-out: every 5x5 window of the undistorted image reads at most
+ * 9 x 9 source pixels, and (b) the compact table: tap displacements within 11 bits.  A lens model outside either bound is
+ * still filtered exactly, but every tile of every image goes through the dense row pipeline: the same results at about 7x
+ * the time on a dark scene.  This call makes that visible instead of silent (sparse_path = 0). */
+typedef struct mocap_undistort_info_t {
+    int32_t identity;            /* the table is the identity (zero distortion) */
+    int32_t compact_table;       /* displacements fit the box kernel's 4-byte table */
+    int32_t early_out_provable;  /* the dark-tile bound holds for this table */
+    int32_t max_source_weight;   /* largest total blend weight of one source pixel over all output pixels (1024 = one pixel; 0 = not provable) */
+    int32_t sparse_path;         /* 1 = images of this slot take the sparse road (also needs the tuning switches at their defaults) */
+} mocap_undistort_info_t;
+MOCAP_API int mocap_undistort_info(mocap_ctx_t ctx, int slot, mocap_undistort_info_t* out);
+
 /* camera_params + camera_poses of lib/Helpers.py (K_i, dist_i from jsons/camera-params-in.json :30-40,
  * R_i, t_i from get_extrinsics :282-291); n <= 32.  Synchronous host->device copy. */
 MOCAP_API int mocap_set_cameras(mocap_ctx_t ctx, int n, const double* K /*[n][9]*/, const double* dist /*[n][5]*/,

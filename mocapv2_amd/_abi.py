@@ -19,6 +19,11 @@ class BlobParams(C.Structure):
                 ("min_circ", C.c_double)]
 
 
+class UndistortInfo(C.Structure):
+    _fields_ = [("identity", C.c_int32), ("compact_table", C.c_int32), ("early_out_provable", C.c_int32),
+                ("max_source_weight", C.c_int32), ("sparse_path", C.c_int32)]
+
+
 class Contour(C.Structure):
     _fields_ = [("key", C.c_int32), ("is_hole", C.c_int32), ("sx", C.c_int32), ("sy", C.c_int32), ("npts", C.c_int32),
                 ("steps", C.c_int32), ("a00", C.c_int64), ("a10", C.c_int64), ("a01", C.c_int64), ("area", C.c_double),
@@ -39,6 +44,7 @@ SIGNATURES = {
     "mocap_set_blob_params": [_vp, C.POINTER(BlobParams)],
     "mocap_set_tuning": [_vp, C.c_char_p, _i],
     "mocap_set_undistort": [_vp, _i, _dp, _dp, _ip],
+    "mocap_undistort_info": [_vp, _i, C.POINTER(UndistortInfo)],
     "mocap_set_cameras": [_vp, _i, _dp, _dp, _dp, _dp],
     "mocap_set_fundamentals": [_vp, _i, _dp],
     "mocap_blob_centroids": [_vp, _vp, _i, _i, _i, _sz, _i, _vp, _l, _vp, _l, _i, _vp],

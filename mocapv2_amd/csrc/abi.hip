@@ -428,6 +428,21 @@ int mocap_set_undistort(mocap_ctx_t c, int slot, const double K[9], const double
     return MOCAP_OK;
 }
 
+int mocap_undistort_info(mocap_ctx_t c, int slot, mocap_undistort_info_t* out)
+{
+    if (!c || !out) return fail(MOCAP_E_INVALID, "null argument");
+    if (slot < 0 || slot >= c->n_slots) return fail(MOCAP_E_INVALID, "slot %d out of range", slot);
+    if (c->slot_state[slot] == 0) return fail(MOCAP_E_STATE, "mocap_set_undistort was not called for slot %d", slot);
+    out->identity = c->slot_state[slot] == 1;
+    out->compact_table = c->slot_compact[slot] != 0 && c->W >= 8;
+    out->early_out_provable = c->slot_wmax[slot] != 0 && c->W >= 8;
+    out->max_source_weight = (int32_t)c->slot_wmax[slot];
+    // the sparse path (streaming scan + box kernel on the marked tiles) needs both; otherwise every tile of every image goes
+    // through the dense row pipeline (same results, ~7x the time on a dark IR scene: DESIGN.md 4.1)
+    out->sparse_path = out->compact_table && out->early_out_provable && c->tune.skip_dark && !c->tune.general_filter;
+    return MOCAP_OK;
+}
+
 int mocap_set_cameras(mocap_ctx_t c, int n, const double* K, const double* dist, const double* R, const double* t)
 {
     if (!c || !K || !dist || !R || !t) return fail(MOCAP_E_INVALID, "null argument");

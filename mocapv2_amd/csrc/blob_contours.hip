@@ -745,46 +745,62 @@ __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a) { con
 // (capping the candidates kernel at 72 registers for 7 workgroups per CU instead of 5 spills 13 of them: 325 k against 337 k frames/s)
 __global__ __launch_bounds__(NTHREADS) void contour_candidates_kernel(ContourArgs a) { contours_body<1>(a); }
 
-// The walks of the whole batch, one lane each, whatever image they belong to: an image of a sparse IR frame has a handful of
-// borders, so a per-image kernel's walking wave runs its ~150 instructions per border step for 8 busy lanes; here every lane
-// of a wave follows a border.  The waves are PERSISTENT and refill their lanes: every FOLLOW_K steps a wave looks at its
-// lanes; those whose walk has ended store their record (one round of atomics and stores for all of them), and when enough
-// lanes are idle the wave takes that many new entries from the batch-wide list (one atomic on its head), stages their mask
-// windows (64 rows x 64 columns from one row above each start, in LDS, row-major over the lanes: bank-conflict-free for
-// lanes at different rows) and starts them -- so a wave's instruction stream is shared by ~64 live walks most of the time,
-// instead of running on for the one long border of a merged pair of markers while its other 63 lanes wait.
-// The walk is `follow` above cut into resumable steps: same neighbour search, same vertex rule, same sums.
+// The walks of the whole batch, whatever image they belong to, TWO LANES PER BORDER: lane 2i follows the border forwards from
+// its start, lane 2i + 1 backwards from the same start (border following is reversible: the backward walk is the forward rule
+// on the vertically mirrored neighbourhood), and the pair stops where the two meet -- half the steps of the longest border, which
+// is what the kernel's duration comes down to (a merged pair of markers has a border of ~900 steps, ~0.5 us each).  Each lane
+// accounts for the forward steps it covers (Green sums, vertices, runs, raster minima, box); the sums add, the two runs that
+// straddle the seams (at the start pixel and at the meeting point) are joined before their float32 lengths are taken, exactly
+// as the reference measures the whole polygon.
+// The waves are PERSISTENT and refill their lane pairs: every FOLLOW_K steps a wave looks at its lanes; pairs whose walk has
+// ended store their record (one round of atomics and stores for all of them), walks that have reached the rim of their mask
+// window pause until it is staged anew around them, and when enough pairs are idle the wave takes that many new entries from
+// the batch-wide list (one atomic on its head).  The windows (64 rows x 64 columns, in LDS, row-major over the lanes:
+// bank-conflict-free for lanes at different rows) are staged by the whole wave, lane = row, eight windows per round; a pair
+// shares one window until one of its lanes leaves it.  No global memory access happens inside the step loop.
+// The step is `follow` above cut into resumable, direction-symmetric steps: same neighbour search, same vertex rule, same sums.
 constexpr int FOLLOW_K = 16;      // steps between two looks at the lanes
-constexpr int FOLLOW_REFILL = 16; // idle lanes that make a refill worth its three dependent memory round trips
+constexpr int FOLLOW_REFILL = 8;  // idle pairs that make a refill worth its three dependent memory round trips
 
-struct Walk { // one lane's walk
+__device__ __forceinline__ int pair_swap(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1 /*quad_perm:[1,0,3,2]*/, 0xf, 0xf, true); }
+__device__ __forceinline__ int64_t pair_swap64(int64_t v)
+{
+    const uint32_t lo = (uint32_t)pair_swap((int)(uint32_t)v), hi = (uint32_t)pair_swap((int)(uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ double pair_swap_f64(double v) { return __longlong_as_double(pair_swap64(__double_as_longlong(v))); }
+
+struct Walk { // one lane's half of a walk
     uint64_t rU, rM, rD; // the three 64-column mask rows around the current pixel
     int64_t a00, a10, a01;
     double diag, pend;
-    int sx, sy, i1x, i1y, x, y, s, prev_s, run, first_len, axis, npts, steps, min_fg, min_ebg, bx0, bx1, by0, by1;
-    int wx0, wy0;        // the lane's window in LDS: columns wx0 .. wx0 + 63, rows wy0 .. wy0 + 63 of its image's mask
-    int abort_lt, key;
-    uint32_t n, meta;    // meta: kind | border << 2 | image << 11 (kind 0 outer / 1 hole candidate, 2 / 3 link walks)
-    bool abort_on_fg;
+    int sx, sy, x, y, known; // start pixel of the border; current pixel; the direction this lane knows there: the way back
+                             //   (forward lane) / the way forward (backward lane)
+    int run, head, axis, npts, steps, min_fg, min_ebg, bx0, bx1, by0, by1;
+    int wx0, wy0, wslot; // the lane's window: columns wx0 .. wx0 + 63, rows wy0 .. wy0 + 63 of its image's mask, in LDS column wslot
+    int abort_lt, key, s0;
+    uint32_t n, meta;    // n: neighbourhood (mirrored for the backward lane); meta: kind | border << 2 | image << 11
+    bool abort_on_fg, has_head;
     int status;          // 0 closed, 1 aborted, 2 step limit
 };
 
 __global__ __launch_bounds__(64) void contour_follow_kernel(ContourArgs a)
 {
-    __shared__ uint64_t win[64][64]; // [row of the window][lane]
+    __shared__ uint64_t win[64][64]; // [row of the window][window]
     __shared__ double diag_len[64];
     const int lane = threadIdx.x;
+    const bool isB = (lane & 1) != 0;
     diag_len[lane] = run_length(1, lane);
     const uint64_t* const list = a.follow_list ? a.link_list : a.walk_list;
     const uint32_t total = a.walk_count[2 * a.follow_list];
-    uint32_t* const head = &a.walk_count[2 * a.follow_list + 1];
+    uint32_t* const head_ctr = &a.walk_count[2 * a.follow_list + 1];
     ContourWork* const works = (ContourWork*)a.work;
     const uint32_t image_words = (uint32_t)a.H * (uint32_t)a.words_per_row;
     const int RS = a.W + 1;
     Walk w;
-    w.status = 0; w.meta = 0; w.n = 0; w.s = 0; w.x = 0; w.y = 0; w.wx0 = 0; w.wy0 = 0;
-    // A lane is idle, or holds a walk that is running, or paused (its next pixel lies at the edge of its window: it waits for
-    // the next look at the lanes, where the window is staged anew around it), or finished (its record is not stored yet).
+    w.status = 0; w.meta = 0; w.n = 0; w.known = 0; w.x = 0; w.y = 0; w.wx0 = 0; w.wy0 = 0; w.wslot = lane; w.steps = 0; w.s0 = 0;
+    // A lane is idle, or holds half a walk that is running, or paused (its pixel lies on the rim of its window: it waits for the
+    // next look at the lanes), or finished (the pair has met, or given up; the record is not stored yet).
     bool active = false, paused = false, finished = false;
     bool drained = false;                  // (wave-uniform) the list has no more entries
     // optional phase clock (follow_timing = 1, a debugging aid): per wave, 100 MHz ticks in store / refill / walk, wave steps, lane steps, walks, refills
@@ -793,75 +809,120 @@ __global__ __launch_bounds__(64) void contour_follow_kernel(ContourArgs a)
     uint64_t t_prev = clk ? wall_clock64() : 0;
     auto lap = [&](int i) { if (clk) { const uint64_t t = wall_clock64(); tk[i] += t - t_prev; t_prev = t; } };
     __syncthreads();
-    auto fetch = [&](int yy) -> uint64_t { return win[(yy - w.wy0) & 63][lane]; }; // the row is inside the window (see the pause rule)
-    auto nbr8 = [&]() -> uint32_t {
+    auto fetch = [&](int yy) -> uint64_t { return win[(yy - w.wy0) & 63][w.wslot]; }; // inside the window (see the pause rule)
+    // occupancy of the 8 neighbours of (x,y), bit s = direction code s (0=E 1=NE 2=N 3=NW 4=W 5=SW 6=S 7=SE) -- for the backward
+    // lane of the vertically mirrored image (rows swapped: NE <-> SE, N <-> S, NW <-> SW)
+    auto nbr8 = [&](bool mirror) -> uint32_t {
         const int c = w.x - w.wx0 - 1; // column x-1 at bit 0
-        const uint32_t up = (uint32_t)(w.rU >> c) & 7u, mid = (uint32_t)(w.rM >> c) & 7u, dn = (uint32_t)(w.rD >> c) & 7u;
+        const uint64_t ru = mirror ? w.rD : w.rU, rd = mirror ? w.rU : w.rD;
+        const uint32_t up = (uint32_t)(ru >> c) & 7u, mid = (uint32_t)(w.rM >> c) & 7u, dn = (uint32_t)(rd >> c) & 7u;
         const uint32_t up_rev = (0x73516240u >> (4u * up)) & 7u; // bit order NE, N, NW = columns x+1, x, x-1
         return (mid >> 2) | (up_rev << 1) | ((mid & 1u) << 4) | (dn << 5);
     };
+    auto on_rim = [&]() { const int lx = w.x - w.wx0, ly = w.y - w.wy0; return lx < 1 || lx > 62 || ly < 1 || ly > 62; };
+    auto close_run = [&](int len, int parity) { // one CHAIN_APPROX_SIMPLE segment of `len` steps: its cv.arcLength term
+        if (parity) w.diag += len < 64 ? diag_len[len] : run_length(1, len);
+        else w.axis += len;
+    };
     for (;;) {
-        // ---- the lanes whose walk has ended store their results (all of them in one round) ----
-        if (finished) {
-            const int kind = (int)(w.meta & 3u), image = (int)(w.meta >> 11), border = (int)((w.meta >> 2) & 511u);
-            ContourWork& work = works[image];
-            if (w.status == 2) atomicMax(&work.st_err, 1);
-            if (kind >= 2) { // a link walk: which border is this?
-                if (w.status == 0) {
-                    const int ltype = w.a00 > 0 ? 1 : 0; // hole borders run the other way round
-                    work.link_key[border] = ltype ? w.min_ebg : w.min_fg;
-                    work.link_type[border] = (uint8_t)ltype;
-                } else atomicMax(&work.st_err, 1);
-            } else if (w.status == 0) {
-                const int slot = atomicAdd(&work.st_nrec, 1);
-                if (slot < MAXR) {
-                    ContourRec r;
-                    r.key = w.key; r.is_hole = kind;
-                    r.sx = w.sx; r.sy = w.sy;
-                    r.npts = w.npts; r.steps = w.steps;
-                    r.a00 = w.a00; r.a10 = w.a10; r.a01 = w.a01;
-                    r.area = fabs((double)w.a00 * 0.5);
-                    r.perimeter = w.npts > 1 ? (double)w.axis + w.diag : 0.0;
-                    r.link = -1; r.parent = -1; r.order = -1;
-                    select_contour(r, a.min_area, a.min_circ);
-                    work.recs[slot] = r;
-                    work.rkey[slot] = w.key; work.rsx[slot] = (int16_t)w.sx; work.rsy[slot] = (int16_t)w.sy;
-                    work.rhole[slot] = (uint8_t)kind; work.rkept[slot] = (uint8_t)r.kept;
-                    work.rbox[slot][0] = (int16_t)w.bx0; work.rbox[slot][1] = (int16_t)w.by0;
-                    work.rbox[slot][2] = (int16_t)w.bx1; work.rbox[slot][3] = (int16_t)w.by1;
+        // ---- the pairs whose walk has ended: the forward lane gathers the backward lane's half and stores the record ----
+        if (__ballot(finished)) {
+            // (both lanes of a pair are finished together; the exchange runs for the whole wave, idle lanes carry zeros)
+            const int64_t o_a00 = pair_swap64(w.a00), o_a10 = pair_swap64(w.a10), o_a01 = pair_swap64(w.a01);
+            const double o_diag = pair_swap_f64(w.diag + w.pend);
+            const int o_axis = pair_swap(w.axis), o_npts = pair_swap(w.npts), o_steps = pair_swap(w.steps), o_run = pair_swap(w.run);
+            const int o_head = pair_swap(w.head), o_has_head = pair_swap(w.has_head ? 1 : 0);
+            const int o_min_fg = pair_swap(w.min_fg), o_min_ebg = pair_swap(w.min_ebg);
+            const int o_bx0 = pair_swap(w.bx0), o_bx1 = pair_swap(w.bx1), o_by0 = pair_swap(w.by0), o_by1 = pair_swap(w.by1);
+            const int o_status = pair_swap(w.status);
+            if (finished && !isB) {
+                const int kind = (int)(w.meta & 3u), image = (int)(w.meta >> 11), border = (int)((w.meta >> 2) & 511u);
+                ContourWork& work = works[image];
+                const bool single = w.npts == 1 && w.steps == 0 && o_steps == 0 && w.status == 0 && w.s0 < 0; // an isolated pixel
+                int status = w.status > o_status ? w.status : o_status;
+                if (!single && status == 0) {
+                    // join the halves: sums add; the run through the start pixel = the two heads (or, when a half has no vertex at
+                    // all, that half's whole run as well), the run through the meeting point = the two tails
+                    w.a00 += o_a00; w.a10 += o_a10; w.a01 += o_a01;
+                    w.diag += w.pend; w.pend = 0.0; w.diag += o_diag; w.axis += o_axis;
+                    w.npts += o_npts; w.steps += o_steps;
+                    w.min_fg = o_min_fg < w.min_fg ? o_min_fg : w.min_fg; w.min_ebg = o_min_ebg < w.min_ebg ? o_min_ebg : w.min_ebg;
+                    w.bx0 = o_bx0 < w.bx0 ? o_bx0 : w.bx0; w.bx1 = o_bx1 > w.bx1 ? o_bx1 : w.bx1;
+                    w.by0 = o_by0 < w.by0 ? o_by0 : w.by0; w.by1 = o_by1 > w.by1 ? o_by1 : w.by1;
+                    const int par0 = w.s0 & 1, par_tail = w.known & 1; // direction parity of the run through the start / of the forward tail
+                    if (w.has_head && o_has_head) {
+                        close_run(w.head + o_head, par0);
+                        close_run(w.run + o_run, par_tail);
+                    } else
+                        close_run((w.has_head ? w.head : 0) + (o_has_head ? o_head : 0) + w.run + o_run, par0);
+                }
+                if (status == 2) atomicMax(&work.st_err, 1);
+                if (kind >= 2) { // a link walk: which border is this?
+                    if (status == 0) {
+                        const int ltype = w.a00 > 0 ? 1 : 0; // hole borders run the other way round
+                        work.link_key[border] = ltype ? w.min_ebg : w.min_fg;
+                        work.link_type[border] = (uint8_t)ltype;
+                    } else atomicMax(&work.st_err, 1);
+                } else if (status == 0) {
+                    const int slot = atomicAdd(&work.st_nrec, 1);
+                    if (slot < MAXR) {
+                        ContourRec r;
+                        r.key = w.key; r.is_hole = kind;
+                        r.sx = w.sx; r.sy = w.sy;
+                        r.npts = w.npts; r.steps = w.steps;
+                        r.a00 = w.a00; r.a10 = w.a10; r.a01 = w.a01;
+                        r.area = fabs((double)w.a00 * 0.5);
+                        r.perimeter = w.npts > 1 ? (double)w.axis + w.diag : 0.0;
+                        r.link = -1; r.parent = -1; r.order = -1;
+                        select_contour(r, a.min_area, a.min_circ);
+                        work.recs[slot] = r;
+                        work.rkey[slot] = w.key; work.rsx[slot] = (int16_t)w.sx; work.rsy[slot] = (int16_t)w.sy;
+                        work.rhole[slot] = (uint8_t)kind; work.rkept[slot] = (uint8_t)r.kept;
+                        work.rbox[slot][0] = (int16_t)w.bx0; work.rbox[slot][1] = (int16_t)w.by0;
+                        work.rbox[slot][2] = (int16_t)w.bx1; work.rbox[slot][3] = (int16_t)w.by1;
+                    }
                 }
             }
             finished = false;
         }
         lap(0);
-        // ---- refill: new walks for the idle lanes; new windows for them and for the paused walks ----
+        // ---- refill: new walks for the idle pairs; new windows for them and for the paused lanes ----
         const uint64_t busy = __ballot(active);
-        const int n_idle = 64 - __popcll(busy);
+        const uint64_t busy_pairs = (busy | (busy >> 1)) & 0x5555555555555555ull; // bit 2i: pair i holds a walk
+        const int n_idle = 32 - __popcll(busy_pairs);
         bool take = false;
-        int kind = 0, ex = 0, border = 0;
+        int kind = 0, ex = 0;
         if (!drained && (n_idle >= FOLLOW_REFILL || busy == 0)) {
             uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(head, (uint32_t)n_idle);
+            if (lane == 0) base = atomicAdd(head_ctr, (uint32_t)n_idle);
             base = (uint32_t)uni((int)base);
             const int n_new = base < total ? (int)(total - base < (uint32_t)n_idle ? total - base : (uint32_t)n_idle) : 0;
             drained = n_new < n_idle;
             if (clk) { tk[5] += (uint64_t)n_new; tk[6]++; }
-            const int rank = __popcll(~busy & ((1ull << lane) - 1ull)); // this lane's number among the idle ones
-            take = !active && rank < n_new;
+            const uint64_t idle_pairs = ~busy_pairs & 0x5555555555555555ull;
+            const int rank = __popcll(idle_pairs & ((1ull << (lane & ~1)) - 1ull)); // this pair's number among the idle ones
+            take = ((idle_pairs >> (lane & ~1)) & 1ull) != 0 && rank < n_new;
             uint64_t e = 0;
             if (take) e = list[base + (uint32_t)rank];
-            ex = (int)(e & 0x7fffu); kind = (int)((e >> 30) & 3u); border = (int)((e >> 52) & 511u);
+            ex = (int)(e & 0x7fffu); kind = (int)((e >> 30) & 3u);
             if (take) {
                 const int ey = (int)((e >> 15) & 0x7fffu);
                 const int sx = ex - (kind == 1 ? 1 : 0); // a hole candidate's border pixel lies left of its scan position
-                w.meta = (uint32_t)kind | ((uint32_t)border << 2) | ((uint32_t)((e >> 32) & 0xfffffu) << 11);
+                w.meta = (uint32_t)kind | ((uint32_t)((e >> 52) & 511u) << 2) | ((uint32_t)((e >> 32) & 0xfffffu) << 11);
                 w.sx = sx; w.sy = ey; w.x = sx; w.y = ey;
-                w.wx0 = sx - 31; w.wy0 = ey - 1; // the walk starts at its border's topmost row: the window reaches down from there
+                // an outer border starts at its topmost row: its window reaches down from there; a hole border has pixels one row
+                // higher; a link walk starts anywhere on its border
+                w.wx0 = sx - 31; w.wy0 = kind == 0 ? ey - 1 : (kind == 1 ? ey - 2 : ey - 31);
+                w.wslot = lane & ~1; // the pair shares the forward lane's window until one of the two leaves it
             }
         }
-        if (paused) { w.wx0 = w.x - 31; w.wy0 = w.y - 31; } // anew around the current pixel
-        const uint64_t stage = __ballot(take || paused);
-        if (stage) {
+        if (paused) { w.wx0 = w.x - 31; w.wy0 = w.y - 31; } // anew around the current pixel ...
+        {   // ... in the one of the pair's two windows that the partner does not use (both paused: each takes its own)
+            const int partner_slot = pair_swap(w.wslot), partner_paused = pair_swap(paused ? 1 : 0);
+            if (paused) w.wslot = partner_paused ? lane : (partner_slot == (lane & ~1) ? (lane | 1) : (lane & ~1));
+        }
+        const uint64_t stage = __ballot((take && !isB) || paused);
+        if (__ballot(take || paused)) {
             // lane = row of the window, eight windows per round so that their 24 loads are in flight together
             const int image = (int)(w.meta >> 11);
             for (uint64_t todo = stage; todo;) {
@@ -881,101 +942,127 @@ __global__ __launch_bounds__(64) void contour_follow_kernel(ContourArgs a)
                 }
 #pragma unroll
                 for (int j = 0; j < 8; j++)
-                    if (cs[j] >= 0) win[lane][cs[j]] = rows[j];
+                    if (cs[j] >= 0) win[lane][__builtin_amdgcn_readlane(w.wslot, cs[j])] = rows[j];
             }
             __syncthreads(); // (one wave) the windows are in LDS before any lane reads its own
-            if (take || paused) {
+            if (take) { // both lanes of the pair: the start's first neighbour, clockwise from the one known to be background
                 w.rU = fetch(w.y - 1); w.rM = fetch(w.y); w.rD = fetch(w.y + 1);
-                w.n = nbr8();
-                paused = false;
-            }
-            if (take) {
+                const uint32_t n0 = nbr8(false);
                 const int sx = w.sx, ey = w.sy;
                 w.key = ey * RS + ex;
-                const int first = (kind == 0 || kind == 2) ? 4 : 0; // the neighbour known to be background: W (outer start) / E
+                const int first = (kind == 0 || kind == 2) ? 4 : 0; // W (outer start) / E
                 w.abort_on_fg = kind == 0;
                 w.abort_lt = kind <= 1 ? w.key : -1;  // link walks run all the way round
-                w.a00 = w.a10 = w.a01 = 0; w.npts = 0; w.steps = 0;
-                w.min_fg = ey * RS + sx; w.min_ebg = 0x7fffffff;
-                w.bx0 = w.bx1 = sx; w.by0 = w.by1 = ey;
+                w.a00 = w.a10 = w.a01 = 0; w.npts = 0; w.steps = 0; w.axis = 0; w.diag = 0.0; w.pend = 0.0;
+                w.run = 0; w.head = 0; w.has_head = false;
+                w.min_fg = 0x7fffffff; w.min_ebg = 0x7fffffff;
+                w.bx0 = 0x7fffffff; w.bx1 = -1; w.by0 = 0x7fffffff; w.by1 = -1;
                 int s = first;
                 do {
                     s = (s - 1) & 7;
-                } while (!((w.n >> s) & 1u) && s != first);
+                } while (!((n0 >> s) & 1u) && s != first);
                 w.status = 0;
                 if (s == first) { // isolated pixel: one vertex, zero area, zero perimeter
-                    w.npts = 1; w.min_ebg = ey * RS + sx + 1; w.axis = 0; w.diag = 0.0;
+                    w.s0 = -1;
+                    if (!isB) { w.npts = 1; w.min_fg = ey * RS + sx; w.min_ebg = ey * RS + sx + 1; w.bx0 = w.bx1 = sx; w.by0 = w.by1 = ey; }
                     finished = true;
                 } else {
-                    w.s = s;
-                    w.i1x = sx + dir_dx(s); w.i1y = ey + dir_dy(s);
-                    w.prev_s = s ^ 4; w.run = 0; w.first_len = 0; w.axis = 0; w.diag = 0.0; w.pend = 0.0;
+                    w.s0 = s;
+                    if (isB) { w.x = sx + dir_dx(s); w.y = ey + dir_dy(s); w.known = s ^ 4; } // one step back along the border: the way forward from there
+                    else w.known = s;
                     active = true;
+                    paused = on_rim();
                 }
             }
+            if ((take && active && isB && !paused) || (paused && !take)) {
+                // the rows around the lane's pixel from its (new) window
+                const bool was = paused && !take;
+                w.rU = fetch(w.y - 1); w.rM = fetch(w.y); w.rD = fetch(w.y + 1);
+                if (was) paused = false;
+            }
+            if (active && !paused) w.n = nbr8(isB);
         }
         lap(1);
         if (__ballot(active || finished) == 0) break; // nothing in flight (and nothing left in the list, or the refill would have run)
-        // ---- FOLLOW_K steps of every running walk ----
+        // ---- FOLLOW_K steps of every running lane ----
         for (int k = 0; k < FOLLOW_K; k++) {
-            if (active && !paused) {
-                const int s_end = w.s;
-                // first occupied neighbour counter-clockwise from s_end+1
-                const uint32_t rot = ((w.n | (w.n << 8)) >> (s_end + 1)) & 0xffu;
-                const int s = (s_end + __ffs((int)rot)) & 7;
+            const bool go = active && !paused;
+            // the step, tentatively: search the next border pixel (counter-clockwise from known + 1; the backward lane does the same on
+            // its mirrored neighbourhood, i.e. clockwise from known - 1)
+            const int kn = isB ? (8 - w.known) & 7 : w.known;
+            const uint32_t rot = ((w.n | (w.n << 8)) >> (kn + 1)) & 0xffu;
+            const int su = (kn + __ffs((int)rot)) & 7;
+            const int srch = isB ? (8 - su) & 7 : su;
+            const int nx = w.x + dir_dx(srch), ny = w.y + dir_dy(srch);
+            // where the two lanes stand on the border's cycle of (pixel, way back) states: the forward lane at its own state, the
+            // backward lane just behind the state (pixel ahead of it, way back to it)
+            const int st_x = isB ? w.x + dir_dx(w.known) : w.x, st_y = isB ? w.y + dir_dy(w.known) : w.y, st_d = isB ? w.known ^ 4 : w.known;
+            const int nw_x = isB ? w.x : nx, nw_y = isB ? w.y : ny, nw_d = isB ? srch : srch ^ 4; // ... and after this step
+            const int o_st_x = pair_swap(st_x), o_st_y = pair_swap(st_y), o_st_d = pair_swap(st_d);
+            const int o_nw_x = pair_swap(nw_x), o_nw_y = pair_swap(nw_y), o_nw_d = pair_swap(nw_d);
+            const int o_flags = pair_swap((go ? 1 : 0) | (active ? 2 : 0) | (w.status << 2));
+            const int o_steps = pair_swap(w.steps);
+            const bool o_go = (o_flags & 1) != 0;
+            const bool met = active && (o_flags & 2) && st_x == o_st_x && st_y == o_st_y && st_d == o_st_d && w.steps + o_steps > 0;
+            // the forward lane's step completes the cycle: the backward lane must not take the same step from the other side
+            const bool fwd_closes = isB ? (o_go && o_nw_x == st_x && o_nw_y == st_y && o_nw_d == st_d) : (nw_x == o_st_x && nw_y == o_st_y && nw_d == o_st_d);
+            const bool partner_gave_up = active && (o_flags >> 2) != 0;
+            if (met || partner_gave_up || (isB && active && fwd_closes)) {
+                // met: the halves cover the whole border; the last case: the forward lane's step of this round completes the cycle, the
+                // backward lane must not take the same step from the other side
+                active = false; finished = true; paused = false;
+            } else if (go) {
+                // this lane accounts for one forward step of the border: from its pixel, in direction s, having arrived from s_end
+                const int s = isB ? w.known : srch, s_end = isB ? srch : w.known;
                 const int r = w.y * RS + w.x;
                 const bool east_bg = (unsigned)(s - 1) < (unsigned)s_end; // the East neighbour was examined and is background
                 const int re = east_bg ? r + 1 : 0x7fffffff;
                 w.min_ebg = re < w.min_ebg ? re : w.min_ebg;
                 w.min_fg = r < w.min_fg ? r : w.min_fg;
-                // (x,y) is a CHAIN_APPROX_SIMPLE vertex when the direction changes: close the run that ends here
-                const bool vertex = s != w.prev_s;
-                const bool open_start = vertex && w.npts == 0 && w.steps > 0; // the start was not a vertex: its run is closed at the end
-                w.first_len = open_start ? w.run : w.first_len;
-                const int kk = (vertex && !open_start) ? w.run : 0;
-                const bool odd = (w.prev_s & 1) != 0;
+                w.bx0 = w.x < w.bx0 ? w.x : w.bx0; w.bx1 = w.x > w.bx1 ? w.x : w.bx1;
+                w.by0 = w.y < w.by0 ? w.y : w.by0; w.by1 = w.y > w.by1 ? w.y : w.by1;
+                // (x,y) is a CHAIN_APPROX_SIMPLE vertex when the direction changes there.  Forward lane: the run that ENDS here closes,
+                // then this step opens / extends the next one; backward lane: this step extends the run that STARTS here, then it closes.
+                const bool vertex = s != (s_end ^ 4);
+                w.run += isB ? 1 : 0;
+                const int len = vertex ? w.run : 0;
+                const bool first_vertex = vertex && !w.has_head; // the lane's first run is joined with the partner's at the end
+                w.head = first_vertex ? len : w.head;
+                w.has_head = w.has_head || vertex;
+                const int kk = first_vertex ? 0 : len;
+                const bool odd = ((isB ? s : s_end) & 1) != 0;
                 w.axis += odd ? 0 : kk;
                 w.diag += w.pend;
                 const int kd = odd ? kk : 0;                                  // diag_len[0] = 0
                 w.pend = diag_len[kd < 63 ? kd : 63];
                 if (kd > 63) w.pend = run_length(1, kd);                      // (a diagonal run longer than the table: rare)
                 w.npts += vertex ? 1 : 0;
-                w.prev_s = s;
-                w.run = vertex ? 1 : w.run + 1;
+                w.run = (vertex ? 0 : w.run) + (isB ? 0 : 1);
                 const int dx = dir_dx(s), dy = dir_dy(s);
-                const int nx = w.x + dx, ny = w.y + dy;
                 const int cross = w.x * dy - dx * w.y; // x*ny - nx*y
                 w.a00 += cross;
                 w.a10 += (int64_t)cross * (2 * w.x + dx);
                 w.a01 += (int64_t)cross * (2 * w.y + dy);
                 w.steps++;
                 const bool aborted = (w.abort_on_fg ? r : re) < w.abort_lt;
-                const bool closed = nx == w.sx && ny == w.sy && w.x == w.i1x && w.y == w.i1y;
-                if (aborted || closed || w.steps > a.max_steps) {
-                    w.status = aborted ? 1 : (closed ? 0 : 2);
-                    active = false;
-                    finished = !aborted || (w.meta & 3u) >= 2; // an aborted candidate leaves nothing behind
-                    if (w.status == 0) { // the run that arrives at the start, merged with the run that left it when the start is not a vertex
-                        w.diag += w.pend;
-                        const int kc = w.run + w.first_len;
-                        if (w.prev_s & 1) w.diag += kc < 64 ? diag_len[kc] : run_length(1, kc);
-                        else w.axis += kc;
-                    }
+                if (aborted || w.steps > a.max_steps) {
+                    w.status = aborted ? 1 : 2;
+                    active = false; finished = true;
+                } else if (!isB && fwd_closes) {
+                    active = false; finished = true; // (the backward lane sees the same condition and stops as well)
+                    w.known = srch ^ 4;              // the way back from the meeting pixel: the direction of the forward tail
                 } else {
-                    w.bx0 = nx < w.bx0 ? nx : w.bx0; w.bx1 = nx > w.bx1 ? nx : w.bx1;
-                    w.by0 = ny < w.by0 ? ny : w.by0; w.by1 = ny > w.by1 ? ny : w.by1;
                     // move.  The three rows around the new pixel and its left / right neighbour columns must lie inside the window:
-                    // a walk that steps onto the window's rim pauses until its window is staged anew (no global load in this loop).
-                    const int lx = nx - w.wx0, ly = ny - w.wy0;
-                    paused = lx < 1 || lx > 62 || ly < 1 || ly > 62;
-                    const uint64_t nw = fetch(ny + dy); // (dy = 0: the middle row again, unused; a paused lane reads some row of its own window)
+                    // a lane that steps onto the window's rim pauses until its window is staged anew (no global load in this loop).
+                    const int my = ny - w.y;
+                    w.x = nx; w.y = ny; w.known = srch ^ 4;
+                    paused = on_rim();
+                    const uint64_t nwr = fetch(ny + my); // (my = 0: the middle row again, unused; a paused lane reads some row of its window)
                     const uint64_t oU = w.rU, oM = w.rM, oD = w.rD;
-                    w.rU = dy > 0 ? oM : (dy < 0 ? nw : oU);
-                    w.rM = dy > 0 ? oD : (dy < 0 ? oU : oM);
-                    w.rD = dy > 0 ? nw : (dy < 0 ? oM : oD);
-                    w.x = nx; w.y = ny;
-                    w.s = (s + 4) & 7;
-                    w.n = nbr8(); // (garbage while paused: recomputed with the new window)
+                    w.rU = my > 0 ? oM : (my < 0 ? nwr : oU);
+                    w.rM = my > 0 ? oD : (my < 0 ? oU : oM);
+                    w.rD = my > 0 ? nwr : (my < 0 ? oM : oD);
+                    w.n = nbr8(isB); // (garbage while paused: recomputed with the new window)
                 }
             }
             if (clk) { tk[3]++; tk[4] += (uint64_t)__popcll(__ballot(active && !paused)); }

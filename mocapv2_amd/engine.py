@@ -75,7 +75,7 @@ class MocapContext:
         """One performance switch of this context (mocap_set_tuning; names in include/mocap_hip.h).  None changes a result."""
         _abi.check(self.lib.mocap_set_tuning(self._h, name.encode(), int(value)))
 
-    def set_undistort(self, slot, K, dist):
+    def set_undistort(self, slot, K, dist, warn_dense=True):
         K, Kp = _dbl(K, 9)
         d, dp = _dbl(dist, 5)
         key = K.tobytes() + d.tobytes()
@@ -85,7 +85,20 @@ class MocapContext:
         _abi.check(self.lib.mocap_set_undistort(self._h, slot, Kp, dp, C.byref(ident)))
         self._und_key[slot] = key
         self.identity[slot] = bool(ident.value)
+        if warn_dense and not self.undistort_info(slot)["sparse_path"]:
+            import warnings
+            warnings.warn(f"mocapv2_amd: undistort slot {slot}: the lens table is outside the bounds of the sparse path "
+                          f"({self.undistort_info(slot)}); its images are filtered by the dense kernel: same results, several times "
+                          "slower on dark scenes", RuntimeWarning, stacklevel=2)
         return self.identity[slot]
+
+    def undistort_info(self, slot=0):
+        """What set_undistort found out about the slot's table (mocap_undistort_info): dict with identity, compact_table,
+        early_out_provable, max_source_weight, sparse_path.  sparse_path False = the slot's images take the dense row
+        pipeline (same results, several times slower on a dark scene)."""
+        info = _abi.UndistortInfo()
+        _abi.check(self.lib.mocap_undistort_info(self._h, int(slot), C.byref(info)))
+        return {k: (bool(getattr(info, k)) if k != "max_source_weight" else int(info.max_source_weight)) for k, _ in info._fields_}
 
     def set_cameras(self, K, dist, R, t):
         n = len(K)

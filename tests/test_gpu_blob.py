@@ -309,6 +309,43 @@ def test_batches_of_varying_size_on_one_context(torch_cuda, scale):
     assert stats == fresh.tile_stats() and stats[1] > 0.5 * stats[0], (stats, fresh.tile_stats())
 
 
+def test_a_lens_outside_the_sparse_paths_bounds_is_reported_not_silent(torch_cuda):
+    """mocap_undistort_info: the identity and the mild lens take the sparse road; a lens whose 5x5 windows read more than
+    9 x 9 source pixels falls back to the dense row pipeline -- same results (equal to the oracle), but the caller is told
+    (sparse_path False, a RuntimeWarning from MocapContext.set_undistort) instead of silently running several times slower."""
+    import warnings
+    torch = torch_cuda
+    from mocapv2_amd.engine import MocapContext
+    W, H = 640, 360
+    sc = Scene(1, width=W, height=H, dist=ZERO_DIST)
+    ctx = MocapContext(W, H, n_slots=3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # neither of these may warn
+        ctx.set_undistort(0, sc.K, ZERO_DIST)
+        ctx.set_undistort(1, sc.K, MILD_DIST)
+    i0, i1 = ctx.undistort_info(0), ctx.undistort_info(1)
+    assert i0["identity"] and i0["sparse_path"] and i0["max_source_weight"] == 1024
+    assert not i1["identity"] and i1["sparse_path"] and i1["compact_table"] and i1["early_out_provable"] and i1["max_source_weight"] > 0
+    wild = None
+    for scale in (12.0, 30.0, 80.0):  # stronger and stronger barrel distortion until the bound is not provable any more
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            ctx.set_undistort(2, sc.K, np.array(MILD_DIST) * scale)
+        if not ctx.undistort_info(2)["sparse_path"]:
+            wild = np.array(MILD_DIST) * scale
+            assert any(issubclass(w.category, RuntimeWarning) and "dense" in str(w.message) for w in caught)
+            break
+        assert not caught
+    assert wild is not None, "no test lens left the sparse path"
+    rng = np.random.default_rng(4)
+    frames = dark_frames(rng, 2, H, W, n_discs=4, salt=0.001)
+    xy, cnt = ctx.record_views(ctx.blob_centroids(torch.from_numpy(frames).cuda(), cam_mod=1, slot_base=2))
+    xy, cnt = xy.cpu().numpy(), cnt.cpu().numpy()
+    for i in range(2):
+        exp = oracle.find_dot(frames[i], sc.K, wild)
+        assert cnt[i] == len(exp) and xy[i, :cnt[i]].tolist() == exp
+
+
 def test_set_tuning_rejects_unknown_names(torch_cuda):
     from mocapv2_amd._abi import MocapError
     from mocapv2_amd.engine import MocapContext
