@@ -70,6 +70,7 @@ struct Tuning {
     int box_timing = 0, contour_timing = 0, follow_timing = 0; // phase clocks on stderr (synchronous debugging aids)
     int scan_wide = 1;           // 0 = the scan's 8-byte loads
     int scan_blocks_per_cu = 0;  // > 0: the scan as a persistent pass of that many workgroups per CU (0 = one workgroup per block)
+    int scan_slices = 1;         // the scan goes out as that many launches over consecutive runs of images
     int excess_base = -1;        // >= 0: pins the scan's excess base
     int base_sel = 1;            // the base a context starts with (0 tight, 1 tolerant)
     int probe_debug = 0;
@@ -87,7 +88,7 @@ static const TuneName kTuneNames[] = {
     {"box_prio", &Tuning::box_prio, 0, 1}, {"scan_prio", &Tuning::scan_prio, 0, 3}, {"contour_prio", &Tuning::contour_prio, 0, 3},
     {"corr_prio", &Tuning::corr_prio, 0, 3}, {"box_stage_bytes", &Tuning::box_stage_bytes, 0, BOX_SCAP},
     {"box_blocks_per_cu", &Tuning::box_blocks_per_cu, 0, 32}, {"box_timing", &Tuning::box_timing, 0, 1},
-    {"contour_timing", &Tuning::contour_timing, 0, 1}, {"follow_timing", &Tuning::follow_timing, 0, 1}, {"scan_wide", &Tuning::scan_wide, 0, 1}, {"scan_blocks_per_cu", &Tuning::scan_blocks_per_cu, 0, 64}, {"excess_base", &Tuning::excess_base, -1, 254},
+    {"contour_timing", &Tuning::contour_timing, 0, 1}, {"follow_timing", &Tuning::follow_timing, 0, 1}, {"scan_wide", &Tuning::scan_wide, 0, 1}, {"scan_blocks_per_cu", &Tuning::scan_blocks_per_cu, 0, 64}, {"scan_slices", &Tuning::scan_slices, 1, 64}, {"excess_base", &Tuning::excess_base, -1, 254},
     {"base_sel", &Tuning::base_sel, 0, 1}, {"probe_debug", &Tuning::probe_debug, 0, 1}, {"contour_boxes", &Tuning::contour_boxes, 0, 1},
     {"contours_split", &Tuning::contours_split, 0, 1}, {"corr_threads", &Tuning::corr_threads, 64, 256},
     {"corr_step_groups", &Tuning::corr_step_groups, 0, 0x7fffffff},
@@ -692,6 +693,7 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
                      mask, own_mask ? 0 : (size_t)n_images * c->H * c->wpr, ((uintptr_t)mask & 15) == 0, nullptr, base_alt, allow_alt / 4, 0};
         b.prio = c->tune.scan_prio; // A/B switch
         b.max_blocks = c->tune.scan_blocks_per_cu * c->n_cu; b.blocks_x = 0;
+        b.slices = c->tune.scan_slices; b.image0 = 0; b.slice_images = n_images;
         const bool probe = fixed_base < 0 && !c->probe_pending && allow_alt >= 0 && base_alt != base && !bayer &&
                            (c->probe_age == 0 || c->probe_age >= 32);
         if (probe) {

@@ -446,25 +446,24 @@ __device__ __forceinline__ void contours_body(const ContourArgs& a)
             for (int p0 = 0; p0 < cnt; p0 += 6) {
                 const int k = kf - 1 + p0 + sub;
                 const bool tests = sub >= 1 && sub <= 6 && k < kf + cnt && k >= ka && k <= kb;
-                for (int jh = 0; jh < 8; jh += 4) { // four rows at a time: their 8 loads are in flight together
-                uint32_t wr[4], nr_[4];
+                // the cell's 8 rows and the row above the first: 9 loads in flight together (the row above row j is row j - 1)
+                uint32_t rw[9];
+                rw[0] = cv ? M.word(y0 - 1, k) : 0u;
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int y = y0 + jh + j;
-                    const bool rowv = y < yend && 8 * g + jh + j < R;
-                    wr[j] = rowv ? M.word(y, k) : 0u;
-                    nr_[j] = rowv ? M.word(y - 1, k) : 0u;
+                for (int j = 0; j < 8; j++) {
+                    const int y = y0 + j;
+                    const bool rowv = y < yend && 8 * g + j < R;
+                    rw[1 + j] = rowv ? M.word(y, k) : 0u;
                 }
                 // the neighbours' words, exchanged while every lane of the group is active (before any lane-divergent code)
-                uint32_t pw[4], pn[4], nw[4], nn[4];
+                uint32_t pr[9], nx[9];
 #pragma unroll
-                for (int j = 0; j < 4; j++) { pw[j] = lane_prev(wr[j]); pn[j] = lane_prev(nr_[j]); nw[j] = lane_next(wr[j]); nn[j] = lane_next(nr_[j]); }
+                for (int j = 0; j < 9; j++) { pr[j] = lane_prev(rw[j]); nx[j] = lane_next(rw[j]); }
 #pragma unroll
-                for (int jj = 0; jj < 4; jj++) {
-                    const int j = jh + jj;
+                for (int j = 0; j < 8; j++) {
                     const int y = y0 + j;
-                    const uint32_t w = wr[jj], n = nr_[jj];
-                    const uint32_t prev_w = pw[jj], prev_n = pn[jj], next_w = nw[jj], next_n = nn[jj];
+                    const uint32_t w = rw[1 + j], n = rw[j];
+                    const uint32_t prev_w = pr[1 + j], prev_n = pr[j], next_w = nx[1 + j], next_n = nx[j];
                     if (!tests || !(y < yend && 8 * g + j < R)) continue;
                     const uint32_t Wn = (w << 1) | (prev_w >> 31);
                     // Necessary conditions, evaluated on the 64 columns starting at this word (this word + the next):
@@ -506,7 +505,6 @@ __device__ __forceinline__ void contours_body(const ContourArgs& a)
                         const int slot = atomicAdd(&ncand, 1);
                         if (slot < MAXC) cand[slot] = (uint32_t)(32 * k + b) | ((uint32_t)y << 16) | 0x8000u;
                     }
-                }
                 }
             }
         }
@@ -759,8 +757,14 @@ __global__ __launch_bounds__(NTHREADS) void contour_candidates_kernel(ContourArg
 // bank-conflict-free for lanes at different rows) are staged by the whole wave, lane = row, eight windows per round; a pair
 // shares one window until one of its lanes leaves it.  No global memory access happens inside the step loop.
 // The step is `follow` above cut into resumable, direction-symmetric steps: same neighbour search, same vertex rule, same sums.
-constexpr int FOLLOW_K = 16;      // steps between two looks at the lanes
+#ifndef FOLLOW_K_STEPS
+#define FOLLOW_K_STEPS 16
+#endif
+constexpr int FOLLOW_K = FOLLOW_K_STEPS; // steps between two looks at the lanes
 constexpr int FOLLOW_REFILL = 8;  // idle pairs that make a refill worth its three dependent memory round trips
+#ifndef STAGE_N
+#define STAGE_N 8                 // windows staged per round (3 loads each in flight together)
+#endif
 
 __device__ __forceinline__ int pair_swap(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1 /*quad_perm:[1,0,3,2]*/, 0xf, 0xf, true); }
 __device__ __forceinline__ int64_t pair_swap64(int64_t v)
@@ -926,22 +930,22 @@ __global__ __launch_bounds__(64) void contour_follow_kernel(ContourArgs a)
             // lane = row of the window, eight windows per round so that their 24 loads are in flight together
             const int image = (int)(w.meta >> 11);
             for (uint64_t todo = stage; todo;) {
-                int cs[8];
-                uint64_t rows[8];
+                int cs[STAGE_N];
+                uint64_t rows[STAGE_N];
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
+                for (int j = 0; j < STAGE_N; j++) {
                     cs[j] = todo ? __ffsll((long long)todo) - 1 : -1;
                     todo &= todo - 1; // (0 & anything = 0)
                 }
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
+                for (int j = 0; j < STAGE_N; j++) {
                     const int c = cs[j] < 0 ? cs[0] : cs[j]; // a short last round repeats its first window (not stored)
                     const int img_c = __builtin_amdgcn_readlane(image, c), x0_c = __builtin_amdgcn_readlane(w.wx0, c), y0_c = __builtin_amdgcn_readlane(w.wy0, c);
                     const Mask Mc{a.mask + (size_t)img_c * image_words, a.words_per_row, a.H, a.W, RS};
                     rows[j] = row64(Mc, y0_c + lane, x0_c);
                 }
 #pragma unroll
-                for (int j = 0; j < 8; j++)
+                for (int j = 0; j < STAGE_N; j++)
                     if (cs[j] >= 0) win[lane][__builtin_amdgcn_readlane(w.wslot, cs[j])] = rows[j];
             }
             __syncthreads(); // (one wave) the windows are in LDS before any lane reads its own

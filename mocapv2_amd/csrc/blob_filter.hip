@@ -314,10 +314,10 @@ __global__ __launch_bounds__(256) void bright_cells_kernel(BrightArgs a)
     if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
     else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
     else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
-    const uint32_t total = (uint32_t)a.blocks_x * (uint32_t)a.n_images;
+    const uint32_t total = (uint32_t)a.blocks_x * (uint32_t)a.slice_images;
     for (uint32_t vb = blockIdx.x; vb < total; vb += gridDim.x) {
         const uint32_t image = vb / (uint32_t)a.blocks_x;
-        bright_cells_block<WIDE, FULL>(a, (int)(vb - image * (uint32_t)a.blocks_x), (int)image);
+        bright_cells_block<WIDE, FULL>(a, (int)(vb - image * (uint32_t)a.blocks_x), a.image0 + (int)image);
     }
     if (a.mask_words) {
         // caller-owned masks: clear them on the side (16 bytes per thread and round), the filter kernel then only
@@ -868,13 +868,24 @@ void launch_bright_cells(const BrightArgs& a_, hipStream_t s)
     BrightArgs a = a_;
     const int n = ((a.W + 7) >> 3) * ((a.H + 7) >> 3);
     a.blocks_x = a.wide ? (n / 2 + 255) / 256 : (n + 511) / 512;
-    const long long total = (long long)a.blocks_x * a.n_images;
-    long long grid = total;
-    if (a.max_blocks > 0 && a.max_blocks < grid) grid = a.max_blocks; // persistent form: a fixed number of workgroups
-    if (grid > 0x7fffffffLL) grid = 0x7fffffffLL;
-    if (a.wide && a.H % 8 == 0) hipLaunchKernelGGL((bright_cells_kernel<true, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
-    else if (a.wide) hipLaunchKernelGGL(bright_cells_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(bright_cells_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, a);
+    // The pass goes out as `slices` launches over consecutive runs of images (1 = one launch).  Between two slices the stream's
+    // queue has a kernel boundary: while a slice drains, the short kernels of the other batches in flight get the registers and
+    // wave slots that the pass, with its hundreds of thousands of ready workgroups, otherwise holds until its last block.
+    const int slices = a.slices > 1 ? (a.slices < a.n_images ? a.slices : a.n_images) : 1;
+    const int per = (a.n_images + slices - 1) / slices;
+    const size_t mask_words = a.mask_words;
+    for (int i0 = 0; i0 < a.n_images; i0 += per) {
+        a.image0 = i0;
+        a.slice_images = a.n_images - i0 < per ? a.n_images - i0 : per;
+        a.mask_words = i0 == 0 ? mask_words : 0; // (the side job of clearing caller-owned masks goes with the first slice)
+        const long long total = (long long)a.blocks_x * a.slice_images;
+        long long grid = total;
+        if (a.max_blocks > 0 && a.max_blocks < grid) grid = a.max_blocks; // persistent form: a fixed number of workgroups
+        if (grid > 0x7fffffffLL) grid = 0x7fffffffLL;
+        if (a.wide && a.H % 8 == 0) hipLaunchKernelGGL((bright_cells_kernel<true, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
+        else if (a.wide) hipLaunchKernelGGL(bright_cells_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(bright_cells_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, a);
+    }
 }
 void launch_undistort_map(const MapArgs& m, hipStream_t s)
 {

@@ -148,6 +148,8 @@ struct BrightArgs {
     int prio;                     // wave priority of the scan (s_setprio): its few instructions are loads that keep HBM busy
     int max_blocks;               // > 0: launch at most this many workgroups, each looping over the batch's blocks (persistent form)
     int blocks_x;                 // blocks of 256 threads per image (set by launch_bright_cells)
+    int slices;                   // > 1: the pass goes out as that many launches over consecutive runs of images
+    int image0, slice_images;     // set by launch_bright_cells: the images of this launch
 };
 void launch_bright_cells(const BrightArgs& a, hipStream_t s);
 // set-up statistics of an undistort table, for the dark-tile bound: stats[0] = largest total blend weight any source
