@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turns the rocprofv3 output of profiles/collect.sh (gpurun_out/prof_*) into the summaries kept under profiles/:
-r02_kernel_stats_depth3_default.csv, r02_kernel_stats_depth1.csv (copies of rocprofv3's own kernel_stats),
-r02_pmc_FETCH_SIZE.csv / r02_pmc_WRITE_SIZE.csv (per-kernel averages in KB per launch) and hbm_traffic.json
+r03_kernel_stats_depth3_default.csv, r03_kernel_stats_depth1.csv (copies of rocprofv3's own kernel_stats),
+r03_pmc_FETCH_SIZE.csv / r03_pmc_WRITE_SIZE.csv (per-kernel averages in KB per launch) and hbm_traffic.json
 (= (2 * FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch; FETCH_SIZE doubled per the MI355X guide's gfx950 rule)."""
 import csv
 import json
@@ -30,10 +30,12 @@ def pmc(path, counter, dst):
 
 
 def main():
-    shutil.copy(os.path.join(SRC, "prof_d3", "d3_kernel_stats.csv"), os.path.join(OUT, "r02_kernel_stats_depth3_default.csv"))
-    shutil.copy(os.path.join(SRC, "prof_d1", "d1_kernel_stats.csv"), os.path.join(OUT, "r02_kernel_stats_depth1.csv"))
-    fetch = pmc(os.path.join(SRC, "prof_fetch", "f_counter_collection.csv"), "FETCH_SIZE", os.path.join(OUT, "r02_pmc_FETCH_SIZE.csv"))
-    write = pmc(os.path.join(SRC, "prof_write", "w_counter_collection.csv"), "WRITE_SIZE", os.path.join(OUT, "r02_pmc_WRITE_SIZE.csv"))
+    shutil.copy(os.path.join(SRC, "prof_d3", "d3_kernel_stats.csv"), os.path.join(OUT, "r03_kernel_stats_depth3_default.csv"))
+    shutil.copy(os.path.join(SRC, "prof_d1", "d1_kernel_stats.csv"), os.path.join(OUT, "r03_kernel_stats_depth1.csv"))
+    if os.path.exists(os.path.join(SRC, "prof_m32d1", "m32d1_kernel_stats.csv")):  # BASELINE.json configs[2]: 32 markers
+        shutil.copy(os.path.join(SRC, "prof_m32d1", "m32d1_kernel_stats.csv"), os.path.join(OUT, "r03_kernel_stats_depth1_markers32.csv"))
+    fetch = pmc(os.path.join(SRC, "prof_fetch", "f_counter_collection.csv"), "FETCH_SIZE", os.path.join(OUT, "r03_pmc_FETCH_SIZE.csv"))
+    write = pmc(os.path.join(SRC, "prof_write", "w_counter_collection.csv"), "WRITE_SIZE", os.path.join(OUT, "r03_pmc_WRITE_SIZE.csv"))
     per = {}
     for short in ("bright_cells_kernel", "settle_tiles_kernel", "box_filter_kernel", "filter_mask_kernel"):
         kf = [k for k in fetch if short in k]
@@ -45,7 +47,7 @@ def main():
     scan_fetch = fetch[[k for k in fetch if "bright_cells_kernel" in k][0]]
     algo = FRAME_BYTES * IMAGES
     doc = {"workload_key": "6x1920x1080-m8-mild", "dist": "mild", "images_per_launch": float(IMAGES), "markers": 8, "hbm_bytes_per_launch": per,
-           "derivation": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 from profiles/r02_pmc_FETCH_SIZE.csv / r02_pmc_WRITE_SIZE.csv (separate "
+           "derivation": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 from profiles/r03_pmc_FETCH_SIZE.csv / r03_pmc_WRITE_SIZE.csv (separate "
                          "--pmc passes of `python bench.py --depth 1 --steps 3 --warmup 2 --cpu-steps 0 --no-secondary --no-extra`, "
                          "profiles/collect.sh + summarize.py); FETCH_SIZE doubled per the MI355X guide's gfx950 rule, confirmed on this "
                          "access pattern: bright_cells_kernel reads every frame byte exactly once (%d B per launch, 16-byte loads) "
