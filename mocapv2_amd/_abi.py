@@ -83,6 +83,13 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C mocapv2_amd/csrc` "
                            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    # PyTorch (the device-buffer provider of the host side) ships its own libamdhip64; a process must initialise the GPU through
+    # ONE copy of the runtime.  Loading this library first would bind /opt/rocm's copy and leave it without a device once torch
+    # has initialised its own ("no ROCm-capable device is detected"): torch goes first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError = library does not match the header

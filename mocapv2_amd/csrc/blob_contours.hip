@@ -95,7 +95,11 @@ __device__ __forceinline__ double run_length(int s, int k)
 {
     float d = (float)k;
     float q = (s & 1) ? __fadd_rn(__fmul_rn(d, d), __fmul_rn(d, d)) : __fmul_rn(d, d);
-    return (double)__fsqrt_rn(q);
+    // cv.arcLength takes a correctly rounded float32 square root (sqrtss); the device's float32 root (v_sqrt_f32) is good to 1 ulp
+    // only, which showed on diagonal runs of a few lengths (tests/test_gpu_blob.py::test_contours_match_oracle_large_masks).  The
+    // FP64 root of the (exact, integer-valued) float32 q, rounded to float32, IS the correctly rounded float32 root: sqrt(q) is never
+    // within 2^-26 relative of a float32 midpoint for an integer q, and the FP64 root errs by 2^-53.
+    return (double)(float)sqrt((double)q);
 }
 
 // Border following by one LANE.  Follows the border through pixel (sx,sy) whose neighbour in direction `first`

@@ -175,6 +175,43 @@ def test_contours_match_oracle(torch_cuda, seed):
     assert seen > 0
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MOCAP_FUZZ_CONTOUR_SEEDS", "6"))))
+def test_contours_match_oracle_large_masks(torch_cuda, seed):
+    """The same comparison on masks several mask windows wide and tall (the follow kernel's lanes pause at the rim of their
+    64 x 64 window and have it staged anew; the forward and the backward lane of a border leave their shared window at
+    different times): rings within rings, long thin bars (borders walked out and back), blobs touching the image border,
+    one batch of 12 images so that walks of different images share waves."""
+    from gpu_util import pack_mask
+    from mocapv2_amd.engine import MocapContext
+    rng = np.random.default_rng(7000 + seed)
+    H, W = [(300, 420), (257, 513), (480, 300)][seed % 3]
+    masks = []
+    for i in range(12):
+        m = structured_mask(rng, H, W, n=rng.integers(3, 14)) != 0
+        yy, xx = np.mgrid[0:H, 0:W]
+        for _ in range(int(rng.integers(0, 4))):  # bars one or two pixels thick, any slope
+            x0, y0, x1, y1 = rng.uniform(0, W), rng.uniform(0, H), rng.uniform(0, W), rng.uniform(0, H)
+            t = ((xx - x0) * (x1 - x0) + (yy - y0) * (y1 - y0)) / max(1e-9, (x1 - x0) ** 2 + (y1 - y0) ** 2)
+            d = np.hypot(xx - (x0 + t * (x1 - x0)), yy - (y0 + t * (y1 - y0)))
+            m |= (d <= rng.choice([0.5, 0.8, 1.2])) & (t >= 0) & (t <= 1)
+        if i % 4 == 3:
+            m ^= rng.random((H, W)) < 0.002  # a few single-pixel specks and pinholes
+        masks.append((m * 255).astype(np.uint8))
+    ctx = MocapContext(W, H)
+    ctx.set_blob_params(min_area=20.0, min_circ=0.05)
+    xy, cnt, recs = ctx.contours_from_mask(pack_mask(np.stack(masks)), max_blobs=128, debug_cap=384)
+    xy, cnt = xy.cpu().numpy(), cnt.cpu().numpy()
+    seen = longest = 0
+    for i, m in enumerate(masks):
+        if cnt[i] < 0:  # capacity overflow is reported, never silent
+            assert len(oracle.find_contours(m)) > 100, cnt[i]
+            continue
+        n_all, _ = check_against_oracle(m, recs[i], xy[i], cnt[i], 20.0, 0.05, 128)
+        seen += n_all
+        longest = max([longest] + [r["steps"] for r in recs[i]])
+    assert seen > 20 and longest > 300  # borders far longer than a window is wide were among them
+
+
 @pytest.mark.parametrize("dist", [ZERO_DIST, MILD_DIST], ids=["nodist", "mild"])
 def test_find_dot_synthetic_frames(torch_cuda, dist):
     torch = torch_cuda
