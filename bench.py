@@ -275,6 +275,13 @@ def same_results(rec_a, out_a, rec_b, out_b):
     return all(torch.equal(out_a[k][roots], out_b[k][roots]) for k in ("xyz", "grp", "order"))
 
 
+def batch_index(i, depth, n_batches):
+    """Which resident batch step i takes: consecutive steps take different batches, and the order is chosen so that consecutive
+    steps of one LANE (every `depth`-th step: a lane = one context with its own mask) differ too -- otherwise a lane would
+    filter the same frames every time and its mask would never need clearing."""
+    return (i % n_batches) if depth % n_batches else ((i + i // depth) % n_batches)
+
+
 KERNELS = (("scan", "bright_cells_kernel"), ("settle", "settle_tiles_kernel"), ("filter", "box_filter_kernel + filter_mask_kernel (wide tiles)"))
 
 
@@ -380,11 +387,7 @@ def main():
         torch.cuda.synchronize()
 
     def batch_of(tracker, n_batches):
-        """Which resident batch the next step takes: consecutive steps take consecutive batches, and the order is chosen so
-        that consecutive steps of one LANE (every `depth`-th step: a lane = one context with its own mask) differ too --
-        otherwise a lane would filter the same frames every time and its mask would never need clearing."""
-        i, depth = tracker._k, len(tracker.lanes)
-        return (i % n_batches) if depth % n_batches else ((i + i // depth) % n_batches)
+        return batch_index(tracker._k, len(tracker.lanes), n_batches)
 
     def timed(tracker, batches, steps, warmup):
         """W untimed + K timed steps rotating through the resident batches, barrier + synchronize on both sides, max over
