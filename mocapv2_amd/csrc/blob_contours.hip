@@ -10,21 +10,23 @@
 //   * a hole border starts at the foreground pixel left of a background pixel whose W and N neighbours are
 //     foreground and that is the raster-minimum of the left-side cracks of the border.
 // Candidates are found with word-parallel bit tests on the mask, guided by the occupancy words the filter kernels leave
-// per tile and by the tiles' boxes (settle_tiles_kernel); a group of 8 lanes holds consecutive words of a mask row.  Each
-// candidate is then followed by ONE LANE: the lane keeps the three 64-column mask rows around its current pixel in registers
-// (a vertical move takes one new row from a 64 x 64 window staged in LDS, from L1/L2 outside it), the walker state and the
-// integer Green's-theorem sums are per-lane registers, so the 64 lanes of a wave follow 64 borders at once (a border walk is
-// a serial chain of ~150 instructions per step: what counts is how many walks share a wave's instruction stream).  The step
-// itself is literally the reference border-following step (same neighbour order, same CHAIN_APPROX_SIMPLE vertex rule); a
-// candidate is dropped as soon as it meets an earlier pixel of its own border.  The polygon sums are exact integers (int64),
-// the perimeter is a sum of float32 square roots held exactly in a double.
+// per tile and by the tiles' boxes (settle_tiles_kernel); a group of 8 lanes holds consecutive words of a mask row.  Every
+// candidate becomes one entry of a batch-wide walk list and is followed by a PAIR OF LANES of contour_follow_kernel: one lane
+// forwards, one backwards from the same start, until they meet (see there); a lane keeps the three 64-column mask rows around
+// its current pixel in registers (a vertical move takes one new row from a 64 x 64 window staged in LDS), the walker state and
+// the integer Green's-theorem sums are per-lane registers.  The step itself is literally the reference border-following step
+// (same neighbour order, same CHAIN_APPROX_SIMPLE vertex rule); a candidate is dropped as soon as one of its lanes meets an
+// earlier pixel of its own border.  The polygon sums are exact integers (int64), the perimeter is a sum of correctly rounded
+// float32 square roots held exactly in a double.
 // Tree order (parent = enclosing border, siblings in reverse discovery order, pre-order walk) is rebuilt from
 // "which border owns the crack left of my start pixel": from the bounding boxes when that is unambiguous, else by
-// following that border once.
-// Three kernels per batch: contour_candidates_kernel (one workgroup of 4 waves per image) -> contour_follow_kernel (every
-// walk of the batch, 64 to a wave whatever image they belong to) -> contours_kernel<2> (tree and output, one workgroup per
-// image); the hand-over is the per-image global workspace (L2) and one batch-wide walk list.  contours_kernel<0> is the same
-// work as one kernel per image (MOCAP_CONTOURS_SPLIT=0, and whenever the phase clock is on).  The mask is 1/8 B per pixel.
+// following that border once -- as one more entry of a (second) walk list.
+// Five launches per batch: contour_candidates_kernel (one workgroup of 4 waves per image) -> contour_follow_kernel (persistent
+// waves, every walk of the batch whatever image it belongs to) -> contours_kernel<2> (tree and output, one workgroup per image;
+// images with an ambiguous link wait) -> contour_follow_kernel (the link walks) -> contours_kernel<2> (the images that waited);
+// the hand-over is the per-image global workspace (L2) and the two batch-wide walk lists.  contours_kernel<0> is the same work
+// as one kernel per image with the lone-lane walker `follow` below (contours_split = 0, and whenever contour_timing is on).
+// The mask is 1/8 B per pixel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "kernels.h"
