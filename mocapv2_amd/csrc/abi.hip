@@ -88,7 +88,7 @@ static const TuneName kTuneNames[] = {
     {"box_prio", &Tuning::box_prio, 0, 1}, {"scan_prio", &Tuning::scan_prio, 0, 3}, {"contour_prio", &Tuning::contour_prio, 0, 3},
     {"corr_prio", &Tuning::corr_prio, 0, 3}, {"box_stage_bytes", &Tuning::box_stage_bytes, 0, BOX_SCAP},
     {"box_blocks_per_cu", &Tuning::box_blocks_per_cu, 0, 32}, {"box_timing", &Tuning::box_timing, 0, 1},
-    {"contour_timing", &Tuning::contour_timing, 0, 1}, {"follow_timing", &Tuning::follow_timing, 0, 1}, {"scan_wide", &Tuning::scan_wide, 0, 1}, {"scan_blocks_per_cu", &Tuning::scan_blocks_per_cu, 0, 64}, {"scan_slices", &Tuning::scan_slices, 1, 64}, {"excess_base", &Tuning::excess_base, -1, 254},
+    {"contour_timing", &Tuning::contour_timing, 0, 1}, {"follow_timing", &Tuning::follow_timing, 0, 2}, {"scan_wide", &Tuning::scan_wide, 0, 1}, {"scan_blocks_per_cu", &Tuning::scan_blocks_per_cu, 0, 64}, {"scan_slices", &Tuning::scan_slices, 1, 64}, {"excess_base", &Tuning::excess_base, -1, 254},
     {"base_sel", &Tuning::base_sel, 0, 1}, {"probe_debug", &Tuning::probe_debug, 0, 1}, {"contour_boxes", &Tuning::contour_boxes, 0, 1},
     {"contours_split", &Tuning::contours_split, 0, 1}, {"corr_threads", &Tuning::corr_threads, 64, 256},
     {"corr_step_groups", &Tuning::corr_step_groups, 0, 0x7fffffff},
@@ -823,7 +823,7 @@ static int run_contours(mocap_ctx* c, const uint32_t* mask, const uint32_t* cell
     a.walk_list = split ? c->walk_list : nullptr; a.link_list = c->link_list; a.walk_count = c->walk_count;
     a.follow_grid = c->n_cu * 4;  // 4 one-wave workgroups per CU (33 KB of LDS each): persistent, they refill their lanes from the list
     a.follow_grid2 = c->n_cu;     // the link walks are few
-    a.follow_list = 0; a.tree_pass = 0; a.follow_dbg = nullptr;
+    a.follow_list = 0; a.tree_pass = 0; a.follow_dbg = nullptr; a.follow_dbg_list = c->tune.follow_timing == 2 ? 1 : 0;
     if (c->tune.follow_timing && split) {
         HIP_TRY(hipMalloc(&a.follow_dbg, sizeof(uint64_t) * 8 * a.follow_grid));
         HIP_TRY(hipMemsetAsync(a.follow_dbg, 0, sizeof(uint64_t) * 8 * a.follow_grid, s));

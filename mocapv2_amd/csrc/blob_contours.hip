@@ -319,6 +319,7 @@ __device__ __forceinline__ void contours_body(const ContourArgs& a)
     __shared__ int32_t rkey[MAXR];                 // per border: discovery key, start pixel, kind, links
     __shared__ int16_t rsx[MAXR], rsy[MAXR], rlink[MAXR], rparent[MAXR];
     __shared__ uint8_t rhole[MAXR], rkept[MAXR];
+    __shared__ uint8_t rres[MAXR];                 // 1 = the border's parent follows from the bounding boxes alone (phase C0)
     __shared__ int ncand, nrec, nkept, err, ncell, dbg_steps;
     __shared__ double diag_len[64]; // float32 length of a diagonal run of k steps, as a double
     __shared__ uint64_t win[NWIN][64]; // mask windows of the first NWIN candidates (see follow)
@@ -593,6 +594,29 @@ __device__ __forceinline__ void contours_body(const ContourArgs& a)
     //   hole border : left end of the foreground run holding the start pixel     -> its West crack
     // One wave per border (wave-uniform control flow).
     const int nr = nrec;
+    // ---- phase C0: the parents the bounding boxes alone decide (no mask access, no link) ----------------------------
+    //   An outer border's parent is the hole border of the hole its component lies in, or the frame; lying in a hole puts every
+    //   pixel of the border, its start included, inside that hole border's box: no hole border's box around the start -> the frame.
+    //   A hole border's parent is the outer border of its own component, whose box contains every pixel of the component, the
+    //   hole's border pixels included: exactly one outer border's box around the hole border's box -> that one.
+    //   Everything else (nested rings, boxes that overlap) goes through the link below.  A frame of separate, hole-free markers --
+    //   the usual IR frame -- needs nothing more than this.
+    for (int c = tid; c < nr; c += NTHREADS) {
+        const int me = rhole[c];
+        int hits = 0, found = -1;
+        if (!me) {
+            const int x = rsx[c], y = rsy[c];
+            for (int j = 0; j < nr; j++)
+                hits += rhole[j] && rbox[j][0] <= x && x <= rbox[j][2] && rbox[j][1] <= y && y <= rbox[j][3];
+        } else {
+            for (int j = 0; j < nr; j++)
+                if (!rhole[j] && rbox[j][0] <= rbox[c][0] && rbox[c][2] <= rbox[j][2] && rbox[j][1] <= rbox[c][1] && rbox[c][3] <= rbox[j][3]) { hits++; found = j; }
+        }
+        const bool res = me ? hits == 1 : hits == 0;
+        rres[c] = res ? 1 : 0;
+        if (res) rparent[c] = (int16_t)found;
+    }
+    __syncthreads();
     if (second_pass) {
         // the links the first pass left open: the second follow pass has identified the border each of their cracks belongs to
         for (int c = tid; c < nr; c += NTHREADS) {
@@ -606,6 +630,7 @@ __device__ __forceinline__ void contours_body(const ContourArgs& a)
         }
     }
     for (int c = wv; c < nr && !second_pass; c += NWAVES) {
+        if (rres[c]) continue; // (wave-uniform)
         const int r_is_hole = rhole[c], r_sx = rsx[c], y = rsy[c];
         // hole: nearest background pixel at/left of the start; outer: nearest foreground pixel left of it.
         // The words of the row up to that column are examined 64 at a time, one per lane, right to left.
@@ -689,8 +714,12 @@ __device__ __forceinline__ void contours_body(const ContourArgs& a)
 
     // ---- phase C2: parents (Suzuki's table: same kind -> the link's parent, else the link itself) -----------
     for (int c = tid; c < nr; c += NTHREADS) {
+        if (rres[c]) continue;
         int me = rhole[c], j = rlink[c], guard = 0;
-        while (j >= 0 && rhole[j] == me && guard++ < MAXR) j = rlink[j];
+        while (j >= 0 && rhole[j] == me && guard++ < MAXR) {
+            if (rres[j]) { j = rparent[j]; break; } // a border of my kind whose parent the boxes gave: its parent is mine
+            j = rlink[j];
+        }
         rparent[c] = (int16_t)j;
     }
     __syncthreads();
@@ -815,7 +844,7 @@ __global__ __launch_bounds__(64) void contour_follow_kernel(ContourArgs a)
     bool drained = false;                  // (wave-uniform) the list has no more entries
     // optional phase clock (follow_timing = 1, a debugging aid): per wave, 100 MHz ticks in store / refill / walk, wave steps, lane steps, walks, refills
     uint64_t tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const bool clk = a.follow_dbg != nullptr && a.follow_list == 0;
+    const bool clk = a.follow_dbg != nullptr && a.follow_list == a.follow_dbg_list;
     uint64_t t_prev = clk ? wall_clock64() : 0;
     auto lap = [&](int i) { if (clk) { const uint64_t t = wall_clock64(); tk[i] += t - t_prev; t_prev = t; } };
     __syncthreads();

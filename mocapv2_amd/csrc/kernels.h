@@ -122,7 +122,8 @@ struct ContourArgs {
     int follow_grid2;      //   ... of its second pass (the link walks: few)
     int follow_list;       // set by launch_contours: 0 = the follow kernel works through walk_list, 1 = through link_list
     int tree_pass;         // set by launch_contours: 1 / 2 = first / second pass of the tree kernel
-    uint64_t* follow_dbg;  // optional [follow_grid][8] phase clock of the follow kernel's first pass (follow_timing = 1), else null
+    uint64_t* follow_dbg;  // optional [follow_grid][8] phase clock of the follow kernel (follow_timing = 1: first pass, 2: second), else null
+    int follow_dbg_list;
 };
 
 enum { BLOB_ERR_CANDIDATES = -2, BLOB_ERR_CONTOURS = -3, BLOB_ERR_STEPS = -4, BLOB_ERR_DEPTH = -5 };
