@@ -693,6 +693,7 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
                      mask, own_mask ? 0 : (size_t)n_images * c->H * c->wpr, ((uintptr_t)mask & 15) == 0, nullptr, base_alt, allow_alt / 4, 0};
         b.prio = c->tune.scan_prio; // A/B switch
         b.max_blocks = c->tune.scan_blocks_per_cu * c->n_cu; b.blocks_x = 0;
+        b.block_ctr = c->n_items + 160; // (words 160..223 of the counter block zeroed above: one per slice)
         b.slices = c->tune.scan_slices; b.image0 = 0; b.slice_images = n_images;
         const bool probe = fixed_base < 0 && !c->probe_pending && allow_alt >= 0 && base_alt != base && !bayer &&
                            (c->probe_age == 0 || c->probe_age >= 32);

@@ -315,9 +315,27 @@ __global__ __launch_bounds__(256) void bright_cells_kernel(BrightArgs a)
     else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
     else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
     const uint32_t total = (uint32_t)a.blocks_x * (uint32_t)a.slice_images;
-    for (uint32_t vb = blockIdx.x; vb < total; vb += gridDim.x) {
-        const uint32_t image = vb / (uint32_t)a.blocks_x;
-        bright_cells_block<WIDE, FULL>(a, (int)(vb - image * (uint32_t)a.blocks_x), a.image0 + (int)image);
+    if (a.block_ctr == nullptr) {
+        for (uint32_t vb = blockIdx.x; vb < total; vb += gridDim.x) {
+            const uint32_t image = vb / (uint32_t)a.blocks_x;
+            bright_cells_block<WIDE, FULL>(a, (int)(vb - image * (uint32_t)a.blocks_x), a.image0 + (int)image);
+        }
+    } else {
+        // persistent form: the workgroups take the blocks in the order of a shared counter, as the hardware dispatcher would hand
+        // them out -- the blocks in flight stay one contiguous window of the frames (a fixed stride per workgroup lets them drift
+        // apart: 1.20 ms against 0.95 at the same occupancy); the next index is fetched while this block's loads are in flight
+        __shared__ uint32_t s_next[2];
+        constexpr uint32_t CH = 16; // blocks per visit of the counter (one atomic per block would serialise on it: 2.4 ms)
+        uint32_t v0 = blockIdx.x * CH;
+        for (int it = 0; v0 < total; it++) {
+            if (threadIdx.x == 0) s_next[it & 1] = gridDim.x * CH + atomicAdd(a.block_ctr, CH);
+            for (uint32_t vb = v0; vb < v0 + CH && vb < total; vb++) {
+                const uint32_t image = vb / (uint32_t)a.blocks_x;
+                bright_cells_block<WIDE, FULL>(a, (int)(vb - image * (uint32_t)a.blocks_x), a.image0 + (int)image);
+            }
+            __syncthreads();
+            v0 = s_next[it & 1];
+        }
     }
     if (a.mask_words) {
         // caller-owned masks: clear them on the side (16 bytes per thread and round), the filter kernel then only
@@ -880,7 +898,12 @@ void launch_bright_cells(const BrightArgs& a_, hipStream_t s)
         a.mask_words = i0 == 0 ? mask_words : 0; // (the side job of clearing caller-owned masks goes with the first slice)
         const long long total = (long long)a.blocks_x * a.slice_images;
         long long grid = total;
-        if (a.max_blocks > 0 && a.max_blocks < grid) grid = a.max_blocks; // persistent form: a fixed number of workgroups
+        uint32_t* const ctr = a_.block_ctr;
+        a.block_ctr = nullptr;
+        if (a.max_blocks > 0 && a.max_blocks < grid) { // persistent form: a fixed number of workgroups
+            grid = a.max_blocks;
+            a.block_ctr = ctr ? ctr + (i0 / per) : nullptr; // one counter per slice (zeroed by the caller)
+        }
         if (grid > 0x7fffffffLL) grid = 0x7fffffffLL;
         if (a.wide && a.H % 8 == 0) hipLaunchKernelGGL((bright_cells_kernel<true, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
         else if (a.wide) hipLaunchKernelGGL(bright_cells_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, a);

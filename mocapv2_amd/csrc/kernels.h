@@ -148,6 +148,7 @@ struct BrightArgs {
     uint32_t* probe; int base_alt, hot_alt;
     int prio;                     // wave priority of the scan (s_setprio): its few instructions are loads that keep HBM busy
     int max_blocks;               // > 0: launch at most this many workgroups, each looping over the batch's blocks (persistent form)
+    uint32_t* block_ctr;          // persistent form: [slices] zeroed counters the workgroups take their blocks from (else null: fixed stride)
     int blocks_x;                 // blocks of 256 threads per image (set by launch_bright_cells)
     int slices;                   // > 1: the pass goes out as that many launches over consecutive runs of images
     int image0, slice_images;     // set by launch_bright_cells: the images of this launch
