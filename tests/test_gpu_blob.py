@@ -691,6 +691,10 @@ def test_blob_centroids_from_bayer_equals_the_two_steps(torch_cuda, monkeypatch,
     {"MOCAP_CONTOURS_SPLIT": "0"},                            # the contour stage as one kernel per image
     {"MOCAP_CONTOUR_BOXES": "0"},                             # candidates from whole strips instead of the tiles' boxes
     {"MOCAP_CONTOURS_SPLIT": "0", "MOCAP_CONTOUR_BOXES": "0"},
+    {"MOCAP_SCAN_BLOCKS_PER_CU": "3"},                        # the scan as a persistent pass (blocks from a shared counter)
+    {"MOCAP_SCAN_SLICES": "5"},                               # the scan in five launches over runs of images
+    {"MOCAP_SCAN_SLICES": "3", "MOCAP_SCAN_BLOCKS_PER_CU": "2", "MOCAP_SCAN_WIDE": "0"},
+    {"MOCAP_CORR_THREADS": "64"},
 ], ids=lambda e: ",".join(f"{k[6:]}={v}" for k, v in e.items()))
 def test_tuning_switches_do_not_change_results(torch_cuda, monkeypatch, env):
     """Routing thresholds, row bands, the side stream, the scan's excess base (pinned or adapting), the grid size and the
