@@ -842,6 +842,7 @@ __global__ __launch_bounds__(64) void contour_follow_kernel(ContourArgs a)
     // next look at the lanes), or finished (the pair has met, or given up; the record is not stored yet).
     bool active = false, paused = false, finished = false;
     bool drained = false;                  // (wave-uniform) the list has no more entries
+    bool first_fill = true;                // (wave-uniform) the wave has not taken entries yet
     // optional phase clock (follow_timing = 1, a debugging aid): per wave, 100 MHz ticks in store / refill / walk, wave steps, lane steps, walks, refills
     uint64_t tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool clk = a.follow_dbg != nullptr && a.follow_list == a.follow_dbg_list;
@@ -932,9 +933,13 @@ __global__ __launch_bounds__(64) void contour_follow_kernel(ContourArgs a)
         bool take = false;
         int kind = 0, ex = 0;
         if (!drained && (n_idle >= FOLLOW_REFILL || busy == 0)) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(head_ctr, (uint32_t)n_idle);
-            base = (uint32_t)uni((int)base);
+            // the first 32 entries of a wave are those at 32 * its number (no atomic, no round trip); the counter hands out the rest
+            uint32_t base = blockIdx.x * 32u;
+            if (!first_fill) {
+                if (lane == 0) base = atomicAdd(head_ctr, (uint32_t)n_idle);
+                base = (uint32_t)uni((int)base) + gridDim.x * 32u;
+            }
+            first_fill = false;
             const int n_new = base < total ? (int)(total - base < (uint32_t)n_idle ? total - base : (uint32_t)n_idle) : 0;
             drained = n_new < n_idle;
             if (clk) { tk[5] += (uint64_t)n_new; tk[6]++; }
