@@ -127,6 +127,12 @@ def test_replay_tracker_matches_oracle_per_time_step():
         sizes.append(len(obj))
     assert sizes == [3, 3, 0, 1, 3, 1, 2], sizes
     assert got[2]["message"] == got[1]["message"]  # nothing found: the previous message again
+    # three batches in flight (batch 2: four batches for the 7 time steps): the same time steps, in order
+    piped = list(ReplayTracker(K, dist, R, t, F, W, H, batch=2, obj_count=obj_count, depth=3).run(frames))
+    assert len(piped) == T
+    for s in range(T):
+        assert piped[s]["message"] == got[s]["message"], s
+        assert np.array_equal(piped[s]["object_points"], got[s]["object_points"]) and np.array_equal(piped[s]["image_points"], got[s]["image_points"]), s
 
 
 def test_eight_cameras_one_per_rank_layout_matches_oracle():
