@@ -111,6 +111,40 @@ def test_ba_residual_vector(helpers):
         assert e.shape == r.shape and np.allclose(e, r, rtol=2e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("C", [2, 3, 6, 8, 16])
+def test_triangulation_against_scipys_svd_on_random_groups(C):
+    """Evidence for the DLT that does not share a line with the kernel or the C oracle (whose Jacobi eigen-solve is the
+    same code): 1500 random groups per camera count through mocap_triangulate_batch against the reference's own route
+    (lib/Helpers.py:58-78: P = K [R|t], rows y P[2] - P[1] and P[0] - x P[2], B = A^T A, scipy.linalg.svd(B), Vh[3,:3] / Vh[3,3])
+    evaluated with SciPy here, bar 1e-7 world units (1e-4 mm); integer pixel observations with noise, as the blob stage
+    delivers them."""
+    import scipy.linalg
+    from mocapv2_amd.engine import MocapContext
+    sc = Scene(C, 1920, 1080, dist=MILD_DIST, radius=3.0 if C <= 8 else 4.0)
+    K = np.stack([sc.K] * C)
+    R, t = np.stack([p["R"] for p in sc.poses]), np.stack([p["t"] for p in sc.poses])
+    rng = np.random.default_rng(100 + C)
+    N = 1500
+    X = rng.uniform(-0.6, 0.6, (N, 3))
+    pts = np.zeros((N, C, 2))
+    for c in range(C):
+        pc = X @ R[c].T + t[c]
+        pts[:, c, 0] = K[c, 0, 0] * pc[:, 0] / pc[:, 2] + K[c, 0, 2]
+        pts[:, c, 1] = K[c, 1, 1] * pc[:, 1] / pc[:, 2] + K[c, 1, 2]
+    pts = np.floor(pts + rng.normal(0, 0.7, pts.shape))
+    ctx = MocapContext(1, 1)
+    ctx.set_cameras(K, np.zeros((C, 5)), R, t)
+    got, ok = ctx.triangulate_batch(pts, np.ones((N, C), np.uint8), compact_k=True)
+    assert ok.all()
+    P = np.stack([K[c] @ np.c_[R[c], t[c]] for c in range(C)])
+    worst = 0.0
+    for n in range(N):
+        A = np.concatenate([np.stack([pts[n, c, 1] * P[c][2] - P[c][1], P[c][0] - pts[n, c, 0] * P[c][2]]) for c in range(C)])
+        _, _, Vh = scipy.linalg.svd(A.T @ A)
+        worst = max(worst, np.abs(got[n] - Vh[3, :3] / Vh[3, 3]).max())
+    assert worst < TOL_XYZ, worst
+
+
 def test_resident_ba_residuals_match_the_reference_fixture_and_the_oracle():
     """mocap_ba_residuals (image points resident, rotvec -> R / triangulation / reprojection / float32 cast in one launch):
     the reference-generated residual vectors of tests/golden/ba_residuals.npz (lib/Helpers.py:161-167 run by
