@@ -56,6 +56,32 @@ def test_filter_mask_identity(torch_cuda, W, H):
         assert np.array_equal(got[i], exp), f"image {i}: {np.argwhere(got[i] != exp)[:5]}"
 
 
+@pytest.mark.parametrize("W,H", [(97, 61), (640, 360), (1920, 1080)])
+def test_filter_mask_against_scipy_without_the_c_oracle(torch_cuda, W, H):
+    """The filter chain of image_filter_gpu (lib/ImageOperations.py:23-31) for an identity lens, restated with SciPy in the test
+    itself -- no line shared with the kernels or with oracle/blob_oracle.c: numba's blur = integer sum of the in-bounds 5x5 taps
+    floor-divided by their count (lib/CudaOperations.py:5-22), cv.threshold(216.75) = > 216, cv.medianBlur(5) = median with
+    replicated borders -- against mocap_filter_mask, bit for bit."""
+    import scipy.ndimage as ndi
+    from gpu_util import unpack_mask
+    torch = torch_cuda
+    rng = np.random.default_rng(W * 7 + H)
+    frames = dark_frames(rng, 2, H, W, n_discs=6 if W > 200 else 2, salt=0.002, noise_max=90)
+    frames[1, : H // 3] = np.maximum(frames[1, : H // 3], rng.integers(150, 256, (H // 3, W), dtype=np.uint8))  # a bright band
+    ctx, K, ident = make_ctx(W, H)
+    assert ident
+    got, pad = unpack_mask(ctx.filter_mask(torch.from_numpy(frames).cuda()), W)
+    assert not pad.any()
+    ones = np.ones((5, 5), np.int64)
+    taps = ndi.convolve(np.ones((H, W), np.int64), ones, mode="constant", cval=0)
+    for i in range(2):
+        S = ndi.convolve(frames[i].astype(np.int64), ones, mode="constant", cval=0)
+        thr = ((S // taps) > 216).astype(np.uint8) * 255
+        exp = ndi.median_filter(thr, size=5, mode="nearest") != 0
+        assert np.array_equal(got[i], exp), (i, np.argwhere(got[i] != exp)[:5])
+        assert exp.any()
+
+
 @pytest.mark.parametrize("W,H", [(64, 48), (250, 130), (251, 77), (500, 300), (960, 540)])
 @pytest.mark.parametrize("scale", [1.0, 4.0, -3.0])
 @pytest.mark.parametrize("mode", ["box", "box_unstaged", "dense", "dense_gather", "dense_boxes"])
