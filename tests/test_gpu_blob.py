@@ -82,6 +82,53 @@ def test_filter_mask_against_scipy_without_the_c_oracle(torch_cuda, W, H):
         assert exp.any()
 
 
+def test_borders_against_scipy_labels_and_picks_theorem(torch_cuda):
+    """Oracle-free properties of the contour stage (SURVEY.md 8c lists them as stand-ins for the missing cv2 pair), on the GPU's own
+    mask of 1080p frames with 24 discs: as many outer borders as 8-connected foreground components and as many hole borders as
+    enclosed 4-connected background components (scipy.ndimage.label); every border's polygon area obeys Pick's theorem with the
+    lattice points the walk visits -- outer border of a hole-free component: pixels - steps / 2 - 1 -- and the truncated centroid of
+    a disc lies within a pixel of its pixel centroid."""
+    import scipy.ndimage as ndi
+    from gpu_util import unpack_mask
+    torch = torch_cuda
+    W, H = 1920, 1080
+    rng = np.random.default_rng(77)
+    frames = dark_frames(rng, 2, H, W, n_discs=24, salt=0.001)
+    ctx, K, ident = make_ctx(W, H)
+    ctx.set_blob_params(min_area=50.0, min_circ=0.3)
+    mask_dev = ctx.filter_mask(torch.from_numpy(frames).cuda())
+    masks, _ = unpack_mask(mask_dev, W)
+    xy, cnt, recs = ctx.contours_from_mask(mask_dev, max_blobs=128, debug_cap=384)
+    eight = np.ones((3, 3), int)
+    checked = 0
+    for i in range(2):
+        m = masks[i]
+        lab, n_fg = ndi.label(m, structure=eight)
+        bg, n_bg = ndi.label(~np.pad(m, 1))  # 4-connected background, the frame's margin joins everything outside
+        outer = [r for r in recs[i] if not r["is_hole"]]
+        holes = [r for r in recs[i] if r["is_hole"]]
+        assert len(outer) == n_fg and len(holes) == n_bg - 1, (len(outer), n_fg, len(holes), n_bg)
+        sizes = ndi.sum(m, lab, index=np.arange(1, n_fg + 1))
+        cents = ndi.center_of_mass(m, lab, index=np.arange(1, n_fg + 1))
+        filled = ndi.binary_fill_holes(m)
+        for r in outer:
+            k = lab[r["sy"], r["sx"]]
+            assert k > 0
+            comp = lab == k
+            if (filled & ~m)[ndi.binary_dilation(comp, structure=eight)].any():
+                continue  # a component with a hole: its outer polygon encloses the hole's pixels too
+            if r["steps"] == 0:
+                continue
+            assert r["a00"] < 0 or r["area"] == 0  # outer borders run this way round
+            if r["area"] == sizes[k - 1] - r["steps"] / 2 - 1:  # Pick: interior + boundary / 2 - 1 (no pixel visited twice)
+                checked += 1
+                if r["kept"]:
+                    assert abs(r["cx"] + 0.5 - cents[k - 1][1]) <= 1.0 and abs(r["cy"] + 0.5 - cents[k - 1][0]) <= 1.0
+            else:  # a pixel of a one-pixel-wide part is visited twice: the polygon's lattice points are fewer than the steps
+                assert r["area"] > sizes[k - 1] - r["steps"] / 2 - 1
+    assert checked >= 30
+
+
 @pytest.mark.parametrize("W,H", [(64, 48), (250, 130), (251, 77), (500, 300), (960, 540)])
 @pytest.mark.parametrize("scale", [1.0, 4.0, -3.0])
 @pytest.mark.parametrize("mode", ["box", "box_unstaged", "dense", "dense_gather", "dense_boxes"])
