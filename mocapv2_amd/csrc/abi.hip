@@ -39,6 +39,10 @@ static int fail(int code, const char* fmt, ...)
     } while (0)
 
 struct EvPair { hipEvent_t a, b; };
+// the scan's probe counters (BrightArgs::probe): 128 pairs, each pair in a cache line of its own (PROBE_STRIDE words apart) -- packed
+// into 8 lines, the ~200 k atomic adds of a probed batch queued up on 8 L2 atomic units: 0.3 ms on top of the scan's 0.95
+constexpr size_t PROBE_BYTES = 128 * mocap::PROBE_STRIDE * sizeof(uint32_t);
+using mocap::PROBE_STRIDE;
 
 // One RCCL communicator per rank, shared by the rank's contexts (= the batches in flight): RCCL wants the operations of a
 // communicator issued one after the other, so every all-gather waits for the event its predecessor recorded (on whatever
@@ -263,8 +267,8 @@ int mocap_ctx_create(int device_id, int width, int height, int n_slots, mocap_ct
     if (e == hipSuccess) e = hipMemset(c->map_flags, 0, sizeof(uint32_t) * n_slots + 256);
     if (e == hipSuccess) e = hipMalloc(&c->n_items, 1024); // item count + the 8 head words of the box kernel's runs
     if (e == hipSuccess) e = hipMemset(c->n_items, 0, 1024);
-    if (e == hipSuccess) e = hipMalloc(&c->probe_dev, 1024);
-    if (e == hipSuccess) e = hipHostMalloc(&c->probe_host, 1024);
+    if (e == hipSuccess) e = hipMalloc(&c->probe_dev, PROBE_BYTES);
+    if (e == hipSuccess) e = hipHostMalloc(&c->probe_host, PROBE_BYTES);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->probe_ev, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
@@ -584,7 +588,7 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
     if (fixed_base >= 0) { if (fixed_base > thr_mul - 1) fixed_base = thr_mul - 1; if (fixed_base > 254) fixed_base = 254; if (fixed_base < 0) fixed_base = 0; }
     if (c->probe_pending && hipEventQuery(c->probe_ev) == hipSuccess) { // the last probe's counts have arrived
         unsigned long long n_cur = 0, n_alt = 0;
-        for (int i = 0; i < 128; i++) { n_cur += c->probe_host[2 * i]; n_alt += c->probe_host[2 * i + 1]; }
+        for (int i = 0; i < 128; i++) { n_cur += c->probe_host[PROBE_STRIDE * i]; n_alt += c->probe_host[PROBE_STRIDE * i + 1]; }
         if (c->tune.probe_debug) fprintf(stderr, "[probe] base %d: %llu hot cells, alternative %d: %llu\n", excess_base(thr_mul, c->base_sel), n_cur, excess_base(thr_mul, c->base_sel ^ 1), n_alt);
         // The tight base (sel 0) leaves tighter boxes around the markers for the same number of hot cells (measured: 33k against
         // 45k marked tiles per 3072 images of the benchmark scene), so it is preferred unless the background makes its hot cells
@@ -698,7 +702,7 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
         const bool probe = fixed_base < 0 && !c->probe_pending && allow_alt >= 0 && base_alt != base && !bayer &&
                            (c->probe_age == 0 || c->probe_age >= 32);
         if (probe) {
-            HIP_TRY(hipMemsetAsync(c->probe_dev, 0, 1024, s));
+            HIP_TRY(hipMemsetAsync(c->probe_dev, 0, PROBE_BYTES, s));
             b.probe = c->probe_dev;
         }
         c->probe_age = probe ? 1 : c->probe_age + 1;
@@ -711,7 +715,7 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
         prof_end(c, 3, s, p, on);
         HIP_TRY(hipGetLastError());
         if (probe) {
-            HIP_TRY(hipMemcpyAsync(c->probe_host, c->probe_dev, 1024, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(c->probe_host, c->probe_dev, PROBE_BYTES, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipEventRecord(c->probe_ev, s));
             c->probe_pending = true;
         }

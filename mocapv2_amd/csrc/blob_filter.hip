@@ -297,8 +297,8 @@ __device__ __forceinline__ void bright_cells_block(const BrightArgs& a, const in
             }
             const int n_cur = __popcll(__ballot((int)acc > a.hot)), n_alt = __popcll(__ballot((int)acc2 > a.hot_alt));
             if ((threadIdx.x & 63) == 0) {
-                atomicAdd(&a.probe[2 * (bx & 127)], (uint32_t)n_cur);
-                atomicAdd(&a.probe[2 * (bx & 127) + 1], (uint32_t)n_alt);
+                atomicAdd(&a.probe[PROBE_STRIDE * (bx & 127)], (uint32_t)n_cur);
+                atomicAdd(&a.probe[PROBE_STRIDE * (bx & 127) + 1], (uint32_t)n_alt);
             }
         }
     }

@@ -130,6 +130,7 @@ enum { BLOB_ERR_CANDIDATES = -2, BLOB_ERR_CONTOURS = -3, BLOB_ERR_STEPS = -4, BL
 
 void launch_filter_mask(const FilterArgs& a, bool remap, hipStream_t s);
 void launch_filter_tiles(const FilterArgs& a, bool remap, int blocks, hipStream_t s);
+constexpr int PROBE_STRIDE = 32; // words between two pairs of probe counters: a cache line each
 struct BrightArgs {
     const uint8_t* src; size_t image_stride; int pitch, H, W, n_images; // W >= 8
     int cam_mod;                  // undistort slot of image n = n % cam_mod (the tables already point at the first slot)
@@ -144,7 +145,7 @@ struct BrightArgs {
                                   //   rows_magic = ceil(2^23 / rows per chunk)
     uint32_t* mask; size_t mask_words; int mask_aligned16; // caller-owned bit masks to clear on the side (mask_words = 0: none)
     // probe (optional): on every 16th image also count the cells that are hot under the current base and under the alternative
-    // base `base_alt` / threshold `hot_alt`, into probe[2 * (block & 127) + 0 / 1]: the host compares the sums and switches
+    // base `base_alt` / threshold `hot_alt`, into probe[PROBE_STRIDE * (block & 127) + 0 / 1]: the host compares the sums and switches
     uint32_t* probe; int base_alt, hot_alt;
     int prio;                     // wave priority of the scan (s_setprio): its few instructions are loads that keep HBM busy
     int max_blocks;               // > 0: launch at most this many workgroups, each looping over the batch's blocks (persistent form)
