@@ -810,7 +810,7 @@ __device__ __forceinline__ int64_t pair_swap64(int64_t v)
 __device__ __forceinline__ double pair_swap_f64(double v) { return __longlong_as_double(pair_swap64(__double_as_longlong(v))); }
 
 struct Walk { // one lane's half of a walk
-    uint64_t rU, rM, rD; // the three 64-column mask rows around the current pixel
+    int r, r_ahead;      // raster key y * (W + 1) + x of the current pixel; backward lane: of the pixel ahead of it (the one it came from)
     int64_t a00, a10, a01;
     double diag, pend;
     int sx, sy, x, y, known; // start pixel of the border; current pixel; the direction this lane knows there: the way back
@@ -849,17 +849,26 @@ __global__ __launch_bounds__(64) void contour_follow_kernel(ContourArgs a)
     uint64_t t_prev = clk ? wall_clock64() : 0;
     auto lap = [&](int i) { if (clk) { const uint64_t t = wall_clock64(); tk[i] += t - t_prev; t_prev = t; } };
     __syncthreads();
-    auto fetch = [&](int yy) -> uint64_t { return win[(yy - w.wy0) & 63][w.wslot]; }; // inside the window (see the pause rule)
     // occupancy of the 8 neighbours of (x,y), bit s = direction code s (0=E 1=NE 2=N 3=NW 4=W 5=SW 6=S 7=SE) -- for the backward
-    // lane of the vertically mirrored image (rows swapped: NE <-> SE, N <-> S, NW <-> SW)
-    auto nbr8 = [&](bool mirror) -> uint32_t {
-        const int c = w.x - w.wx0 - 1; // column x-1 at bit 0
-        const uint64_t ru = mirror ? w.rD : w.rU, rd = mirror ? w.rU : w.rD;
-        const uint32_t up = (uint32_t)(ru >> c) & 7u, mid = (uint32_t)(w.rM >> c) & 7u, dn = (uint32_t)(rd >> c) & 7u;
+    // lane of the vertically mirrored image (rows swapped: NE <-> SE, N <-> S, NW <-> SW).  Straight from the lane's window: the
+    // three columns x-1 .. x+1 of a row lie in the 16 bits at byte (x - 1 - wx0) >> 3 of the window row (one ds_read_u16 each; the
+    // pixel is inside the rim, see the pause rule -- a paused lane reads some bytes of the array and does not use them).
+    const uint8_t* const win_bytes = (const uint8_t*)&win[0][0];
+    const int up_dy = isB ? 1 : -1; // the row that plays "up"
+    auto nbr8 = [&](int x, int y, int up_dy) -> uint32_t {
+        const int c = x - w.wx0 - 1; // column x-1 at bit 0
+        const uint32_t col = (uint32_t)w.wslot * 8u + (((uint32_t)c >> 3) & 7u), sh = (uint32_t)c & 7u;
+        const int ly = y - w.wy0;
+        uint16_t vu, vm, vd;
+        __builtin_memcpy(&vu, win_bytes + ((((uint32_t)(ly + up_dy) & 63u) << 9) + col), 2);
+        __builtin_memcpy(&vm, win_bytes + ((((uint32_t)ly & 63u) << 9) + col), 2);
+        __builtin_memcpy(&vd, win_bytes + ((((uint32_t)(ly - up_dy) & 63u) << 9) + col), 2);
+        const uint32_t up = ((uint32_t)vu >> sh) & 7u, mid = ((uint32_t)vm >> sh) & 7u, dn = ((uint32_t)vd >> sh) & 7u;
         const uint32_t up_rev = (0x73516240u >> (4u * up)) & 7u; // bit order NE, N, NW = columns x+1, x, x-1
         return (mid >> 2) | (up_rev << 1) | ((mid & 1u) << 4) | (dn << 5);
     };
-    auto on_rim = [&]() { const int lx = w.x - w.wx0, ly = w.y - w.wy0; return lx < 1 || lx > 62 || ly < 1 || ly > 62; };
+    auto on_rim = [&]() { return (unsigned)(w.x - w.wx0 - 1) > 61u || (unsigned)(w.y - w.wy0 - 1) > 61u; };
+    auto dir_off = [&](int d) { return __mul24(dir_dy(d), RS) + dir_dx(d); }; // what a step in direction d adds to the raster key
     auto close_run = [&](int len, int parity) { // one CHAIN_APPROX_SIMPLE segment of `len` steps: its cv.arcLength term
         if (parity) w.diag += len < 64 ? diag_len[len] : run_length(1, len);
         else w.axis += len;
@@ -990,8 +999,7 @@ __global__ __launch_bounds__(64) void contour_follow_kernel(ContourArgs a)
             }
             __syncthreads(); // (one wave) the windows are in LDS before any lane reads its own
             if (take) { // both lanes of the pair: the start's first neighbour, clockwise from the one known to be background
-                w.rU = fetch(w.y - 1); w.rM = fetch(w.y); w.rD = fetch(w.y + 1);
-                const uint32_t n0 = nbr8(false);
+                const uint32_t n0 = nbr8(w.x, w.y, -1);
                 const int sx = w.sx, ey = w.sy;
                 w.key = ey * RS + ex;
                 const int first = (kind == 0 || kind == 2) ? 4 : 0; // W (outer start) / E
@@ -1012,19 +1020,14 @@ __global__ __launch_bounds__(64) void contour_follow_kernel(ContourArgs a)
                     finished = true;
                 } else {
                     w.s0 = s;
-                    if (isB) { w.x = sx + dir_dx(s); w.y = ey + dir_dy(s); w.known = s ^ 4; } // one step back along the border: the way forward from there
+                    w.r = ey * RS + sx; w.r_ahead = w.r;
+                    if (isB) { w.x = sx + dir_dx(s); w.y = ey + dir_dy(s); w.r += dir_off(s); w.known = s ^ 4; } // one step back along the border: the way forward from there
                     else w.known = s;
                     active = true;
                     paused = on_rim();
                 }
-            }
-            if ((take && active && isB && !paused) || (paused && !take)) {
-                // the rows around the lane's pixel from its (new) window
-                const bool was = paused && !take;
-                w.rU = fetch(w.y - 1); w.rM = fetch(w.y); w.rD = fetch(w.y + 1);
-                if (was) paused = false;
-            }
-            if (active && !paused) w.n = nbr8(isB);
+            } else if (paused) paused = false; // (its window now lies around its pixel)
+            if (active && !paused) w.n = nbr8(w.x, w.y, up_dy);
         }
         lap(1);
         if (__ballot(active || finished) == 0) break; // nothing in flight (and nothing left in the list, or the refill would have run)
@@ -1039,18 +1042,18 @@ __global__ __launch_bounds__(64) void contour_follow_kernel(ContourArgs a)
             const int srch = isB ? (8 - su) & 7 : su;
             const int nx = w.x + dir_dx(srch), ny = w.y + dir_dy(srch);
             // where the two lanes stand on the border's cycle of (pixel, way back) states: the forward lane at its own state, the
-            // backward lane just behind the state (pixel ahead of it, way back to it)
-            const int st_x = isB ? w.x + dir_dx(w.known) : w.x, st_y = isB ? w.y + dir_dy(w.known) : w.y, st_d = isB ? w.known ^ 4 : w.known;
-            const int nw_x = isB ? w.x : nx, nw_y = isB ? w.y : ny, nw_d = isB ? srch : srch ^ 4; // ... and after this step
-            const int o_st_x = pair_swap(st_x), o_st_y = pair_swap(st_y), o_st_d = pair_swap(st_d);
-            const int o_nw_x = pair_swap(nw_x), o_nw_y = pair_swap(nw_y), o_nw_d = pair_swap(nw_d);
-            const int o_flags = pair_swap((go ? 1 : 0) | (active ? 2 : 0) | (w.status << 2));
-            const int o_steps = pair_swap(w.steps);
-            const bool o_go = (o_flags & 1) != 0;
-            const bool met = active && (o_flags & 2) && st_x == o_st_x && st_y == o_st_y && st_d == o_st_d && w.steps + o_steps > 0;
+            // backward lane just behind the state (pixel ahead of it, way back to it) -- pixels as raster keys
+            const int r_next = w.r + dir_off(srch);
+            const int st_r = isB ? w.r_ahead : w.r, st_d = isB ? w.known ^ 4 : w.known;
+            const int nw_r = isB ? w.r : r_next, nw_d = isB ? srch : srch ^ 4; // ... and after this step
+            const int fl = (go ? 1 : 0) | (active ? 2 : 0) | (w.steps > 0 ? 4 : 0) | (w.status << 3);
+            const int o_st_r = pair_swap(st_r), o_nw_r = pair_swap(nw_r), o_misc = pair_swap(st_d | (nw_d << 3) | (fl << 6));
+            const int o_st_d = o_misc & 7, o_nw_d = (o_misc >> 3) & 7, o_fl = o_misc >> 6;
+            const bool o_go = (o_fl & 1) != 0;
+            const bool met = active && (o_fl & 2) && st_r == o_st_r && st_d == o_st_d && ((fl | o_fl) & 4);
             // the forward lane's step completes the cycle: the backward lane must not take the same step from the other side
-            const bool fwd_closes = isB ? (o_go && o_nw_x == st_x && o_nw_y == st_y && o_nw_d == st_d) : (nw_x == o_st_x && nw_y == o_st_y && nw_d == o_st_d);
-            const bool partner_gave_up = active && (o_flags >> 2) != 0;
+            const bool fwd_closes = (isB ? o_nw_r : nw_r) == (isB ? st_r : o_st_r) && (isB ? o_nw_d : nw_d) == (isB ? st_d : o_st_d) && (o_go || !isB);
+            const bool partner_gave_up = active && (o_fl >> 3) != 0;
             if (met || partner_gave_up || (isB && active && fwd_closes)) {
                 // met: the halves cover the whole border; the last case: the forward lane's step of this round completes the cycle, the
                 // backward lane must not take the same step from the other side
@@ -1058,7 +1061,7 @@ __global__ __launch_bounds__(64) void contour_follow_kernel(ContourArgs a)
             } else if (go) {
                 // this lane accounts for one forward step of the border: from its pixel, in direction s, having arrived from s_end
                 const int s = isB ? w.known : srch, s_end = isB ? srch : w.known;
-                const int r = w.y * RS + w.x;
+                const int r = w.r;
                 const bool east_bg = (unsigned)(s - 1) < (unsigned)s_end; // the East neighbour was examined and is background
                 const int re = east_bg ? r + 1 : 0x7fffffff;
                 w.min_ebg = re < w.min_ebg ? re : w.min_ebg;
@@ -1083,31 +1086,25 @@ __global__ __launch_bounds__(64) void contour_follow_kernel(ContourArgs a)
                 w.npts += vertex ? 1 : 0;
                 w.run = (vertex ? 0 : w.run) + (isB ? 0 : 1);
                 const int dx = dir_dx(s), dy = dir_dy(s);
-                const int cross = w.x * dy - dx * w.y; // x*ny - nx*y
+                const int cross = __mul24(w.x, dy) - __mul24(dx, w.y); // x*ny - nx*y (coordinates below 2^15)
                 w.a00 += cross;
                 w.a10 += (int64_t)cross * (2 * w.x + dx);
                 w.a01 += (int64_t)cross * (2 * w.y + dy);
                 w.steps++;
-                const bool aborted = (w.abort_on_fg ? r : re) < w.abort_lt;
-                if (aborted || w.steps > a.max_steps) {
-                    w.status = aborted ? 1 : 2;
-                    active = false; finished = true;
-                } else if (!isB && fwd_closes) {
-                    active = false; finished = true; // (the backward lane sees the same condition and stops as well)
-                    w.known = srch ^ 4;              // the way back from the meeting pixel: the direction of the forward tail
-                } else {
-                    // move.  The three rows around the new pixel and its left / right neighbour columns must lie inside the window:
-                    // a lane that steps onto the window's rim pauses until its window is staged anew (no global load in this loop).
-                    const int my = ny - w.y;
-                    w.x = nx; w.y = ny; w.known = srch ^ 4;
-                    paused = on_rim();
-                    const uint64_t nwr = fetch(ny + my); // (my = 0: the middle row again, unused; a paused lane reads some row of its window)
-                    const uint64_t oU = w.rU, oM = w.rM, oD = w.rD;
-                    w.rU = my > 0 ? oM : (my < 0 ? nwr : oU);
-                    w.rM = my > 0 ? oD : (my < 0 ? oU : oM);
-                    w.rD = my > 0 ? nwr : (my < 0 ? oM : oD);
-                    w.n = nbr8(isB); // (garbage while paused: recomputed with the new window)
-                }
+                const bool aborted = (w.abort_on_fg ? r : re) < w.abort_lt, limit = w.steps > a.max_steps;
+                // the walk ends here when it has left its border's claim (aborted), ran too long, or -- forward lane -- this step completes
+                // the cycle (the backward lane sees the same condition and stops as well; known = the way back from the meeting pixel: the
+                // direction of the forward tail)
+                const bool stop = aborted || limit || (!isB && fwd_closes);
+                w.status = aborted ? 1 : (limit ? 2 : w.status);
+                // move (a lane that stops moves too: nothing reads its position afterwards).  The three rows around the new pixel and its
+                // left / right neighbour columns must lie inside the window: a lane that steps onto the window's rim pauses until its
+                // window is staged anew (no global load in this loop).
+                w.x = nx; w.y = ny; w.known = srch ^ 4;
+                w.r_ahead = w.r; w.r = r_next;
+                paused = !stop && on_rim();
+                w.n = nbr8(nx, ny, up_dy); // (garbage while paused: read again from the new window)
+                active = !stop; finished = stop;
             }
             if (clk) { tk[3]++; tk[4] += (uint64_t)__popcll(__ballot(active && !paused)); }
             if (__ballot(active && !paused) == 0) break;
