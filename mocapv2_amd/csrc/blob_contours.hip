@@ -310,7 +310,7 @@ constexpr int MAX_SPLIT_IMAGES = 1 << 20; // image field of a walk entry
 // form -- candidates only (handed to contour_follow_kernel through the workspace and the batch-wide walk list) / tree only
 // (from the records that kernel left).
 template <int MODE>
-__device__ __forceinline__ void contours_body(const ContourArgs& a)
+__device__ __forceinline__ void contours_body(const ContourArgs& a, const int image)
 {
     __shared__ uint32_t cand[MAXC];
     // phase A: cell_list (uint16 [MAXCELL]); afterwards: rbox (int16 [MAXR][4]), kept_idx (int16 [MAXK]), kept_depth (int8 [MAXK])
@@ -333,7 +333,6 @@ __device__ __forceinline__ void contours_body(const ContourArgs& a)
     if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
     else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
     else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
-    const int image = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = uni(tid >> 6);
     Mask M{a.mask + (size_t)image * a.H * a.words_per_row, a.words_per_row, a.H, a.W, a.W + 1};
@@ -704,7 +703,10 @@ __device__ __forceinline__ void contours_body(const ContourArgs& a)
         if (!second_pass && n_amb > 0) { // hand the open links to the second follow pass; this image is finished by the second tree pass
             __shared__ uint32_t lbase;
             const int na = n_amb < MAXA ? n_amb : MAXA;
-            if (tid == 0) { lbase = atomicAdd(&a.walk_count[2], (uint32_t)na); work.st_pending = na; }
+            if (tid == 0) {
+                lbase = atomicAdd(&a.walk_count[2], (uint32_t)na); work.st_pending = na;
+                a.wait_list[atomicAdd(&a.walk_count[4], 1u)] = (uint32_t)image; // the second tree pass runs over this list
+            }
             __syncthreads();
             for (int i = tid; i < na; i += NTHREADS) a.link_list[lbase + (uint32_t)i] = amb[i];
             for (int c = tid; c < nr; c += NTHREADS) work.rlink[c] = rlink[c];
@@ -773,10 +775,34 @@ __device__ __forceinline__ void contours_body(const ContourArgs& a)
     }
 }
 
+// The workgroups take images in a stride loop: the launch may hold fewer workgroups than the batch has images (ContourArgs::image_grid).
+// Beside another batch's streaming scan a workgroup of four waves waits long for a place -- the scan's small waves take every hole a
+// retiring wave leaves -- so a workgroup that has one keeps it for several images.  The second tree pass runs over the list of the
+// images that wait for link walks (mostly none: its workgroups read one counter and leave).
 template <int MODE>
-__global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a) { contours_body<MODE>(a); }
+__global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
+{
+    if (MODE == 2 && a.tree_pass == 2) {
+        const uint32_t n = a.walk_count[4];
+        for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+            contours_body<MODE>(a, (int)a.wait_list[i]);
+            __syncthreads();
+        }
+        return;
+    }
+    for (int image = blockIdx.x; image < a.n_images; image += gridDim.x) {
+        contours_body<MODE>(a, image);
+        __syncthreads(); // the next image reuses the LDS arrays
+    }
+}
 // (capping the candidates kernel at 72 registers for 7 workgroups per CU instead of 5 spills 13 of them: 325 k against 337 k frames/s)
-__global__ __launch_bounds__(NTHREADS) void contour_candidates_kernel(ContourArgs a) { contours_body<1>(a); }
+__global__ __launch_bounds__(NTHREADS) void contour_candidates_kernel(ContourArgs a)
+{
+    for (int image = blockIdx.x; image < a.n_images; image += gridDim.x) {
+        contours_body<1>(a, image);
+        __syncthreads();
+    }
+}
 
 // The walks of the whole batch, whatever image they belong to, TWO LANES PER BORDER: lane 2i follows the border forwards from
 // its start, lane 2i + 1 backwards from the same start (border following is reversible: the backward walk is the forward rule
@@ -1125,16 +1151,17 @@ void launch_contours(const ContourArgs& a_, hipStream_t s)
         // candidates per image -> every walk of the batch -> tree per image; the (few) links whose owner only a walk can tell go
         // through a second, equally packed, follow pass, and the second tree pass finishes the images that waited for them
         ContourArgs a = a_;
-        (void)hipMemsetAsync(a.walk_count, 0, 4 * sizeof(uint32_t), s);
-        hipLaunchKernelGGL(contour_candidates_kernel, dim3(a.n_images), dim3(NTHREADS), 0, s, a);
+        const int grid = a.image_grid > 0 && a.image_grid < a.n_images ? a.image_grid : a.n_images;
+        (void)hipMemsetAsync(a.walk_count, 0, 8 * sizeof(uint32_t), s);
+        hipLaunchKernelGGL(contour_candidates_kernel, dim3(grid), dim3(NTHREADS), 0, s, a);
         a.follow_list = 0;
         hipLaunchKernelGGL(contour_follow_kernel, dim3(a.follow_grid), dim3(64), 0, s, a);
         a.tree_pass = 1;
-        hipLaunchKernelGGL(contours_kernel<2>, dim3(a.n_images), dim3(NTHREADS), 0, s, a);
+        hipLaunchKernelGGL(contours_kernel<2>, dim3(grid), dim3(NTHREADS), 0, s, a);
         a.follow_list = 1;
         hipLaunchKernelGGL(contour_follow_kernel, dim3(a.follow_grid2), dim3(64), 0, s, a);
         a.tree_pass = 2;
-        hipLaunchKernelGGL(contours_kernel<2>, dim3(a.n_images), dim3(NTHREADS), 0, s, a);
+        hipLaunchKernelGGL(contours_kernel<2>, dim3(a.follow_grid2 < a.n_images ? a.follow_grid2 : a.n_images), dim3(NTHREADS), 0, s, a);
         return;
     }
     hipLaunchKernelGGL(contours_kernel<0>, dim3(a_.n_images), dim3(NTHREADS), 0, s, a_);

@@ -1,0 +1,127 @@
+// hbm_mix.hip -- what a streaming read of 6.4 GB (the scan's access pattern: every byte once, 16-byte non-temporal loads, 8 in
+// flight per lane) loses when another stream's kernel touches HBM at the same time in small scattered pieces, as the filter and contour
+// kernels do -- and what it loses to a kernel that only occupies wave slots.  Round 3: the pipelined step is the scan plus ~0.6 of the
+// other kernels' stand-alone time whatever the placement; this probe separates "slots" from "DRAM efficiency".
+//   hipcc --offload-arch=gfx950 -O3 -o scratch/hbm_mix scratch/hbm_mix.hip && scratch/hbm_mix
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdint>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s -> %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int POLICY> __device__ __forceinline__ u32x4 load16(const uint8_t* p)
+{ // 0 plain, 1 nt, 2 sc1 nt, 3 sc0 sc1 nt, 4 sc1, 5 sc0 sc1
+    u32x4 v;
+    if (POLICY == 0) return *(const u32x4*)p;
+    if (POLICY == 1) return __builtin_nontemporal_load((const u32x4*)p);
+    if (POLICY == 2) asm volatile("global_load_dwordx4 %0, %1, off sc1 nt" : "=v"(v) : "v"(p) : "memory");
+    if (POLICY == 3) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt" : "=v"(v) : "v"(p) : "memory");
+    if (POLICY == 4) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    if (POLICY == 5) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+template <int POLICY>
+__global__ __launch_bounds__(256) void stream_read(const uint8_t* __restrict__ src, uint32_t* sink)
+{ // one block = 32 KB: 8 rows of 4096 bytes, lane = 16 bytes of a row
+    const uint8_t* p = src + (size_t)blockIdx.x * 32768 + threadIdx.x * 16;
+    u32x4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = load16<POLICY>(p + j * 4096);
+    if (POLICY >= 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t s = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) s += __builtin_amdgcn_sad_u8(v[j].x, 0x3f3f3f3fu, 0u) + __builtin_amdgcn_sad_u8(v[j].y, 0x3f3f3f3fu, 0u) +
+                                     __builtin_amdgcn_sad_u8(v[j].z, 0x3f3f3f3fu, 0u) + __builtin_amdgcn_sad_u8(v[j].w, 0x3f3f3f3fu, 0u);
+    if (s == 0xffffffffu) *sink = s;
+}
+
+// mode 0: scattered 4-byte reads, each in a 64-byte line of its own (dependent on nothing: 8 in flight per lane)
+// mode 1: scattered 4-byte writes; mode 2: no memory at all (the same number of waves busy for about as long)
+__global__ __launch_bounds__(64) void scatter(uint32_t* __restrict__ buf, size_t lines, int per_lane, int mode, uint32_t* sink)
+{
+    uint32_t h = (blockIdx.x * 64u + threadIdx.x) * 2654435761u + 12345u;
+    uint32_t acc = 0;
+    for (int i = 0; i < per_lane; i += 8) {
+        uint32_t idx[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) { h = h * 1664525u + 1013904223u; idx[j] = (uint32_t)(((uint64_t)h * lines) >> 32); }
+        if (mode == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc += buf[(size_t)idx[j] * 16];
+        } else if (mode == 1) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) buf[(size_t)idx[j] * 16] = h + j;
+        } else {
+            for (int k = 0; k < 24; k++) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc = acc * 1664525u + idx[j];
+            }
+        }
+    }
+    if (acc == 0xdeadbeefu) *sink = acc;
+}
+
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int main()
+{
+    const size_t big = 6370099200ull / 32768 * 32768; // the bench's 3072 frames
+    const size_t lines = (1ull << 30) / 64;          // 1 GB of lines for the scattered kernel
+    uint8_t* src; uint32_t* buf; uint32_t* sink;
+    CK(hipMalloc(&src, big)); CK(hipMalloc(&buf, lines * 64)); CK(hipMalloc(&sink, 64));
+    CK(hipMemset(src, 1, big)); CK(hipMemset(buf, 0, lines * 64));
+    hipStream_t s1, s2;
+    CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    const int nblk = (int)(big / 32768);
+    int policy = 1;
+    size_t set_lines = lines;
+    auto run = [&](int mode, int waves, int per_lane, bool with_stream, bool with_scatter) -> double {
+        (void)hipDeviceSynchronize();
+        const double t0 = now_ms();
+        if (with_stream) {
+            if (policy == 0) stream_read<0><<<nblk, 256, 0, s1>>>(src, sink);
+            if (policy == 1) stream_read<1><<<nblk, 256, 0, s1>>>(src, sink);
+            if (policy == 2) stream_read<2><<<nblk, 256, 0, s1>>>(src, sink);
+            if (policy == 3) stream_read<3><<<nblk, 256, 0, s1>>>(src, sink);
+            if (policy == 4) stream_read<4><<<nblk, 256, 0, s1>>>(src, sink);
+            if (policy == 5) stream_read<5><<<nblk, 256, 0, s1>>>(src, sink);
+        }
+        if (with_scatter) scatter<<<waves, 64, 0, s2>>>(buf, set_lines, per_lane, mode, sink);
+        (void)hipDeviceSynchronize();
+        return now_ms() - t0;
+    };
+    run(0, 256, 64, true, true); // warm-up
+    const char* names[3] = {"scattered reads ", "scattered writes", "no memory       "};
+    for (int rep = 0; rep < 1; rep++) {
+        const double alone = run(0, 0, 0, true, false);
+        printf("stream alone: %.3f ms (%.2f TB/s)\n", alone, big / alone / 1e9);
+        for (int mode = 0; mode < 3; mode++)
+            for (int waves = 1024; waves <= 4096; waves *= 4)
+                for (int per_lane = 32; per_lane <= 128; per_lane *= 2) {
+                    const double mb = (double)waves * 64 * per_lane * 64 / 1e6; // bytes of DRAM lines touched
+                    const double a = run(mode, waves, per_lane, false, true), both = run(mode, waves, per_lane, true, true);
+                    printf("%s %5d waves x %3d per lane (%6.0f MB of lines): alone %.3f ms, with the stream %.3f ms\n", names[mode], waves, per_lane,
+                           mode == 2 ? 0.0 : mb, a, both);
+                }
+    }
+    // a SMALL set (32 / 128 MB of lines) read over and over beside the stream: does it stay in the memory-side cache (256 MB) under
+    // each load policy of the stream?  4096 waves x 128 per lane = 33.5 M reads = 64 x the 32 MB set
+    const char* pol[6] = {"plain", "nt", "sc1 nt", "sc0 sc1 nt", "sc1", "sc0 sc1"};
+    for (int rep = 0; rep < 2; rep++)
+        for (policy = 0; policy < 6; policy++) {
+            set_lines = lines;
+            const double alone = run(0, 0, 0, true, false);
+            printf("stream [%-10s] alone %.3f ms |", pol[policy], alone);
+            for (size_t mbs : {32, 128, 1024}) {
+                set_lines = mbs * (1ull << 20) / 64;
+                run(0, 4096, 128, false, true);
+                const double a = run(0, 4096, 128, false, true), both = run(0, 4096, 128, true, true);
+                printf("  %4zu MB set: reads alone %.3f, with the stream %.3f (+%.3f)", mbs, a, both, both - alone);
+            }
+            printf("\n");
+        }
+    return 0;
+}
