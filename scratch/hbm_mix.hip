@@ -64,6 +64,59 @@ __global__ __launch_bounds__(64) void scatter(uint32_t* __restrict__ buf, size_t
     if (acc == 0xdeadbeefu) *sink = acc;
 }
 
+// a kernel shaped like box_filter_kernel: `waves` one-wave workgroups, ~240 registers each (two per SIMD), 20 KB of LDS, busy with
+// VALU work (mode 0) or with LDS reads and writes (mode 1) for `iters` rounds, no global memory
+__global__ __launch_bounds__(64) void busy(int iters, int mode, uint32_t* sink)
+{
+    __shared__ uint32_t lds[5120];
+    uint32_t r[200];
+#pragma unroll
+    for (int i = 0; i < 200; i++) r[i] = threadIdx.x * 2654435761u + i;
+    for (int i = threadIdx.x; i < 5120; i += 64) lds[i] = i;
+    __syncthreads();
+    for (int it = 0; it < iters; it++) {
+        if (mode == 0) {
+#pragma unroll
+            for (int i = 0; i < 200; i++) r[i] = r[i] * 1664525u + r[(i + 7) % 200];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 200; i += 4) {
+                const uint32_t a = lds[(r[i] + threadIdx.x) % 5120];
+                lds[(a + threadIdx.x * 17) % 5120] = r[i + 1];
+                r[i] += a;
+            }
+        }
+    }
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 200; i++) acc ^= r[i];
+    if (acc == 0xdeadbeefu) *sink = acc;
+}
+
+// the same streaming read as a persistent launch: `gridDim.x` workgroups take 32 KB blocks from a shared counter, 16 at a time
+__global__ __launch_bounds__(256) void stream_read_persistent(const uint8_t* __restrict__ src, int nblk, uint32_t* ctr, uint32_t* sink)
+{
+    __shared__ uint32_t base;
+    uint32_t s = 0;
+    for (;;) {
+        if (threadIdx.x == 0) base = atomicAdd(ctr, 16u);
+        __syncthreads();
+        const uint32_t b0 = base;
+        __syncthreads();
+        if (b0 >= (uint32_t)nblk) break;
+        for (uint32_t b = b0; b < b0 + 16 && b < (uint32_t)nblk; b++) {
+            const uint8_t* p = src + (size_t)b * 32768 + threadIdx.x * 16;
+            u32x4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = __builtin_nontemporal_load((const u32x4*)(p + j * 4096));
+#pragma unroll
+            for (int j = 0; j < 8; j++) s += __builtin_amdgcn_sad_u8(v[j].x, 0x3f3f3f3fu, 0u) + __builtin_amdgcn_sad_u8(v[j].y, 0x3f3f3f3fu, 0u) +
+                                             __builtin_amdgcn_sad_u8(v[j].z, 0x3f3f3f3fu, 0u) + __builtin_amdgcn_sad_u8(v[j].w, 0x3f3f3f3fu, 0u);
+        }
+    }
+    if (s == 0xffffffffu) *sink = s;
+}
+
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int main()
@@ -95,7 +148,7 @@ int main()
     };
     run(0, 256, 64, true, true); // warm-up
     const char* names[3] = {"scattered reads ", "scattered writes", "no memory       "};
-    for (int rep = 0; rep < 1; rep++) {
+    for (int rep = 0; rep < 0; rep++) {
         const double alone = run(0, 0, 0, true, false);
         printf("stream alone: %.3f ms (%.2f TB/s)\n", alone, big / alone / 1e9);
         for (int mode = 0; mode < 3; mode++)
@@ -107,10 +160,59 @@ int main()
                            mode == 2 ? 0.0 : mb, a, both);
                 }
     }
+    {   // who runs when: events around each kernel on its own stream, both referred to one start event
+        hipEvent_t e0, a0, a1, b0, b1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&a0)); CK(hipEventCreate(&a1)); CK(hipEventCreate(&b0)); CK(hipEventCreate(&b1));
+        uint32_t* ctr; CK(hipMalloc(&ctr, 64));
+        for (int rep = 0; rep < 2; rep++)
+            for (int form = 0; form < 4; form++)      // 0: one workgroup per block; 1 / 2 / 3: persistent, 8 / 4 / 2 workgroups per CU
+                for (int order = 0; order < 2; order++) { // which kernel is launched first
+                    (void)hipDeviceSynchronize();
+                    CK(hipMemsetAsync(ctr, 0, 64, s1));
+                    (void)hipDeviceSynchronize();
+                    CK(hipEventRecord(e0, s1));
+                    auto launch_a = [&]() {
+                        (void)hipEventRecord(a0, s1);
+                        if (form == 0) stream_read<1><<<nblk, 256, 0, s1>>>(src, sink);
+                        else stream_read_persistent<<<256 * (16 >> form), 256, 0, s1>>>(src, nblk, ctr, sink);
+                        (void)hipEventRecord(a1, s1);
+                    };
+                    auto launch_b = [&]() {
+                        (void)hipEventRecord(b0, s2);
+                        busy<<<1024, 64, 0, s2>>>(400, 0, sink);
+                        (void)hipEventRecord(b1, s2);
+                    };
+                    if (order == 0) { launch_a(); launch_b(); } else { launch_b(); launch_a(); }
+                    (void)hipDeviceSynchronize();
+                    float ta0, ta1, tb0, tb1;
+                    (void)hipEventElapsedTime(&ta0, e0, a0); (void)hipEventElapsedTime(&ta1, e0, a1);
+                    (void)hipEventElapsedTime(&tb0, e0, b0); (void)hipEventElapsedTime(&tb1, e0, b1);
+                    printf("stream %s, %s first: stream %.3f .. %.3f ms, VALU kernel (1024 fat waves, 0.39 ms alone) %.3f .. %.3f ms\n",
+                           form == 0 ? "one workgroup per block" : form == 1 ? "persistent 8 per CU    " : form == 2 ? "persistent 4 per CU    " : "persistent 2 per CU    ",
+                           order == 0 ? "stream" : "VALU  ", ta0, ta1, tb0, tb1);
+                }
+    }
+    for (int rep = 0; rep < 0; rep++)
+        for (int mode = 0; mode < 2; mode++)
+          for (int nwaves = 2048; nwaves >= 512; nwaves /= 2)
+            for (int iters = 100; iters <= 200; iters *= 2) {
+                policy = 1;
+                auto runb = [&](bool with_stream) {
+                    (void)hipDeviceSynchronize();
+                    const double t0 = now_ms();
+                    if (with_stream) stream_read<1><<<nblk, 256, 0, s1>>>(src, sink);
+                    busy<<<nwaves, 64, 0, s2>>>(iters * (2048 / nwaves), mode, sink);
+                    (void)hipDeviceSynchronize();
+                    return now_ms() - t0;
+                };
+                runb(false);
+                const double a = runb(false), both = runb(true);
+                printf("%s kernel, %d waves of ~240 registers, %3d rounds: alone %.3f ms, with the stream %.3f ms\n", mode ? "LDS " : "VALU", nwaves, iters * (2048 / nwaves), a, both);
+            }
     // a SMALL set (32 / 128 MB of lines) read over and over beside the stream: does it stay in the memory-side cache (256 MB) under
     // each load policy of the stream?  4096 waves x 128 per lane = 33.5 M reads = 64 x the 32 MB set
     const char* pol[6] = {"plain", "nt", "sc1 nt", "sc0 sc1 nt", "sc1", "sc0 sc1"};
-    for (int rep = 0; rep < 2; rep++)
+    for (int rep = 0; rep < 0; rep++)
         for (policy = 0; policy < 6; policy++) {
             set_lines = lines;
             const double alone = run(0, 0, 0, true, false);
