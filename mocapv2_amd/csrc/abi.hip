@@ -80,7 +80,6 @@ struct Tuning {
     int probe_debug = 0;
     int contour_boxes = 1;       // 0 = candidates from whole strips
     int contours_split = 1;      // 0 = the contour stage as one kernel per image
-    int contour_grid_per_cu = 0; // > 0: the per-image contour kernels (candidates, tree) as that many workgroups per CU, looping over the images
     int corr_threads = 256;      // threads per time step of the correspondence kernel (64 / 128 / 256)
     int corr_step_groups = 0;    // candidate groups one time step may hold in all (error scratch per step); 0 = max(2 * max_groups, 8192)
 };
@@ -95,7 +94,7 @@ static const TuneName kTuneNames[] = {
     {"box_blocks_per_cu", &Tuning::box_blocks_per_cu, 0, 32}, {"box_timing", &Tuning::box_timing, 0, 1},
     {"contour_timing", &Tuning::contour_timing, 0, 1}, {"follow_timing", &Tuning::follow_timing, 0, 2}, {"scan_wide", &Tuning::scan_wide, 0, 1}, {"scan_blocks_per_cu", &Tuning::scan_blocks_per_cu, 0, 64}, {"scan_slices", &Tuning::scan_slices, 1, 64}, {"excess_base", &Tuning::excess_base, -1, 254},
     {"base_sel", &Tuning::base_sel, 0, 1}, {"probe_debug", &Tuning::probe_debug, 0, 1}, {"contour_boxes", &Tuning::contour_boxes, 0, 1},
-    {"contours_split", &Tuning::contours_split, 0, 1}, {"contour_grid_per_cu", &Tuning::contour_grid_per_cu, 0, 64}, {"corr_threads", &Tuning::corr_threads, 64, 256},
+    {"contours_split", &Tuning::contours_split, 0, 1}, {"corr_threads", &Tuning::corr_threads, 64, 256},
     {"corr_step_groups", &Tuning::corr_step_groups, 0, 0x7fffffff},
 };
 static bool tune_set(Tuning& t, const char* name, int v)
@@ -830,7 +829,6 @@ static int run_contours(mocap_ctx* c, const uint32_t* mask, const uint32_t* cell
     a.follow_grid = c->n_cu * 4;  // 4 one-wave workgroups per CU (33 KB of LDS each): persistent, they refill their lanes from the list
     a.follow_grid2 = c->n_cu;     // the link walks are few
     a.wait_list = (uint32_t*)((uint8_t*)c->link_list + contour_link_bytes() * c->cwork_images);
-    a.image_grid = c->tune.contour_grid_per_cu * c->n_cu;
     a.follow_list = 0; a.tree_pass = 0; a.follow_dbg = nullptr; a.follow_dbg_list = c->tune.follow_timing == 2 ? 1 : 0;
     if (c->tune.follow_timing && split) {
         HIP_TRY(hipMalloc(&a.follow_dbg, sizeof(uint64_t) * 8 * a.follow_grid));

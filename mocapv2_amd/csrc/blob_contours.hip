@@ -775,34 +775,21 @@ __device__ __forceinline__ void contours_body(const ContourArgs& a, const int im
     }
 }
 
-// The workgroups take images in a stride loop: the launch may hold fewer workgroups than the batch has images (ContourArgs::image_grid).
-// Beside another batch's streaming scan a workgroup of four waves waits long for a place -- the scan's small waves take every hole a
-// retiring wave leaves -- so a workgroup that has one keeps it for several images.  The second tree pass runs over the list of the
-// images that wait for link walks (mostly none: its workgroups read one counter and leave).
+// One workgroup per image.  The second tree pass runs over the list of the images that wait for link walks (mostly none: its
+// workgroups read one counter and leave).  (The kernels as loops over the images, fewer workgroups than images: 19 more registers for
+// the candidates kernel, 42 for the tree kernel, 8 us slower each, nothing gained in the pipeline -- profiles/README.md.)
 template <int MODE>
 __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
 {
+    int image = blockIdx.x;
     if (MODE == 2 && a.tree_pass == 2) {
-        const uint32_t n = a.walk_count[4];
-        for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
-            contours_body<MODE>(a, (int)a.wait_list[i]);
-            __syncthreads();
-        }
-        return;
+        if ((uint32_t)image >= a.walk_count[4]) return;
+        image = uni((int)a.wait_list[image]);
     }
-    for (int image = blockIdx.x; image < a.n_images; image += gridDim.x) {
-        contours_body<MODE>(a, image);
-        __syncthreads(); // the next image reuses the LDS arrays
-    }
+    contours_body<MODE>(a, image);
 }
 // (capping the candidates kernel at 72 registers for 7 workgroups per CU instead of 5 spills 13 of them: 325 k against 337 k frames/s)
-__global__ __launch_bounds__(NTHREADS) void contour_candidates_kernel(ContourArgs a)
-{
-    for (int image = blockIdx.x; image < a.n_images; image += gridDim.x) {
-        contours_body<1>(a, image);
-        __syncthreads();
-    }
-}
+__global__ __launch_bounds__(NTHREADS) void contour_candidates_kernel(ContourArgs a) { contours_body<1>(a, blockIdx.x); }
 
 // The walks of the whole batch, whatever image they belong to, TWO LANES PER BORDER: lane 2i follows the border forwards from
 // its start, lane 2i + 1 backwards from the same start (border following is reversible: the backward walk is the forward rule
@@ -1151,17 +1138,16 @@ void launch_contours(const ContourArgs& a_, hipStream_t s)
         // candidates per image -> every walk of the batch -> tree per image; the (few) links whose owner only a walk can tell go
         // through a second, equally packed, follow pass, and the second tree pass finishes the images that waited for them
         ContourArgs a = a_;
-        const int grid = a.image_grid > 0 && a.image_grid < a.n_images ? a.image_grid : a.n_images;
         (void)hipMemsetAsync(a.walk_count, 0, 8 * sizeof(uint32_t), s);
-        hipLaunchKernelGGL(contour_candidates_kernel, dim3(grid), dim3(NTHREADS), 0, s, a);
+        hipLaunchKernelGGL(contour_candidates_kernel, dim3(a.n_images), dim3(NTHREADS), 0, s, a);
         a.follow_list = 0;
         hipLaunchKernelGGL(contour_follow_kernel, dim3(a.follow_grid), dim3(64), 0, s, a);
         a.tree_pass = 1;
-        hipLaunchKernelGGL(contours_kernel<2>, dim3(grid), dim3(NTHREADS), 0, s, a);
+        hipLaunchKernelGGL(contours_kernel<2>, dim3(a.n_images), dim3(NTHREADS), 0, s, a);
         a.follow_list = 1;
         hipLaunchKernelGGL(contour_follow_kernel, dim3(a.follow_grid2), dim3(64), 0, s, a);
         a.tree_pass = 2;
-        hipLaunchKernelGGL(contours_kernel<2>, dim3(a.follow_grid2 < a.n_images ? a.follow_grid2 : a.n_images), dim3(NTHREADS), 0, s, a);
+        hipLaunchKernelGGL(contours_kernel<2>, dim3(a.n_images), dim3(NTHREADS), 0, s, a);
         return;
     }
     hipLaunchKernelGGL(contours_kernel<0>, dim3(a_.n_images), dim3(NTHREADS), 0, s, a_);

@@ -120,7 +120,6 @@ struct ContourArgs {
     uint32_t* walk_count;  // split form: [8] entries in walk_list, its head, entries in link_list, its head, entries in wait_list
                            //   (zeroed by launch_contours)
     uint32_t* wait_list;   // split form: [n_images] the images the first tree pass left to the second one
-    int image_grid;        // split form: workgroups of the per-image kernels (candidates, tree); 0 or >= n_images: one per image
     int follow_grid;       // split form: workgroups (waves) of the follow kernel
     int follow_grid2;      //   ... of its second pass (the link walks: few)
     int follow_list;       // set by launch_contours: 0 = the follow kernel works through walk_list, 1 = through link_list
