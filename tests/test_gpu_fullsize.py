@@ -127,3 +127,66 @@ def test_config5_sixteen_cameras_64_markers_and_ba_residuals():
     obj = H.triangulate_points(groups.tolist(), poses)
     got = H.calculate_reprojection_errors(groups.tolist(), obj, poses).astype(np.float32)
     assert got.shape == exp.shape and np.allclose(got, exp, rtol=1e-5, atol=1e-6)
+
+
+def test_full_batch_512_time_steps_properties_and_oracle_sample():
+    """BASELINE.json configs[1] at its full size -- ONE batch of 512 time steps x 6 cameras x 1080p (3072 images, 6.4 GB) through
+    BatchTracker -- checked by what does not depend on the size: (a) the batch holds 16 copies of 32 rendered time steps: every copy of
+    a time step gives the same centroid record and the same 3-D points; (b) permuting the time steps of the batch permutes the results
+    and changes nothing else (a result does not depend on its neighbours in the batch, on the wave / workgroup / list position its blobs
+    land in, nor on the lane of the pipeline); (c) eight of the 32 time steps against the CPU oracle, frame -> centroid -> 3-D."""
+    import torch
+    from mocapv2_amd.pipeline import BatchTracker, scene_arrays
+    from test_gpu_oracle_e2e import assert_records_equal, assert_step_equal, oracle_step
+    C, T, W, H, base = 6, 512, 1920, 1080, 32
+    sc = Scene(C, W, H, dist=MILD_DIST)
+    K, dist, R, t, F = scene_arrays(sc)
+    frames = sc.render_batch(seed=5100, n_steps=base, n_markers=8, radius_range=(16, 22), salt=0.001)  # [32, 6, H, W]
+    dev32 = torch.from_numpy(frames).cuda()
+    g = torch.Generator().manual_seed(5)
+    order = torch.cat([torch.randperm(base, generator=g) for _ in range(T // base)])  # time step s of the batch = rendered step order[s]
+    batch = dev32[order.cuda()].reshape(T * C, H, W).contiguous()
+    perm = torch.randperm(T, generator=g)
+    batch_p = batch.reshape(T, C, H, W)[perm.cuda()].reshape(T * C, H, W).contiguous()
+    trk = BatchTracker(K, dist, R, t, F, W, H, T, depth=3)
+
+    def run(x):
+        out = trk.step(x)
+        trk.synchronize()
+        rec = trk.records.cpu().numpy().copy()
+        return rec, {k: v.cpu().numpy().copy() for k, v in out.items()}
+
+    rec, out = run(batch)           # lane 0
+    rec_p, out_p = run(batch_p)     # lane 1
+    rec2, out2 = run(batch)         # lane 2
+    def same_record(a, b):
+        return a[0] == b[0] and np.array_equal(a[2:2 + 2 * max(0, a[0])], b[2:2 + 2 * max(0, a[0])])
+
+    assert all(same_record(rec[i], rec2[i]) for i in range(T * C)) and np.array_equal(out["n"], out2["n"])  # another lane, same results
+    order_np, perm_np = order.numpy(), perm.numpy()
+    first = {}
+    points = 0
+    for s in range(T):
+        k = int(out["n"][s])
+        assert k >= 0, (s, k)
+        live = [(rec[s * C + c, 0], rec[s * C + c, 2:2 + 2 * max(0, rec[s * C + c, 0])].tolist()) for c in range(C)]
+        res = (k, out["root"][s, :k].tolist(), out["grp"][s, :k].tolist(), out["xyz"][s, :k].tolist(), out["order"][s, :k].tolist())
+        r = int(order_np[s])
+        if r in first:
+            assert (live, res) == first[r], ("copies of one time step differ", s, r)                       # (a)
+        else:
+            first[r] = (live, res)
+        points += k
+    for j in range(T):  # (b): position j of the permuted batch holds time step perm[j]
+        s = int(perm_np[j])
+        for c in range(C):
+            assert same_record(rec_p[j * C + c], rec[s * C + c]), (j, s, c)
+        k = int(out_p["n"][j])
+        assert k == int(out["n"][s]) and np.array_equal(out_p["xyz"][j, :k], out["xyz"][s, :k]) and np.array_equal(out_p["grp"][j, :k], out["grp"][s, :k]), (j, s)
+    assert len(first) == base and points >= 3 * T
+    for r in range(0, base, 4):  # (c)
+        s = int(np.nonzero(order_np == r)[0][0])
+        lists, ref = oracle_step(frames[r], K, dist, R, t, F)
+        for c in range(C):
+            assert_records_equal(rec, s * C + c, lists[c], (s, c))
+        assert_step_equal(out, s, ref, s)
