@@ -129,8 +129,9 @@ def test_config5_sixteen_cameras_64_markers_and_ba_residuals():
     assert got.shape == exp.shape and np.allclose(got, exp, rtol=1e-5, atol=1e-6)
 
 
-def test_full_batch_512_time_steps_properties_and_oracle_sample():
-    """BASELINE.json configs[1] at its full size -- ONE batch of 512 time steps x 6 cameras x 1080p (3072 images, 6.4 GB) through
+@pytest.mark.parametrize("markers", [8, 32], ids=["configs1", "configs2"])
+def test_full_batch_512_time_steps_properties_and_oracle_sample(markers):
+    """BASELINE.json configs[1] / configs[2] (8 / 32 markers) at full size -- ONE batch of 512 time steps x 6 cameras x 1080p (3072 images, 6.4 GB) through
     BatchTracker -- checked by what does not depend on the size: (a) the batch holds 16 copies of 32 rendered time steps: every copy of
     a time step gives the same centroid record and the same 3-D points; (b) permuting the time steps of the batch permutes the results
     and changes nothing else (a result does not depend on its neighbours in the batch, on the wave / workgroup / list position its blobs
@@ -141,14 +142,15 @@ def test_full_batch_512_time_steps_properties_and_oracle_sample():
     C, T, W, H, base = 6, 512, 1920, 1080, 32
     sc = Scene(C, W, H, dist=MILD_DIST)
     K, dist, R, t, F = scene_arrays(sc)
-    frames = sc.render_batch(seed=5100, n_steps=base, n_markers=8, radius_range=(16, 22), salt=0.001)  # [32, 6, H, W]
+    frames = sc.render_batch(seed=5100, n_steps=base, n_markers=markers, radius_range=(16, 22), salt=0.001)  # [32, 6, H, W]
+    max_groups = 4096  # a time step whose cartesian expansion exceeds it is given up by kernel and oracle alike (n = -2)
     dev32 = torch.from_numpy(frames).cuda()
     g = torch.Generator().manual_seed(5)
     order = torch.cat([torch.randperm(base, generator=g) for _ in range(T // base)])  # time step s of the batch = rendered step order[s]
     batch = dev32[order.cuda()].reshape(T * C, H, W).contiguous()
     perm = torch.randperm(T, generator=g)
     batch_p = batch.reshape(T, C, H, W)[perm.cuda()].reshape(T * C, H, W).contiguous()
-    trk = BatchTracker(K, dist, R, t, F, W, H, T, depth=3)
+    trk = BatchTracker(K, dist, R, t, F, W, H, T, depth=3, max_points=2 * markers if markers > 16 else 32, max_groups=max_groups)
 
     def run(x):
         out = trk.step(x)
@@ -168,9 +170,11 @@ def test_full_batch_512_time_steps_properties_and_oracle_sample():
     points = 0
     for s in range(T):
         k = int(out["n"][s])
-        assert k >= 0, (s, k)
+        assert k >= 0 or k == -2, (s, k)
+        n_s = k
+        k = max(k, 0)
         live = [(rec[s * C + c, 0], rec[s * C + c, 2:2 + 2 * max(0, rec[s * C + c, 0])].tolist()) for c in range(C)]
-        res = (k, out["root"][s, :k].tolist(), out["grp"][s, :k].tolist(), out["xyz"][s, :k].tolist(), out["order"][s, :k].tolist())
+        res = (n_s, out["root"][s, :k].tolist(), out["grp"][s, :k].tolist(), out["xyz"][s, :k].tolist(), out["order"][s, :k].tolist())
         r = int(order_np[s])
         if r in first:
             assert (live, res) == first[r], ("copies of one time step differ", s, r)                       # (a)
@@ -181,12 +185,15 @@ def test_full_batch_512_time_steps_properties_and_oracle_sample():
         s = int(perm_np[j])
         for c in range(C):
             assert same_record(rec_p[j * C + c], rec[s * C + c]), (j, s, c)
-        k = int(out_p["n"][j])
-        assert k == int(out["n"][s]) and np.array_equal(out_p["xyz"][j, :k], out["xyz"][s, :k]) and np.array_equal(out_p["grp"][j, :k], out["grp"][s, :k]), (j, s)
-    assert len(first) == base and points >= 3 * T
+        k = max(int(out_p["n"][j]), 0)
+        assert int(out_p["n"][j]) == int(out["n"][s]) and np.array_equal(out_p["xyz"][j, :k], out["xyz"][s, :k]) and np.array_equal(out_p["grp"][j, :k], out["grp"][s, :k]), (j, s)
+    assert len(first) == base and points >= 3 * T  # (32 markers: 8-12 triangulated roots per time step that is not given up)
     for r in range(0, base, 4):  # (c)
         s = int(np.nonzero(order_np == r)[0][0])
-        lists, ref = oracle_step(frames[r], K, dist, R, t, F)
+        lists, ref = oracle_step(frames[r], K, dist, R, t, F, max_groups=max_groups)
         for c in range(C):
             assert_records_equal(rec, s * C + c, lists[c], (s, c))
-        assert_step_equal(out, s, ref, s)
+        if ref is None:
+            assert out["n"][s] == -2, s
+        else:
+            assert_step_equal(out, s, ref, s)
