@@ -796,3 +796,50 @@ def test_tuning_switches_do_not_change_results(torch_cuda, monkeypatch, env):
             n = rec[i, 0]
             assert n == len(exp) and rec[i, 2:2 + 2 * n].reshape(-1, 2).tolist() == exp, (b, i, env)
             assert np.array_equal(got[i], m != 0), (b, i, env)
+
+
+def test_translation_invariance_identity_lens(torch_cuda):
+    """A size- and oracle-independent property of the whole blob stage: with the identity lens map, moving a frame's content by (dx, dy)
+    moves the mask and every centroid by exactly (dx, dy) and keeps the contour order -- whatever 8 x 8 scan cell, 240 x 68 filter tile,
+    mask byte / word, box-kernel item or wide-tile entry the blobs then fall into.  One 1080p frame (discs, a merged pair, a ring, a
+    bar; noise background) in 14 shifted copies as one batch."""
+    torch = torch_cuda
+    from gpu_util import unpack_mask
+    from mocapv2_amd.engine import MocapContext
+    H, W, M = 1080, 1920, 320  # M: margin the content keeps from the border, so that no shift cuts a blob
+    rng = np.random.default_rng(77)
+    base = rng.integers(0, 50, (H, W), dtype=np.uint8)
+    yy, xx = np.mgrid[0:H, 0:W]
+    centres = []
+    while len(centres) < 14:
+        cx, cy, r = rng.integers(M, W - M), rng.integers(M, H - M), rng.integers(14, 26)
+        if all((cx - a) ** 2 + (cy - b) ** 2 > (r + c + 12) ** 2 for a, b, c in centres):
+            centres.append((cx, cy, r))
+            base[(xx - cx) ** 2 + (yy - cy) ** 2 <= r * r] = 255
+    cx, cy, r = centres[0]
+    base[(xx - cx - r - 8) ** 2 + (yy - cy) ** 2 <= r * r] = 255                                  # a merged pair
+    cx, cy, r = centres[1]
+    base[((xx - cx) ** 2 + (yy - cy) ** 2 <= (r + 14) ** 2) & ((xx - cx) ** 2 + (yy - cy) ** 2 >= (r + 4) ** 2)] = 255  # a ring around a disc
+    base[M - 40:M - 28, M:M + 300] = 255                                                           # a bar: a wide box
+    shifts = [(0, 0), (1, 0), (0, 1), (3, 5), (7, 7), (8, 8), (31, 33), (32, 64), (239, 67), (240, 68), (-1, -1), (-9, -70), (-241, 5), (121, -35)]
+    batch = np.zeros((len(shifts), H, W), np.uint8)
+    for i, (dx, dy) in enumerate(shifts):
+        ys, yd = (slice(0, H - dy), slice(dy, H)) if dy >= 0 else (slice(-dy, H), slice(0, H + dy))
+        xs, xd = (slice(0, W - dx), slice(dx, W)) if dx >= 0 else (slice(-dx, W), slice(0, W + dx))
+        batch[i][yd, xd] = base[ys, xs]
+    ctx = MocapContext(W, H, 1)
+    ctx.set_undistort(0, np.array([[1000.0, 0, W / 2], [0, 1000.0, H / 2], [0, 0, 1]]), np.zeros(5))
+    dev = torch.from_numpy(batch).cuda()
+    masks, _ = unpack_mask(ctx.filter_mask(dev, cam_mod=1), W)
+    xy, cnt = ctx.record_views(ctx.blob_centroids(dev, cam_mod=1))
+    xy, cnt = xy.cpu().numpy(), cnt.cpu().numpy()
+    assert cnt[0] >= 14 and masks[0].sum() > 10000
+    inner = (slice(250, H - 250), slice(250, W - 250))  # the part of the mask every shifted copy still holds
+    for i, (dx, dy) in enumerate(shifts):
+        assert cnt[i] == cnt[0], (dx, dy)
+        assert np.array_equal(xy[i, :cnt[i]], xy[0, :cnt[0]] + np.array([dx, dy])), (dx, dy)
+        moved = np.zeros_like(masks[0])
+        ys, yd = (slice(0, H - dy), slice(dy, H)) if dy >= 0 else (slice(-dy, H), slice(0, H + dy))
+        xs, xd = (slice(0, W - dx), slice(dx, W)) if dx >= 0 else (slice(-dx, W), slice(0, W + dx))
+        moved[yd, xd] = masks[0][ys, xs]
+        assert np.array_equal(masks[i][inner], moved[inner]), (dx, dy)
