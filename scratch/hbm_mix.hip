@@ -66,6 +66,24 @@ __global__ __launch_bounds__(64) void scatter(uint32_t* __restrict__ buf, size_t
 
 // a kernel shaped like box_filter_kernel: `waves` one-wave workgroups, ~240 registers each (two per SIMD), 20 KB of LDS, busy with
 // VALU work (mode 0) or with LDS reads and writes (mode 1) for `iters` rounds, no global memory
+template <int NR>
+__global__ __launch_bounds__(64) void busy_n(int iters, uint32_t* sink)
+{ // NR live registers per lane, VALU only, 20 KB of LDS like the box kernel
+    __shared__ uint32_t lds[5120];
+    uint32_t r[NR];
+#pragma unroll
+    for (int i = 0; i < NR; i++) r[i] = threadIdx.x * 2654435761u + i;
+    lds[threadIdx.x] = r[0];
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < NR; i++) r[i] = r[i] * 1664525u + r[(i + 7) % NR];
+    }
+    uint32_t acc = lds[(threadIdx.x * 7) & 63];
+#pragma unroll
+    for (int i = 0; i < NR; i++) acc ^= r[i];
+    if (acc == 0xdeadbeefu) *sink = acc;
+}
+
 __global__ __launch_bounds__(64) void busy(int iters, int mode, uint32_t* sink)
 {
     __shared__ uint32_t lds[5120];
@@ -160,11 +178,38 @@ int main()
                            mode == 2 ? 0.0 : mb, a, both);
                 }
     }
+    {   // a VALU kernel of 2048 one-wave workgroups with 40 / 100 / 200 live registers launched 20 us AFTER the stream has started
+        hipEvent_t e0, a1, b0, b1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&a1)); CK(hipEventCreate(&b0)); CK(hipEventCreate(&b1));
+        for (int rep = 0; rep < 2; rep++)
+            for (int nr = 0; nr < 3; nr++) {
+                float alone = 0;
+                for (int with_stream = 0; with_stream < 2; with_stream++) {
+                    (void)hipDeviceSynchronize();
+                    CK(hipEventRecord(e0, s1));
+                    if (with_stream) { stream_read<1><<<nblk, 256, 0, s1>>>(src, sink); CK(hipEventRecord(a1, s1)); }
+                    const double t0 = now_ms();
+                    while (now_ms() - t0 < 0.02) { }
+                    CK(hipEventRecord(b0, s2));
+                    if (nr == 0) busy_n<40><<<2048, 64, 0, s2>>>(1500, sink);
+                    if (nr == 1) busy_n<100><<<2048, 64, 0, s2>>>(600, sink);
+                    if (nr == 2) busy_n<200><<<2048, 64, 0, s2>>>(300, sink);
+                    CK(hipEventRecord(b1, s2));
+                    (void)hipDeviceSynchronize();
+                    float ta1 = 0, tb0, tb1;
+                    if (with_stream) (void)hipEventElapsedTime(&ta1, e0, a1);
+                    (void)hipEventElapsedTime(&tb0, e0, b0); (void)hipEventElapsedTime(&tb1, e0, b1);
+                    if (!with_stream) alone = tb1 - tb0;
+                    else printf("VALU kernel with %3d live registers, launched after the stream: alone %.3f ms; beside the stream %.3f .. %.3f ms, stream ends at %.3f ms\n",
+                                nr == 0 ? 40 : nr == 1 ? 100 : 200, alone, tb0, tb1, ta1);
+                }
+            }
+    }
     {   // who runs when: events around each kernel on its own stream, both referred to one start event
         hipEvent_t e0, a0, a1, b0, b1;
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&a0)); CK(hipEventCreate(&a1)); CK(hipEventCreate(&b0)); CK(hipEventCreate(&b1));
         uint32_t* ctr; CK(hipMalloc(&ctr, 64));
-        for (int rep = 0; rep < 2; rep++)
+        for (int rep = 0; rep < 0; rep++)
             for (int form = 0; form < 4; form++)      // 0: one workgroup per block; 1 / 2 / 3: persistent, 8 / 4 / 2 workgroups per CU
                 for (int order = 0; order < 2; order++) { // which kernel is launched first
                     (void)hipDeviceSynchronize();
