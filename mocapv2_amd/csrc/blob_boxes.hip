@@ -321,11 +321,17 @@ __device__ __forceinline__ SrcBounds source_bounds_partial(const ushort4* __rest
     return b;
 }
 
-__global__ __launch_bounds__(64) void box_filter_kernel(BoxArgs a)
+// LDS as a dynamic allocation and an explicit two waves per SIMD: with the 20 KB declared statically the compiler knows that no more
+// than two waves per SIMD can ever be resident and takes 242 registers; told to aim at two, it takes 214 (3 % slower alone).  The
+// difference decides whether a box wave finds room while another batch's scan is running (the cliff lies
+// between ~200 and ~240 registers).
+constexpr size_t BOX_LDS_BYTES = 1024 + (size_t)(BOX_HCAP + 64) * 8 + BOX_SCAP;
+__global__ __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(64) void box_filter_kernel(BoxArgs a)
 {
-    __shared__ uint32_t lut[256];
-    __shared__ uint2 Hs[BOX_HCAP + 64];                              // + 64: where lanes without a row park their store
-    __shared__ __attribute__((aligned(16))) uint8_t Sbuf[BOX_SCAP];   // staged source pixels; afterwards the window counts
+    extern __shared__ __attribute__((aligned(16))) uint8_t box_lds[];
+    uint32_t* const lut = (uint32_t*)box_lds;
+    uint2* const Hs = (uint2*)(box_lds + 1024);                         // + 64: where lanes without a row park their store
+    uint8_t* const Sbuf = box_lds + 1024 + (size_t)(BOX_HCAP + 64) * 8; // staged source pixels; afterwards the window counts
     uint32_t* const Cs = (uint32_t*)Sbuf;
     static_assert((BOX_HCAP + 64) * 4 <= BOX_SCAP, "counts alias the source buffer");
 
@@ -745,13 +751,13 @@ void launch_settle_tiles(const BoxArgs& a, hipStream_t s)
 int box_filter_blocks_per_cu()
 {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, box_filter_kernel, 64, 0) != hipSuccess || n < 1) n = 8;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, box_filter_kernel, 64, BOX_LDS_BYTES) != hipSuccess || n < 1) n = 8;
     return n;
 }
 
 void launch_box_filter(const BoxArgs& a, int grid, hipStream_t s)
 {
-    hipLaunchKernelGGL(box_filter_kernel, dim3(grid), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(box_filter_kernel, dim3(grid), dim3(64), BOX_LDS_BYTES, s, a);
 }
 
 } // namespace mocap
