@@ -1,7 +1,10 @@
 // hbm_mix.hip -- what a streaming read of 6.4 GB (the scan's access pattern: every byte once, 16-byte non-temporal loads, 8 in
 // flight per lane) loses when another stream's kernel touches HBM at the same time in small scattered pieces, as the filter and contour
 // kernels do -- and what it loses to a kernel that only occupies wave slots.  Round 3: the pipelined step is the scan plus ~0.6 of the
-// other kernels' stand-alone time whatever the placement; this probe separates "slots" from "DRAM efficiency".
+// other kernels' stand-alone time whatever the placement; this probe separates wave slots, registers and memory-side requests.
+// Parts: scattered reads / writes / no memory beside the stream; fat VALU kernels launched after the stream (82 / 202 / 493 registers);
+// who runs when with the stream as a plain or persistent launch; VALU / LDS kernels of 2048 .. 512 fat waves; the stream's load policies
+// against a small re-read set.  Results: profiles/history/r3_hbm_mix.log.
 //   hipcc --offload-arch=gfx950 -O3 -o scratch/hbm_mix scratch/hbm_mix.hip && scratch/hbm_mix
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -166,7 +169,7 @@ int main()
     };
     run(0, 256, 64, true, true); // warm-up
     const char* names[3] = {"scattered reads ", "scattered writes", "no memory       "};
-    for (int rep = 0; rep < 0; rep++) {
+    for (int rep = 0; rep < 1; rep++) {
         const double alone = run(0, 0, 0, true, false);
         printf("stream alone: %.3f ms (%.2f TB/s)\n", alone, big / alone / 1e9);
         for (int mode = 0; mode < 3; mode++)
@@ -209,7 +212,7 @@ int main()
         hipEvent_t e0, a0, a1, b0, b1;
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&a0)); CK(hipEventCreate(&a1)); CK(hipEventCreate(&b0)); CK(hipEventCreate(&b1));
         uint32_t* ctr; CK(hipMalloc(&ctr, 64));
-        for (int rep = 0; rep < 0; rep++)
+        for (int rep = 0; rep < 1; rep++)
             for (int form = 0; form < 4; form++)      // 0: one workgroup per block; 1 / 2 / 3: persistent, 8 / 4 / 2 workgroups per CU
                 for (int order = 0; order < 2; order++) { // which kernel is launched first
                     (void)hipDeviceSynchronize();
@@ -237,7 +240,7 @@ int main()
                            order == 0 ? "stream" : "VALU  ", ta0, ta1, tb0, tb1);
                 }
     }
-    for (int rep = 0; rep < 0; rep++)
+    for (int rep = 0; rep < 1; rep++)
         for (int mode = 0; mode < 2; mode++)
           for (int nwaves = 2048; nwaves >= 512; nwaves /= 2)
             for (int iters = 100; iters <= 200; iters *= 2) {
@@ -257,7 +260,7 @@ int main()
     // a SMALL set (32 / 128 MB of lines) read over and over beside the stream: does it stay in the memory-side cache (256 MB) under
     // each load policy of the stream?  4096 waves x 128 per lane = 33.5 M reads = 64 x the 32 MB set
     const char* pol[6] = {"plain", "nt", "sc1 nt", "sc0 sc1 nt", "sc1", "sc0 sc1"};
-    for (int rep = 0; rep < 0; rep++)
+    for (int rep = 0; rep < 1; rep++)
         for (policy = 0; policy < 6; policy++) {
             set_lines = lines;
             const double alone = run(0, 0, 0, true, false);
