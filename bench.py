@@ -563,6 +563,110 @@ def main():
                 "drop_in_matches_oracle": bool(got.shape == exp.shape and np.allclose(got, exp, rtol=2e-5, atol=1e-6)),
                 "cpu_oracle_ms_per_evaluation": round(1e3 * dt_cpu, 4)}
 
+
+    def oracle_time_step(wl, arrays, frames_c):
+        """one time step through the oracle (checker only): image-point lists per camera + correspondence result (or None)"""
+        import oracle
+        K, dist_, R, t, F = arrays
+        lists = [oracle.find_dot(frames_c[c], K[c], dist_[c]) for c in range(wl.cameras)]
+        P = max(1, max(len(l) for l in lists))
+        pts = np.zeros((wl.cameras, P, 2))
+        cnt = np.zeros(wl.cameras, np.int32)
+        for c, l in enumerate(lists):
+            cnt[c] = len(l)
+            if l:
+                pts[c, :len(l)] = l
+        try:
+            return lists, oracle.correspond(pts, cnt, K, dist_, R, t, F, max_groups=wl.max_groups)
+        except RuntimeError:
+            return lists, None
+
+    def latency_section(wl, m, n_rep=200):
+        """ONE time step (T = 1, one batch at a time) through the whole path, frames resident: the latency a live tracker would see
+        per frame set (reference: one pass of track_points + track, RealtimeTracking_FLIR.py:95-143,157-209)."""
+        frames_tc = m["frames_host"].reshape(m["T"], wl.cameras, wl.height, wl.width)
+        trk = BatchTracker(*m["arrays"], wl.width, wl.height, 1, depth=1, max_points=wl.max_points, max_groups=wl.max_groups)
+        dev = torch.from_numpy(np.ascontiguousarray(frames_tc[0])).cuda()
+        for _ in range(5):
+            out1 = trk.step(dev)
+        trk.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_rep):
+            out1 = trk.step(dev)
+            trk.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / n_rep
+        lists, ref = oracle_time_step(wl, m["arrays"], frames_tc[0])
+        rec = trk.records.cpu().numpy()
+        n = int(out1["n"].cpu()[0])
+        ok = all(int(rec[c, 0]) == len(lists[c]) and rec[c, 2:2 + 2 * len(lists[c])].reshape(-1, 2).tolist() == [list(p) for p in lists[c]]
+                 for c in range(wl.cameras))
+        ok = ok and ref is not None and n == len(ref["root"]) and (n == 0 or float(np.abs(out1["xyz"][0, :n].cpu().numpy() - ref["xyz"]).max()) < 1e-7)
+        return {"workload": f"one time step of {wl.cameras} cameras, {wl.width}x{wl.height}, frames resident, launch to synchronised result",
+                "latency_one_time_step_ms": round(ms, 4), "repetitions": n_rep, "points": n, "matches_oracle": bool(ok)}
+
+    def replay_section(wl, m, batch=128, runs=4):
+        """N3: the headless replay tracker (mocapv2_amd/replay.py = track_points + track, RealtimeTracking_FLIR.py:95-143,157-209)
+        over device-resident frames: batches of `batch` time steps, three in flight, INCLUDING the read-back of every batch, the
+        obj_count + 1 selection (lib/Helpers.py:274-279) and one msgpack message per time step (RealtimeTracking_FLIR.py:183-188)."""
+        import oracle
+        from mocapv2_amd.replay import OBJ_COUNT, ReplayTracker, tracker_message
+        T = m["T"]
+        frames = m["batches"][0].reshape(T, wl.cameras, wl.height, wl.width)
+        rp = ReplayTracker(*m["arrays"], wl.width, wl.height, batch=batch, max_points=wl.max_points, max_groups=wl.max_groups, depth=3)
+        first = list(rp.run(frames[:batch]))  # warm-up + the results that are checked
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_steps = 0
+        for _ in range(runs):
+            for res in rp.run_batches(frames):
+                n_steps += res["n_steps"]
+        dt_bulk = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        n_gen = 0
+        for _ in range(runs):
+            for _res in rp.run(frames):
+                n_gen += 1
+        dt_gen = time.perf_counter() - t0
+        # the first time steps against the oracle: object points, image points, message bytes
+        frames_tc = m["frames_host"].reshape(T, wl.cameras, wl.height, wl.width)
+        ok, point = True, [0] * 8
+        for s in range(2):
+            _, ref = oracle_time_step(wl, m["arrays"], frames_tc[s])
+            obj = oracle.select_objects(ref, OBJ_COUNT)[0] if ref is not None and len(ref["root"]) else np.array([])
+            if len(obj):
+                point = [0, 0, 0, 0] + list(obj[0])
+            got = first[s]
+            ok = ok and len(got["object_points"]) == len(obj) and (len(obj) == 0 or float(np.abs(got["object_points"] - obj).max()) < 1e-7)
+            ok = ok and (ref is None or len(ref["root"]) == 0 or np.array_equal(got["image_points"], ref["groups"].astype(np.int64)))
+            ok = ok and got["message"][:15] == tracker_message(point)[:15] and len(got["message"]) == len(tracker_message(point))
+        return {"workload": f"ReplayTracker(batch={batch}, depth=3) over {runs} x {T} time steps of the headline frames, device-resident",
+                "value": round(n_steps / dt_bulk, 1), "unit": "time steps/s", "form": "run_batches: results and messages per batch, built in bulk",
+                "per_time_step_generator": {"value": round(n_gen / dt_gen, 1), "unit": "time steps/s",
+                                            "form": "run: one Python dict per time step (the generator itself is the bound)"},
+                "includes": "device-to-host copy of every batch's outputs, obj_count + 1 selection, one msgpack message per time step",
+                "matches_oracle": bool(ok)}
+
+    def from_host_section(wl, m, steps=6):
+        """The PCIe-inclusive rate: the batch stays in pinned host memory and every step uploads it (never the headline `value`)."""
+        host = torch.from_numpy(m["frames_host"]).pin_memory()
+        trk = m["tracker"]
+        for _ in range(2):
+            trk.step(host)
+        trk.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out_h = trk.step(host)
+        trk.synchronize()
+        dt = time.perf_counter() - t0
+        ref_out = trk.step(m["batches"][0])
+        trk.synchronize()
+        same = bool(torch.equal(out_h["n"], ref_out["n"]))
+        nbytes = host.numel()
+        del host
+        return {"workload": "the headline batch uploaded from pinned host memory every step (PCIe-inclusive)", "value": round(m["T"] * steps / dt, 1),
+                "unit": "frames/s", "ms_per_step": round(1e3 * dt / steps, 3), "h2d_GBps": round(nbytes * steps / dt / 1e9, 2),
+                "same_results_as_resident": same}
+
     T_STEPS = args.time_steps or main_wl.default_time_steps()
     m = measure(main_wl, T_STEPS, args.steps, args.warmup)
     tracker, out, elapsed, prof = m["tracker"], m["out"], m["elapsed"], m["prof"]
@@ -615,6 +719,19 @@ def main():
         }
         if args.rehearse_on_one_gpu:
             line["rehearsal"] = "N ranks on one GPU over gloo: a functional check of the multi-rank path, NOT a measurement"
+        if world == 1 and args.extra and std and not args.from_host:
+            # figures that only existed in DESIGN.md, now in the driver-recorded line
+            pipe = {}
+            n_ss = 300
+            _, el_s, prof_s, _ = timed(tracker, m["batches"], n_ss, args.warmup)
+            pipe["steady_state"] = {"workload": main_wl.name(world), "steps": n_ss, "value": round(T_STEPS * n_ss / el_s, 2), "unit": "frames/s",
+                                    "ms_per_step": round(1e3 * el_s / n_ss, 4),
+                                    "kernel_ms_per_step_in_timed_region": kernel_ms(prof_s, True),
+                                    "note": "the headline's timed region with 300 steps instead of --steps: filling and draining the lanes no longer counts"}
+            pipe["latency"] = latency_section(main_wl, m)
+            pipe["replay_tracker"] = replay_section(main_wl, m)
+            pipe["from_host"] = from_host_section(main_wl, m)
+            line["pipeline"] = pipe
         left = m["left"]  # what the timed region left in the lanes' buffers: (batch, records, outputs)
         if world == 1 and args.secondary:
             # the same batches with the early-out off: every tile runs the full filter (dense kernel); the results must not change

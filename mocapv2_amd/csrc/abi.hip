@@ -53,6 +53,15 @@ struct SharedComm {
     hipEvent_t last = nullptr; // completion of the most recent all-gather on this communicator
     bool have_last = false;
     std::mutex mu;             // issue order = lock order
+    bool (*destroy_comm)(void*) = nullptr; // ncclCommDestroy, bound when the communicator is created
+    // the last context sharing the communicator is gone (mocap_comm_destroy, or a context destroyed without it): nothing leaks
+    ~SharedComm()
+    {
+        if (!comm && !last) return;
+        (void)hipSetDevice(device);
+        if (last) { if (have_last) (void)hipEventSynchronize(last); (void)hipEventDestroy(last); }
+        if (comm && destroy_comm) (void)destroy_comm(comm);
+    }
 };
 
 // Performance switches of a context (A/B measurements, tests of the alternative code paths; none changes a result).  They are
@@ -73,6 +82,10 @@ struct Tuning {
     int box_blocks_per_cu = 0;   // 0 = box_filter_blocks_per_cu()
     int box_timing = 0, contour_timing = 0, follow_timing = 0; // phase clocks on stderr (synchronous debugging aids)
     int scan_wide = 1;           // 0 = the scan's 8-byte loads
+    int rows_staged = 1;         // 0 = the row pipeline (dense path, wide tiles) on the general 8-byte tables with tap gathers instead of the compact table + LDS
+    int rows_stage_dw = -1;      // dwords of LDS a band's source rectangle may take (-1 = all of the buffer; 0 = taps from memory: a test switch)
+    int scan_serial = 0;         // 1 = one streaming scan at a time on the device: a context's scan waits for the scan launched before it (event chain across contexts)
+    int scan_hotmap = 1;         // 0 = the scan marks the tiles itself (reach lookup + atomics behind its loads) instead of leaving a hot map
     int scan_blocks_per_cu = 0;  // > 0: the scan as a persistent pass of that many workgroups per CU (0 = one workgroup per block)
     int scan_slices = 1;         // the scan goes out as that many launches over consecutive runs of images
     int excess_base = -1;        // >= 0: pins the scan's excess base
@@ -92,7 +105,7 @@ static const TuneName kTuneNames[] = {
     {"box_prio", &Tuning::box_prio, 0, 1}, {"scan_prio", &Tuning::scan_prio, 0, 3}, {"contour_prio", &Tuning::contour_prio, 0, 3},
     {"corr_prio", &Tuning::corr_prio, 0, 3}, {"box_stage_bytes", &Tuning::box_stage_bytes, 0, BOX_SCAP},
     {"box_blocks_per_cu", &Tuning::box_blocks_per_cu, 0, 32}, {"box_timing", &Tuning::box_timing, 0, 1},
-    {"contour_timing", &Tuning::contour_timing, 0, 1}, {"follow_timing", &Tuning::follow_timing, 0, 2}, {"scan_wide", &Tuning::scan_wide, 0, 1}, {"scan_blocks_per_cu", &Tuning::scan_blocks_per_cu, 0, 64}, {"scan_slices", &Tuning::scan_slices, 1, 64}, {"excess_base", &Tuning::excess_base, -1, 254},
+    {"contour_timing", &Tuning::contour_timing, 0, 1}, {"follow_timing", &Tuning::follow_timing, 0, 2}, {"scan_wide", &Tuning::scan_wide, 0, 1}, {"scan_hotmap", &Tuning::scan_hotmap, 0, 1}, {"scan_serial", &Tuning::scan_serial, 0, 1}, {"rows_staged", &Tuning::rows_staged, 0, 1}, {"rows_stage_dw", &Tuning::rows_stage_dw, -1, 1 << 20}, {"scan_blocks_per_cu", &Tuning::scan_blocks_per_cu, 0, 64}, {"scan_slices", &Tuning::scan_slices, 1, 64}, {"excess_base", &Tuning::excess_base, -1, 254},
     {"base_sel", &Tuning::base_sel, 0, 1}, {"probe_debug", &Tuning::probe_debug, 0, 1}, {"contour_boxes", &Tuning::contour_boxes, 0, 1},
     {"contours_split", &Tuning::contours_split, 0, 1}, {"corr_threads", &Tuning::corr_threads, 64, 256},
     {"corr_step_groups", &Tuning::corr_step_groups, 0, 0x7fffffff},
@@ -131,6 +144,7 @@ struct mocap_ctx {
     uint32_t* maps;           // [2][n_slots][H][W]: tap positions, then blend weights (general form)
     uint32_t* map4;           // [n_slots][H][W] (+ 4 words): compact table of the box kernel
     ushort4* srcbox;          // [n_slots][ceil(H/8)][ceil(W/8)]: source box per 8x8 output cell (box kernel)
+    ushort4* rowbox;          // [n_slots][H][n_strips]: source box per row and strip (staged row pipeline)
     uint32_t* map_flags;      // [n_slots] device
     std::vector<int> slot_state; // 0 unset, 1 identity, 2 remap
     std::vector<int> slot_compact; // 1 = the slot's displacements fit the compact table (identity: always)
@@ -141,6 +155,7 @@ struct mocap_ctx {
     bool mask_dirty;                       // the general kernel wrote the mask whole: clear it before the box path runs again
     uint32_t* cells; size_t cells_images; // occupancy cells written by the filter kernels for c->mask
     int last_images;                       // images of the most recent batch that wrote c->cells
+    uint32_t* hotmap;                      // [mask_images][hot_map_words(H, W, 1)] the scan's hot map (BrightArgs::hotmap)
     uint32_t* tile_rows;                   // [2][mask_images][tiles][4] the scan's box per tile (see BoxArgs): two arrays, alternating
     int tile_rows_flip;                    //   per batch: the one the scan widens and settle reads / the one settle empties
     int tile_rows_hold[2];                 //   images whose boxes each of the two may still hold (batches of varying size)
@@ -166,6 +181,11 @@ struct mocap_ctx {
 };
 
 static int set_device(mocap_ctx* c) { HIP_TRY(hipSetDevice(c->device)); return 0; }
+
+// scan_serial: the scans of all contexts of a device form one chain (each waits for the completion event of the one launched
+// before it), so that two batches' scans never share the chip -- a scan alone saturates HBM, two at once only delay each other
+struct ScanTurn { std::mutex mu; hipEvent_t done = nullptr; bool have = false; };
+static ScanTurn g_scan_turn[64];
 
 struct Tiling { int rows, n_cgroups, n_strips; };
 static Tiling tiling(const mocap_ctx* c)
@@ -241,9 +261,9 @@ int mocap_ctx_create(int device_id, int width, int height, int n_slots, mocap_ct
     mocap_ctx* c = new mocap_ctx();
     c->device = device_id; c->W = width; c->H = height; c->n_slots = n_slots; c->wpr = (width + 31) / 32;
     c->prm = mocap_blob_params{5, 5, 255 * 0.85, 500.0, 0.5};
-    c->maps = nullptr; c->map4 = nullptr; c->srcbox = nullptr; c->reach = nullptr; c->cflags = nullptr; c->map_flags = nullptr;
+    c->maps = nullptr; c->map4 = nullptr; c->srcbox = nullptr; c->rowbox = nullptr; c->reach = nullptr; c->cflags = nullptr; c->map_flags = nullptr;
     c->mask = nullptr; c->mask_images = 0; c->mask_dirty = false; c->cells = nullptr; c->cells_images = 0; c->last_images = 0;
-    c->tile_rows = nullptr; c->tile_rows_flip = 0; c->tile_rows_hold[0] = c->tile_rows_hold[1] = 0; c->cur_box = nullptr; c->items = nullptr; c->n_items = nullptr; c->cap_items = 0; c->wide_tiles = nullptr; c->cap_wide = 0;
+    c->hotmap = nullptr; c->tile_rows = nullptr; c->tile_rows_flip = 0; c->tile_rows_hold[0] = c->tile_rows_hold[1] = 0; c->cur_box = nullptr; c->items = nullptr; c->n_items = nullptr; c->cap_items = 0; c->wide_tiles = nullptr; c->cap_wide = 0;
     c->cells_ext = nullptr; c->cur_box_ext = nullptr; c->cells_ext_images = 0; c->cwork = nullptr; c->cwork_images = 0; c->walk_list = nullptr; c->link_list = nullptr; c->walk_count = nullptr;
     c->cams = nullptr; c->n_cam = 0; c->n_F = 0; c->scratch = nullptr; c->scratch_elems = 0; c->profiling = false;
     c->ba_obj = nullptr; c->ba_obj_elems = 0; c->ba_pinned = nullptr; c->ba_pinned_bytes = 0;
@@ -298,6 +318,7 @@ int mocap_ctx_destroy(mocap_ctx_t c)
     if (c->maps) (void)hipFree(c->maps);
     if (c->map4) (void)hipFree(c->map4);
     if (c->srcbox) (void)hipFree(c->srcbox);
+    if (c->rowbox) (void)hipFree(c->rowbox);
     if (c->cur_box) (void)hipFree(c->cur_box);
     if (c->cur_box_ext) (void)hipFree(c->cur_box_ext);
     if (c->items) (void)hipFree(c->items);
@@ -310,6 +331,7 @@ int mocap_ctx_destroy(mocap_ctx_t c)
     if (c->mask) (void)hipFree(c->mask);
     if (c->cells) (void)hipFree(c->cells);
     if (c->tile_rows) (void)hipFree(c->tile_rows);
+    if (c->hotmap) (void)hipFree(c->hotmap);
     if (c->cwork) (void)hipFree(c->cwork);
     if (c->walk_list) (void)hipFree(c->walk_list);
     if (c->link_list) (void)hipFree(c->link_list);
@@ -361,6 +383,8 @@ int mocap_set_undistort(mocap_ctx_t c, int slot, const double K[9], const double
     if (!c->map4) HIP_TRY(hipMalloc(&c->map4, sizeof(uint32_t) * (per * c->n_slots + 4))); // + 4: a quad load at the last pixel stays inside
     const int ncx_ = (c->W + 7) / 8, ncy_ = (c->H + 7) / 8;
     if (!c->srcbox) HIP_TRY(hipMalloc(&c->srcbox, sizeof(ushort4) * (size_t)ncx_ * ncy_ * c->n_slots));
+    const int n_strips_ = tiling(c).n_strips;
+    if (!c->rowbox) HIP_TRY(hipMalloc(&c->rowbox, sizeof(ushort4) * (size_t)c->H * n_strips_ * c->n_slots));
     MapArgs m;
     memcpy(m.K, K, sizeof(m.K));
     memcpy(m.dist, dist, sizeof(m.dist));
@@ -378,6 +402,8 @@ int mocap_set_undistort(mocap_ctx_t c, int slot, const double K[9], const double
     c->slot_compact[slot] = (flags & 2u) ? 0 : 1;
     c->slot_wmax[slot] = c->slot_state[slot] == 1 ? 1024u : 0u; // identity: every source pixel feeds exactly one output pixel
     launch_srcbox(m.map4, c->srcbox + (size_t)ncx_ * ncy_ * slot, c->H, c->W, 0);
+    HIP_TRY(hipGetLastError());
+    launch_rowbox(m.map4, c->rowbox + (size_t)c->H * n_strips_ * slot, c->H, c->W, n_strips_, 0);
     HIP_TRY(hipGetLastError());
     std::vector<uint32_t> edge((size_t)ncx_ * ncy_, 0); // source cells read by windows that the image border cuts: bit 0 one axis, bit 1 both
     std::vector<int> reach32((size_t)ncx_ * ncy_ * 4);  // per source cell: x0, x1, y0, y1 of the output pixels that read it
@@ -580,6 +606,11 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
         if (c->slot_state[sl] == 2 && !c->slot_compact[sl]) compact = false;
     }
     if (c->tune.general_filter) compact = false; // test switch: the general kernel
+    // the row pipeline's staged form (compact table, source pixels through LDS) serves the dense path and the wide tiles alike
+    bool rows_staged = remap && c->tune.rows_staged && c->map4 && c->rowbox && (c->W & 3) == 0 && c->W >= 8 && c->H >= 2;
+    for (int sl = slot_base; sl < slot_base + cam_mod; sl++)
+        if (!c->slot_compact[sl]) rows_staged = false;
+    const int rows_dw = c->tune.rows_stage_dw < 0 || c->tune.rows_stage_dw > rows_stage_dwords() ? rows_stage_dwords() : c->tune.rows_stage_dw;
     if (cells == c->cells) c->last_images = n_images;
     EvPair p; bool on;
     // dark-tile early-out: largest doubled excess sum 2E (E = sum of max(0, p - base)) per 16x16 block that still proves an
@@ -635,6 +666,9 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
         a.n_strips = tl.n_strips; a.rows_per_chunk = tl.rows; a.n_cgroups = tl.n_cgroups;
         a.pipelined = c->W >= 4 && (c->W & 3) == 0 && c->H >= 2;
         if (!c->tune.remap_pipeline) a.pipelined = 0; // test switch: the per-pixel gather
+        a.staged = rows_staged; a.stage_dw = rows_dw;
+        a.map4 = c->map4 ? c->map4 + (size_t)slot_base * c->H * c->W : nullptr;
+        a.rowbox = c->rowbox ? c->rowbox + (size_t)slot_base * c->H * tl.n_strips : nullptr;
         if (bayer) { launch_bayer_gray(*bayer, s); HIP_TRY(hipGetLastError()); }
         if (own_mask) c->mask_dirty = true;
         prof_begin(c, 0, s, p, on);
@@ -706,14 +740,35 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
             b.probe = c->probe_dev;
         }
         c->probe_age = probe ? 1 : c->probe_age + 1;
+        const bool fused = bayer && own_mask && bayer_scan_fusable(*bayer);
+        // the streaming scan leaves a hot map (two bits per cell, no table lookups or atomics behind its loads) that
+        // mark_tiles_kernel turns into tile boxes; the fused Bayer pass marks the tiles itself (MOCAP_SCAN_HOTMAP=0: so does the scan)
+        const bool two_step = !fused && c->tune.scan_hotmap && c->hotmap;
+        if (two_step) { b.hotmap = c->hotmap; b.hot_words = hot_map_words(c->H, c->W, wide); }
+        ScanTurn* turn = c->tune.scan_serial && c->device >= 0 && c->device < 64 ? &g_scan_turn[c->device] : nullptr;
+        std::unique_lock<std::mutex> turn_lock;
+        if (turn) {
+            turn_lock = std::unique_lock<std::mutex>(turn->mu);
+            if (!turn->done) HIP_TRY(hipEventCreateWithFlags(&turn->done, hipEventDisableTiming));
+            if (turn->have) HIP_TRY(hipStreamWaitEvent(s, turn->done, 0));
+        }
         prof_begin(c, 3, s, p, on);
-        if (bayer && own_mask && bayer_scan_fusable(*bayer)) launch_bayer_gray_scan(*bayer, b, s);
+        if (fused) launch_bayer_gray_scan(*bayer, b, s);
         else {
             if (bayer) launch_bayer_gray(*bayer, s);
             launch_bright_cells(b, s);
         }
         prof_end(c, 3, s, p, on);
         HIP_TRY(hipGetLastError());
+        if (turn) {
+            HIP_TRY(hipEventRecord(turn->done, s));
+            turn->have = true;
+            turn_lock.unlock();
+        }
+        if (two_step) {
+            launch_mark_tiles(b, s);
+            HIP_TRY(hipGetLastError());
+        }
         if (probe) {
             HIP_TRY(hipMemcpyAsync(c->probe_host, c->probe_dev, PROBE_BYTES, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipEventRecord(c->probe_ev, s));
@@ -754,6 +809,8 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
         f.n_strips = tl.n_strips; f.rows_per_chunk = tl.rows; f.n_cgroups = tl.n_cgroups;
         f.tiles = c->wide_tiles; f.n_tiles = c->n_items + 8; f.cap_tiles = c->cap_wide;
         f.pipelined = (c->W & 3) == 0 && c->H >= 2;
+        f.staged = rows_staged; f.stage_dw = rows_dw; f.map4 = a.map4;
+        f.rowbox = c->rowbox ? c->rowbox + (size_t)slot_base * c->H * tl.n_strips : nullptr;
         hipStream_t ws = s;
         if (fork_wide) {
             HIP_TRY(hipEventRecord(c->ev_fork, s));
@@ -909,6 +966,7 @@ static int ensure_mask(mocap_ctx* c, int n_images)
     HIP_TRY(hipMemset(c->cells, 0, cbytes));
     c->cells_images = n_images;
     if (c->tile_rows) { HIP_TRY(hipFree(c->tile_rows)); c->tile_rows = nullptr; }
+    if (c->hotmap) { HIP_TRY(hipFree(c->hotmap)); c->hotmap = nullptr; }
     if (c->cur_box) { HIP_TRY(hipFree(c->cur_box)); c->cur_box = nullptr; }
     if (c->items) { HIP_TRY(hipFree(c->items)); c->items = nullptr; c->cap_items = 0; }
     if (c->wide_tiles) { HIP_TRY(hipFree(c->wide_tiles)); c->wide_tiles = nullptr; c->cap_wide = 0; }
@@ -919,6 +977,9 @@ static int ensure_mask(mocap_ctx* c, int n_images)
         HIP_TRY(hipMemcpy(c->tile_rows, init.data(), sizeof(uint32_t) * init.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->tile_rows + init.size(), init.data(), sizeof(uint32_t) * init.size(), hipMemcpyHostToDevice));
         c->tile_rows_flip = 0; c->tile_rows_hold[0] = c->tile_rows_hold[1] = 0;
+        // the hot map needs no initial contents (the scan writes every word of the images it looks at); sized for either scan form
+        const int hw0 = hot_map_words(c->H, c->W, 0), hw1 = hot_map_words(c->H, c->W, 1);
+        HIP_TRY(hipMalloc(&c->hotmap, sizeof(uint32_t) * (size_t)n_images * (hw0 > hw1 ? hw0 : hw1)));
         for (size_t i = 0; i < init.size(); i++) init[i] = 1u;
         HIP_TRY(hipMalloc(&c->cur_box, sizeof(uint32_t) * init.size()));
         HIP_TRY(hipMemcpy(c->cur_box, init.data(), sizeof(uint32_t) * init.size(), hipMemcpyHostToDevice));
@@ -1141,6 +1202,7 @@ int mocap_comm_init(mocap_ctx_t c, const void* id, int rank, int world)
         return fail(MOCAP_E_HIP, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r_));
     }
     sc->rank = rank; sc->world = world; sc->device = c->device;
+    sc->destroy_comm = [](void* comm) { return g_rccl.lib && g_rccl.CommDestroy(comm) == 0; };
     c->comm = sc;
     return MOCAP_OK;
 }
@@ -1162,11 +1224,14 @@ int mocap_comm_destroy(mocap_ctx_t c)
     std::shared_ptr<SharedComm> sc = c->comm;
     c->comm.reset();
     if (sc.use_count() > 1) return MOCAP_OK; // other contexts of this rank still use it
+    // the last user: destroyed here so that a failure can be reported (the destructor would do the same silently)
     (void)hipSetDevice(sc->device);
     if (sc->have_last) (void)hipEventSynchronize(sc->last);
     (void)hipEventDestroy(sc->last);
-    if (sc->comm && g_rccl.lib) RCCL_TRY(g_rccl.CommDestroy(sc->comm));
+    sc->last = nullptr;
+    void* comm = sc->comm;
     sc->comm = nullptr;
+    if (comm && g_rccl.lib) RCCL_TRY(g_rccl.CommDestroy(comm));
     return MOCAP_OK;
 }
 
@@ -1197,9 +1262,9 @@ int mocap_correspond(mocap_ctx_t c, const void* pts, long pt_st, long pt_sc, con
     if (T < 1 || C < 1 || C > 32 || P < 1 || P > 255 || max_groups < 1) return fail(MOCAP_E_INVALID, "T=%d C=%d P=%d max_groups=%d", T, C, P, max_groups);
     if (c->n_cam < C) return fail(MOCAP_E_STATE, "mocap_set_cameras: %d cameras set, %d needed", c->n_cam, C);
     if (c->n_F < C - 1) return fail(MOCAP_E_STATE, "mocap_set_fundamentals: %d matrices set, %d needed", c->n_F, C - 1);
-    if (correspond_smem_bytes(P, C) + 16 > 64 * 1024) // + the kernel's two static words
-        return fail(MOCAP_E_UNSUPPORTED, "P=%d points x C=%d cameras needs %zu bytes of LDS (> 64 KiB)", P, C, correspond_smem_bytes(P, C));
     if (set_device(c)) return MOCAP_E_HIP;
+    if (!correspond_fits(P, C)) // the plan is adaptive (geom.hip: corr_lds_plan); what is left are the candidate lists, P * C * 16 bytes
+        return fail(MOCAP_E_UNSUPPORTED, "P=%d points x C=%d cameras needs %zu bytes of LDS per time step", P, C, correspond_smem_bytes(P, C));
     // error scratch: the groups of one time step lie back to back, so a step needs room for its total, not P x max_groups;
     // a step with more than max(2 * max_groups, 8192) groups in all reports MOCAP_CORR_E_GROUPS
     size_t budget = 2 * (size_t)max_groups > 8192 ? 2 * (size_t)max_groups : 8192;

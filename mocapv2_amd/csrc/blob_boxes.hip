@@ -275,7 +275,16 @@ __global__ __launch_bounds__(256) void settle_tiles_kernel(BoxArgs a)
 // Global memory latency is taken out of the item loop: the next item's header and the box of source pixels it will read
 // are fetched while the current item is filtered, all staging loads of an item are in flight together, and the table
 // words of the next group of trips are requested before the current group is blended.
-constexpr int BOX_GROUP = 6; // trips whose table / frame loads are issued together
+#ifndef MOCAP_BOX_GROUP      // (build-time knobs for A/B builds: scratch/build_variant.sh)
+#define MOCAP_BOX_GROUP 6
+#endif
+#ifndef MOCAP_BOX_SU
+#define MOCAP_BOX_SU 14
+#endif
+#ifndef MOCAP_BOX_WAVES
+#define MOCAP_BOX_WAVES 2
+#endif
+constexpr int BOX_GROUP = MOCAP_BOX_GROUP; // trips whose table / frame loads are issued together
 
 struct BoxGeom { // derived from an item header, wave-uniform
     int image, tile, slot, remap;
@@ -326,7 +335,7 @@ __device__ __forceinline__ SrcBounds source_bounds_partial(const ushort4* __rest
 // difference decides whether a box wave finds room while another batch's scan is running (the cliff lies
 // between ~200 and ~240 registers).
 constexpr size_t BOX_LDS_BYTES = 1024 + (size_t)(BOX_HCAP + 64) * 8 + BOX_SCAP;
-__global__ __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(64) void box_filter_kernel(BoxArgs a)
+__global__ __attribute__((amdgpu_waves_per_eu(MOCAP_BOX_WAVES, MOCAP_BOX_WAVES))) __launch_bounds__(64) void box_filter_kernel(BoxArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t box_lds[];
     uint32_t* const lut = (uint32_t*)box_lds;
@@ -524,7 +533,7 @@ __global__ __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(64) void
                     if ((unsigned)(gx + k) < (unsigned)W) keep |= 0xffu << (8 * k);
                 if (sb >= 32 || sb < 0) keep = 0;
                 const uint32_t shs = (uint32_t)(sb < 0 || sb > 31 ? 0 : sb);
-                constexpr int SU = 14;
+                constexpr int SU = MOCAP_BOX_SU;
                 const int nround = (SR + rpi - 1) / rpi;
                 // the whole source rectangle inside the image (the usual case): no clamps, no masks
                 const bool interior = sya >= 0 && syb <= Hm1 && sxa >= 0 && sxa + SP <= W;

@@ -215,7 +215,7 @@ __device__ __forceinline__ uint4 load_once16(const uint8_t* p)
 // come in with one 16-byte load per image row (8 loads of 16 B instead of 16 of 8 B per thread).
 // FULL (H a multiple of 8, wide only): every cell has its 8 rows, no row clamping and no per-row validity test.
 // One block of 256 threads of the pass: block `bx` of image `image` (the kernel below deals these to the workgroups).
-template <bool WIDE, bool FULL>
+template <bool WIDE, bool FULL, bool MAP>
 __device__ __forceinline__ void bright_cells_block(const BrightArgs& a, const int bx, const int image)
 {
     const int ncx = (a.W + 7) >> 3, ncy = (a.H + 7) >> 3, n = ncx * ncy;
@@ -223,9 +223,11 @@ __device__ __forceinline__ void bright_cells_block(const BrightArgs& a, const in
     uint2 v[2][8];
     int ci[2], cr[2];
     uint32_t sh[2];
+    bool in_range[2];
     if (WIDE) {
         const int half = ncx >> 1, np = half * ncy; // cell pairs (ncx is even)
         int p = bx * 256 + threadIdx.x;
+        in_range[0] = in_range[1] = p < np;
         p = p < np ? p : np - 1; // threads past the end recount the last pair (and mark the same tiles again)
         const int row = (int)__umulhi((uint32_t)p, a.ncx_magic), cxp = p - row * half; // ncx_magic: for ncx / 2 here
         cr[0] = cr[1] = row;
@@ -252,6 +254,7 @@ __device__ __forceinline__ void bright_cells_block(const BrightArgs& a, const in
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             int i = i0 + 256 * u;
+            in_range[u] = i < n;
             i = i < n ? i : n - 1; // threads past the end recount the last cell (and mark the same tiles again)
             ci[u] = i;
             cr[u] = a.ncx_magic ? (int)__umulhi((uint32_t)i, a.ncx_magic) : i / ncx; // floor(i / ncx) without the division
@@ -271,6 +274,7 @@ __device__ __forceinline__ void bright_cells_block(const BrightArgs& a, const in
     const uint8_t* __restrict__ cflags = a.cflags + (size_t)slot * n;
     uint32_t* __restrict__ rows = a.tile_rows + (size_t)image * a.n_chunks * a.n_strips * 4;
     const uint32_t base4 = (uint32_t)a.base * 0x01010101u, c8 = 8u * (uint32_t)a.base;
+    uint32_t level[2] = {0u, 0u};
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         uint32_t acc = 0;
@@ -285,7 +289,8 @@ __device__ __forceinline__ void bright_cells_block(const BrightArgs& a, const in
                 if (8 * cr[u] + j < a.H) acc += e2;
             }
         }
-        mark_hot_cell(a, reach, cflags, rows, ci[u], acc);
+        if (MAP) level[u] = in_range[u] ? hot_level(a, acc) : 0u;
+        else mark_hot_cell(a, reach, cflags, rows, ci[u], acc);
         if (a.probe && (image & 15) == 0) { // wave-uniform, rare: which base would leave fewer hot cells?
             const uint32_t alt4 = (uint32_t)a.base_alt * 0x01010101u, alt8 = 8u * (uint32_t)a.base_alt;
             uint32_t acc2 = 0;
@@ -302,13 +307,123 @@ __device__ __forceinline__ void bright_cells_block(const BrightArgs& a, const in
             }
         }
     }
+    if (MAP) {
+        // The hot map: two bits per cell in cell order, so the 128 cells of a wave are 8 whole words (WIDE: consecutive lanes hold
+        // consecutive cell pairs) or two runs of 4 (lanes hold cells i and i + 256).  The lanes sharing a word OR their fields
+        // together with DPP moves and one of them stores it: every word of the map is written exactly once per pass -- no atomics,
+        // no clearing, and nothing the wave has to wait for behind its frame loads.
+        const int lane = threadIdx.x & 63;
+        uint32_t* __restrict__ hm = a.hotmap + (size_t)image * a.hot_words;
+        if (WIDE) {
+            uint32_t w = (level[0] | (level[1] << 2)) << (4 * (lane & 7));
+            w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1 /*quad_perm 1,0,3,2*/, 0xf, 0xf, true);
+            w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x4E /*quad_perm 2,3,0,1*/, 0xf, 0xf, true);
+            w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x141 /*row_half_mirror*/, 0xf, 0xf, true);
+            if ((lane & 7) == 0) hm[(bx * 256 + (int)threadIdx.x) >> 3] = w;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                uint32_t w = level[u] << (2 * (lane & 15));
+                w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xf, 0xf, true);
+                w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x4E, 0xf, 0xf, true);
+                w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x141, 0xf, 0xf, true);
+                w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x140 /*row_mirror*/, 0xf, 0xf, true);
+                if ((lane & 15) == 0) hm[(bx * 512 + (int)threadIdx.x + 256 * u) >> 4] = w;
+            }
+        }
+    }
+}
+
+// The hot map of the scan -> tile boxes.  One thread per map word (16 cells); a wave collects its hot cells in a list in LDS
+// and works through it one cell per lane: reach and flags of the cell (the tables of the image's undistort slot), the
+// threshold its flags ask for, and the boxes of the tiles it reaches -- what the scan used to do behind its own loads, where
+// every hot wave then sat through two dependent round trips with no frame loads in flight (0.946 ms for the benchmark batch
+// at 8 markers per frame, 1.133 at 32: most scan waves carry a hot cell then).
+// The hot cells of a marker lie in the same few waves and reach the same one or two tiles, and a memory atomic costs what
+// it costs whether it changes anything or not (the first version issued four per hot cell and tile: 4 M of them per batch
+// at 8 markers, 0.29 ms; 0.89 ms at 32): the wave first merges its cells' rectangles per tile in a 32-entry table in LDS (tag
+// = tile; a collision goes to memory directly) and then widens each tile it touched once.
+__global__ __launch_bounds__(256) void mark_tiles_kernel(BrightArgs a)
+{
+    __shared__ uint16_t s_list[4][1024];
+    __shared__ uint32_t s_tab[4][32][5]; // tile | first row | last row | first column | last column
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wb = (a.hot_words + 255) >> 8; // workgroups per image
+    const int image = blockIdx.x / wb, word0 = (blockIdx.x - image * wb) * 256 + wv * 64;
+    const int n_cells = ((a.W + 7) >> 3) * ((a.H + 7) >> 3);
+    const int wi = word0 + lane;
+    const uint32_t w = wi < a.hot_words ? a.hotmap[(size_t)image * a.hot_words + wi] : 0u;
+    const uint32_t nz = (w | (w >> 1)) & 0x55555555u; // bit 2j: cell j of the word exceeds at least the lowest threshold
+    const int cnt = __popc(nz);
+    if (__ballot(cnt != 0) == 0ull) return;
+    uint32_t (*tab)[5] = s_tab[wv];
+    if (lane < 32) { tab[lane][0] = 0xffffffffu; tab[lane][1] = 0xffffffffu; tab[lane][2] = 0u; tab[lane][3] = 0xffffffffu; tab[lane][4] = 0u; }
+    int incl = cnt; // inclusive prefix sum over the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    int at = incl - cnt;
+    for (uint32_t m = nz; m; m &= m - 1) {
+        const int j2 = __ffs((int)m) - 1; // = 2 j
+        s_list[wv][at++] = (uint16_t)((lane << 6) | (j2 << 1) | ((w >> j2) & 3u)); // lane | cell of the word | level
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): list and table are written (one wave: no barrier needed)
+    __builtin_amdgcn_wave_barrier();
+    const int slot = image % a.cam_mod;
+    const uint2* __restrict__ reach = a.reach + (size_t)slot * n_cells;
+    const uint8_t* __restrict__ cflags = a.cflags + (size_t)slot * n_cells;
+    uint32_t* __restrict__ rows = a.tile_rows + (size_t)image * a.n_chunks * a.n_strips * 4;
+    // widen one tile's box in memory (a box that already holds the rectangle needs no atomics)
+    auto widen = [&](int t, uint32_t ya, uint32_t yb, uint32_t xa, uint32_t xb) __attribute__((always_inline)) {
+        const uint4 cur = *(const uint4*)(rows + 4 * t);
+        if (cur.x <= ya && cur.y >= yb && cur.z <= xa && cur.w >= xb) return;
+        atomicMin(&rows[4 * t], ya);
+        atomicMax(&rows[4 * t + 1], yb);
+        atomicMin(&rows[4 * t + 2], xa);
+        atomicMax(&rows[4 * t + 3], xb);
+    };
+    for (int e0 = 0; e0 < total; e0 += 64) {
+        const int e = e0 + lane;
+        if (e < total) {
+            const uint32_t v = s_list[wv][e];
+            const int ci = 16 * (word0 + (int)(v >> 6)) + (int)((v >> 2) & 15u);
+            if (ci < n_cells) {
+                const uint2 rc = reach[ci];
+                const int x0 = (int)(rc.x & 0xffffu), x1 = (int)(rc.x >> 16), y0 = (int)(rc.y & 0xffffu), y1 = (int)(rc.y >> 16);
+                if (x0 <= x1 && level_is_hot(v & 3u, cflags[ci])) {
+                    // (the rectangle and the tiles it overlaps: as widen_tile_boxes, scan_mark.h)
+                    const int xa = x0 - 4 > 0 ? x0 - 4 : 0, xb = x1 + 4 < a.W - 1 ? x1 + 4 : a.W - 1;
+                    const int ya = y0 - 4 > 0 ? y0 - 4 : 0, yb = y1 + 4 < a.H - 1 ? y1 + 4 : a.H - 1;
+                    const int ch0 = (int)(((uint32_t)ya * a.rows_magic) >> 23), ch1 = (int)(((uint32_t)yb * a.rows_magic) >> 23);
+                    const int st0 = (int)(((uint32_t)xa * 34953u) >> 23), st1 = (int)(((uint32_t)xb * 34953u) >> 23);
+                    for (int ch = ch0; ch <= ch1; ch++)
+                        for (int st = st0; st <= st1; st++) {
+                            const int t = ch * a.n_strips + st, k = t & 31;
+                            const uint32_t old = atomicCAS(&tab[k][0], 0xffffffffu, (uint32_t)t);
+                            if (old == 0xffffffffu || old == (uint32_t)t) {
+                                atomicMin(&tab[k][1], (uint32_t)ya); atomicMax(&tab[k][2], (uint32_t)yb);
+                                atomicMin(&tab[k][3], (uint32_t)xa); atomicMax(&tab[k][4], (uint32_t)xb);
+                            } else
+                                widen(t, (uint32_t)ya, (uint32_t)yb, (uint32_t)xa, (uint32_t)xb);
+                        }
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 32 && tab[lane][0] != 0xffffffffu) widen((int)tab[lane][0], tab[lane][1], tab[lane][2], tab[lane][3], tab[lane][4]);
 }
 
 // The grid is one-dimensional: workgroup b takes the blocks b, b + gridDim.x, ... of the batch's blocks_x * n_images blocks
 // (block -> image = block / blocks_x).  Launched with as many workgroups as blocks it is the plain form (every workgroup one
 // block); launched with a fixed number per CU it is a persistent pass that never holds more than that many wave slots and
 // registers of a SIMD, whatever the batch size (BrightArgs::blocks_x, launch_bright_cells).
-template <bool WIDE, bool FULL = false>
+// MAP: the hot cells go into the hot map (BrightArgs::hotmap) instead of marking their tiles from here.
+template <bool WIDE, bool FULL = false, bool MAP = true>
 __global__ __launch_bounds__(256) void bright_cells_kernel(BrightArgs a)
 {
     if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
@@ -318,7 +433,7 @@ __global__ __launch_bounds__(256) void bright_cells_kernel(BrightArgs a)
     if (a.block_ctr == nullptr) {
         for (uint32_t vb = blockIdx.x; vb < total; vb += gridDim.x) {
             const uint32_t image = vb / (uint32_t)a.blocks_x;
-            bright_cells_block<WIDE, FULL>(a, (int)(vb - image * (uint32_t)a.blocks_x), a.image0 + (int)image);
+            bright_cells_block<WIDE, FULL, MAP>(a, (int)(vb - image * (uint32_t)a.blocks_x), a.image0 + (int)image);
         }
     } else {
         // persistent form: the workgroups take the blocks in the order of a shared counter, as the hardware dispatcher would hand
@@ -331,7 +446,7 @@ __global__ __launch_bounds__(256) void bright_cells_kernel(BrightArgs a)
             if (threadIdx.x == 0) s_next[it & 1] = gridDim.x * CH + atomicAdd(a.block_ctr, CH);
             for (uint32_t vb = v0; vb < v0 + CH && vb < total; vb++) {
                 const uint32_t image = vb / (uint32_t)a.blocks_x;
-                bright_cells_block<WIDE, FULL>(a, (int)(vb - image * (uint32_t)a.blocks_x), a.image0 + (int)image);
+                bright_cells_block<WIDE, FULL, MAP>(a, (int)(vb - image * (uint32_t)a.blocks_x), a.image0 + (int)image);
             }
             __syncthreads();
             v0 = s_next[it & 1];
@@ -639,6 +754,409 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
     } // strips / list entries
 }
 
+// ---- the row pipeline on the compact table, its source pixels staged in LDS -------------------------------------------
+// filter_mask_kernel<REMAP, PIPE> above reads 8 bytes of table per pixel and gathers every tap pair from memory (ten vector
+// memory instructions per 256-pixel row, eight of them 2-byte gathers): 10.6 ms per 3072 1080p images as the dense path, and
+// per row just as much for the wide tiles of the sparse path.  This form reads the box kernel's 4-byte table (one 16-byte load
+// per lane and row) and takes the taps from LDS: the rows of the strip are worked through in bands of up to 8; the
+// rectangle of source pixels a band reads is known from a per-(row, strip) table made at set-up (rowbox), it is staged with
+// coalesced dword loads, zeros outside the image (cv::remap's BORDER_CONSTANT), while the previous band is being filtered.
+// Everything behind the remapped row -- horizontal sums, running vertical sums, threshold, window counts, majority -- is the
+// same arithmetic as above.  Requires W % 4 == 0, H >= 2, every slot's table in the compact format.
+constexpr int ROWS_STAGE_DW = 2304;              // dwords of source pixels per wave and band (9 KB; 61 KB of LDS per workgroup in all)
+constexpr int ROWS_LOADS = ROWS_STAGE_DW / 64;   // staging loads per lane at most
+constexpr int ROWS_LOADS_SHORT = 16;             // ... of a band whose rectangle is small (the usual one away from the corners)
+
+// per (row, strip): box of the tap coordinates the row's pixels of the strip (columns 240 strip - 8 .. + 255) read, + 2
+__global__ void rowbox_kernel(const uint32_t* __restrict__ map4, ushort4* __restrict__ rowbox, int H, int W, int n_strips)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= H * n_strips) return;
+    const int row = i / n_strips, strip = i - row * n_strips;
+    const int xa = strip * 240 - 8 > 0 ? strip * 240 - 8 : 0, xb = strip * 240 + 247 < W - 1 ? strip * 240 + 247 : W - 1;
+    int x0 = 0x7fff, x1 = -0x8000, y0 = 0x7fff, y1 = -0x8000;
+    for (int x = xa; x <= xb; x++) {
+        const uint32_t w = map4[(size_t)row * W + x];
+        const int sx = x + ((int)(w << 21) >> 21), sy = row + ((int)(w << 10) >> 21);
+        x0 = sx < x0 ? sx : x0; x1 = sx + 1 > x1 ? sx + 1 : x1; y0 = sy < y0 ? sy : y0; y1 = sy + 1 > y1 ? sy + 1 : y1;
+    }
+    rowbox[i] = make_ushort4((unsigned short)(x0 + 2), (unsigned short)(x1 + 2), (unsigned short)(y0 + 2), (unsigned short)(y1 + 2));
+}
+void launch_rowbox(const uint32_t* map4, ushort4* rowbox, int H, int W, int n_strips, hipStream_t s)
+{
+    const int n = H * n_strips;
+    hipLaunchKernelGGL(rowbox_kernel, dim3((n + 63) / 64), dim3(64), 0, s, map4, rowbox, H, W, n_strips);
+}
+
+struct BandRect { int sxa, sya, SP, SR, dpr, n; bool staged, interior; }; // source rectangle of a band: origin, pitch (bytes), rows, dwords per row, dwords
+
+template <bool LIST>
+__global__ __launch_bounds__(256) void filter_rows_staged_kernel(FilterArgs a)
+{
+    __shared__ uint32_t lut[256];
+    __shared__ uint2 hring[4][8][64];
+    __shared__ uint32_t cring[4][8][64];
+    __shared__ uint32_t sbuf[4][ROWS_STAGE_DW];
+
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform: keeps the row loop scalar
+
+    int slot = 0, image = 0, chunk = 0;
+    uint32_t n_list = 0;
+    if (LIST) {
+        n_list = *a.n_tiles;
+        n_list = n_list < a.cap_tiles ? n_list : a.cap_tiles;
+        if ((uint32_t)(blockIdx.x * 4 + wv) >= n_list) return;
+    } else {
+        const TileId tid_ = decode_tile(a, blockIdx.x);
+        if (!tid_.valid) return;
+        slot = tid_.slot; image = tid_.image;
+        chunk = tid_.cgroup * 4 + wv;
+        if (chunk * a.rows_per_chunk >= a.H) return;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) { // lut[w]: byte k = number of set bits among bits k..k+4 of the 8-bit window w (every wave writes all of it)
+        uint32_t i = (uint32_t)(lane + 64 * e), v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) v |= (uint32_t)__popc((i >> k) & 0x1fu) << (8 * k);
+        lut[i] = v;
+    }
+    uint32_t* const Sb = sbuf[wv];
+    const uint8_t* const Sbytes = (const uint8_t*)Sb;
+    // kernel arguments as plain scalars (a struct captured by the lambdas below would be kept in scratch memory)
+    const int H = a.H, W = a.W, Hm1 = a.H - 1, pitch = a.pitch, stage_dw = a.stage_dw, n_strips = a.n_strips, thr_mul = a.thr_mul;
+    const int rows_per_chunk = a.rows_per_chunk, n_cgroups = a.n_cgroups, cam_mod = a.cam_mod, words_per_row = a.words_per_row;
+    const uint8_t* __restrict__ const a_src = a.src; const size_t a_image_stride = a.image_stride;
+    const uint32_t* __restrict__ const a_map4 = a.map4; const ushort4* __restrict__ const a_rowbox = a.rowbox;
+    uint32_t* __restrict__ const a_mask = a.mask; uint32_t* __restrict__ const a_cells = a.cells; const uint4* __restrict__ const a_tiles = a.tiles;
+    const uint32_t it_first = LIST ? (uint32_t)(blockIdx.x * 4 + wv) : 0u, it_end = LIST ? n_list : (uint32_t)n_strips;
+    const uint32_t it_step = LIST ? gridDim.x * 4u : 1u;
+    for (uint32_t it = it_first; it < it_end; it += it_step) {
+        int strip = (int)it, r0e = 0, r1e = 0x7fffffff;
+        if (LIST) {
+            const uint4 e = a_tiles[it];
+            image = __builtin_amdgcn_readfirstlane((int)e.x);
+            const int tile = __builtin_amdgcn_readfirstlane((int)e.y);
+            r0e = __builtin_amdgcn_readfirstlane((int)e.z); r1e = __builtin_amdgcn_readfirstlane((int)e.w) + 1;
+            chunk = tile / n_strips; strip = tile - chunk * n_strips;
+            slot = image % cam_mod;
+        }
+        const int tile_r0 = chunk * rows_per_chunk;              // the tile's mask rows [tile_r0, tile_r1)
+        const int tile_r1 = tile_r0 + rows_per_chunk < H ? tile_r0 + rows_per_chunk : H;
+        const size_t cell_index = ((size_t)image * n_cgroups * 4 + chunk) * n_strips + strip;
+        const int r0 = r0e > tile_r0 ? r0e : tile_r0, r1 = r1e < tile_r1 ? r1e : tile_r1; // the rows filtered
+        if (LIST && r0 >= r1) continue; // an empty band
+        const int xbase = strip * 240 - 8;
+
+        int kfirst = r0 - 2;
+        kfirst = kfirst < 0 ? 0 : (kfirst > Hm1 ? Hm1 : kfirst);
+        const int ks = r0 - 1 > 1 ? r0 - 1 : 1;                 // steady range: every iteration slides one source row
+        const int ke = r1 + 1 < Hm1 ? r1 + 1 : Hm1;
+
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            hring[wv][s][lane] = make_uint2(0u, 0u);
+            cring[wv][s][lane] = 0u;
+        }
+        const uint8_t* __restrict__ img = a_src + (size_t)image * a_image_stride;
+        const uint32_t* __restrict__ map4 = a_map4 + (size_t)slot * H * W;
+        const ushort4* __restrict__ rbox = a_rowbox + (size_t)slot * H * n_strips + strip; // row r: rbox[r * n_strips]
+        uint8_t* __restrict__ mrow_base = (uint8_t*)(a_mask + (size_t)image * H * words_per_row);
+        const int row_bytes = words_per_row * 4;
+        const int xl = xbase + 4 * lane;
+        uint32_t cx01, cx23, colmask = 0;
+        {
+            int c0 = taps5(xl, W), c1 = taps5(xl + 1, W), c2 = taps5(xl + 2, W), c3 = taps5(xl + 3, W);
+            cx01 = (uint32_t)(c0 & 0xffff) | ((uint32_t)c1 << 16);
+            cx23 = (uint32_t)(c2 & 0xffff) | ((uint32_t)c3 << 16);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if ((unsigned)(xl + k) < (unsigned)W) colmask |= 1u << k;
+        }
+        const LaneCols lc = lane_cols(xl, W);
+        const bool left_edge = xbase < 0;
+        const bool right_edge = xbase + 255 >= W;
+        const int lane_r = (W - 1 - xbase) >> 2, bit_r = (W - 1 - xbase) & 3; // lane / bit of column W-1
+        const int out_byte = strip * 30 + ((lane - 2) >> 1);
+        const bool stores = ((lane & 1) == 0) && lane >= 2 && lane <= 60 && out_byte < ((W + 7) >> 3) && out_byte < row_bytes;
+        uint32_t V01 = 0, V23 = 0, Cv = 0;
+        uint32_t lacc = 0;
+        const bool out_lane = lane >= 2 && lane <= 61;
+        const int y0 = kfirst - 2;
+
+        // ---- bands: rectangle, staging, table words ----------------------------------------------------------------------
+        // a lane's share of the rows' boxes (lanes 0..nr-1 hold one row each); reduced when the band is about to be staged
+        auto rect_load = [&](int rb, int nr) __attribute__((always_inline)) -> ushort4 {
+            int r = rb + (lane < nr ? lane : 0);
+            r = r < 0 ? 0 : (r > Hm1 ? Hm1 : r);
+            return rbox[(size_t)r * n_strips];
+        };
+        auto rect_reduce = [&](ushort4 p) __attribute__((always_inline)) -> BandRect {
+            int xa = p.x, xb = p.y, ya = p.z, yb = p.w; // lanes beyond the band's rows hold a copy of its first row
+#pragma unroll
+            for (int d = 1; d <= 4; d <<= 1) {
+                const int oxa = __shfl_xor(xa, d), oxb = __shfl_xor(xb, d), oya = __shfl_xor(ya, d), oyb = __shfl_xor(yb, d);
+                xa = oxa < xa ? oxa : xa; xb = oxb > xb ? oxb : xb; ya = oya < ya ? oya : ya; yb = oyb > yb ? oyb : yb;
+            }
+            BandRect R;
+            R.sxa = (__builtin_amdgcn_readfirstlane(xa) - 2) & ~3;
+            const int sxb = __builtin_amdgcn_readfirstlane(xb) - 2;
+            R.sya = __builtin_amdgcn_readfirstlane(ya) - 2;
+            const int syb = __builtin_amdgcn_readfirstlane(yb) - 2;
+            R.SP = (sxb - R.sxa + 4) & ~3; R.SR = syb - R.sya + 1; R.dpr = R.SP >> 2; R.n = R.SR * R.dpr;
+            R.staged = R.n <= stage_dw;
+            R.interior = R.sxa >= 0 && R.sya >= 0 && R.sxa + R.SP <= W && R.sya + R.SR <= H; // no dword of it outside the image
+            return R;
+        };
+        // the staging loads of a band, all in flight: lane -> dwords lane, lane + 64, ... of the rectangle (row-major), which is
+        // also where they go in LDS (the buffer holds 64 dwords per load, so every lane stores every load: no tests).  W % 4 == 0
+        // and an origin that is a multiple of 4 make every dword lie entirely inside or entirely outside the image.
+        // Interior rectangle (the usual case): the address walks on by a wave-uniform step with a carry into the next row --
+        // no division, no clamps; dwords past the rectangle re-read its last dword.
+        auto stage_issue = [&](const BandRect& R, auto& v, auto first_c) __attribute__((always_inline)) { // loads first .. first + size of v
+            constexpr int U0 = decltype(first_c)::value, NL = (int)(sizeof(v) / sizeof(v[0]));
+            const float rcpd = __builtin_amdgcn_rcpf((float)R.dpr);
+            if (R.interior) {
+                const int qr = (int)(64.5f * rcpd), rem = 64 - qr * R.dpr;      // 64 = qr * dpr + rem
+                int idx = lane + 64 * U0;
+                idx = idx < R.n ? idx : R.n - 1;
+                const int r0_ = (int)(((float)idx + 0.5f) * rcpd);
+                int c = idx - r0_ * R.dpr;
+                uint32_t goff = (uint32_t)(R.sya + r0_) * (uint32_t)pitch + (uint32_t)(R.sxa + 4 * c);
+                const uint32_t glast = (uint32_t)(R.sya + R.SR - 1) * (uint32_t)pitch + (uint32_t)(R.sxa + R.SP - 4);
+                const uint32_t step = (uint32_t)qr * (uint32_t)pitch + 4u * (uint32_t)rem, carry = (uint32_t)pitch - (uint32_t)R.SP;
+#pragma unroll
+                for (int u = 0; u < NL; u++) {
+                    __builtin_memcpy(&v[u], img + goff, 4);
+                    c += rem;
+                    goff += step;
+                    if (c >= R.dpr) { c -= R.dpr; goff += carry; }
+                    goff = goff < glast ? goff : glast;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < NL; u++) {
+                    int idx = lane + 64 * (U0 + u);
+                    idx = idx < R.n ? idx : R.n - 1;
+                    const int r = (int)(((float)idx + 0.5f) * rcpd), c = idx - r * R.dpr;
+                    const int gy = R.sya + r, gx = R.sxa + 4 * c;
+                    const int gyc = gy < 0 ? 0 : (gy > Hm1 ? Hm1 : gy), gxc = gx < 0 ? 0 : (gx > W - 4 ? W - 4 : gx);
+                    __builtin_memcpy(&v[u], img + ((uint32_t)gyc * (uint32_t)pitch + (uint32_t)gxc), 4);
+                }
+            }
+        };
+        auto stage_write = [&](const BandRect& R, const auto& v, auto first_c) __attribute__((always_inline)) {
+            constexpr int U0 = decltype(first_c)::value, NL = (int)(sizeof(v) / sizeof(v[0]));
+            if (R.interior) {
+#pragma unroll
+                for (int u = 0; u < NL; u++) Sb[lane + 64 * (U0 + u)] = v[u];
+            } else {
+                const float rcpd = __builtin_amdgcn_rcpf((float)R.dpr);
+#pragma unroll
+                for (int u = 0; u < NL; u++) {
+                    const int idx = lane + 64 * (U0 + u);
+                    const int ic = idx < R.n ? idx : R.n - 1;
+                    const int r = (int)(((float)ic + 0.5f) * rcpd), c = ic - r * R.dpr;
+                    const int gy = R.sya + r, gx = R.sxa + 4 * c;
+                    const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                    Sb[idx] = inside ? v[u] : 0u;
+                }
+            }
+        };
+        auto table_issue = [&](uint4& tw, int row) __attribute__((always_inline)) {
+            const int rc = row < 0 ? 0 : (row > Hm1 ? Hm1 : row);
+            __builtin_memcpy(&tw, map4 + ((uint32_t)rc * (uint32_t)W + (uint32_t)lc.addr_x), 16);
+        };
+        // one remapped row of the strip: the lane's four pixels, blended exactly as cv::remap's fixed point does
+        auto blend_row = [&](const uint4& tw, int row, const BandRect& R) __attribute__((always_inline)) -> uint32_t {
+            const int rc = row < 0 ? 0 : (row > Hm1 ? Hm1 : row);
+            const uint32_t ww[4] = {tw.x, tw.y, tw.z, tw.w};
+            uint32_t B = 0;
+            if (R.staged) {
+                const int rowbase = __mul24(rc - R.sya, R.SP) + (lc.addr_x - R.sxa);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t w = ww[k];
+                    const int dx = (int)(w << 21) >> 21, dy = (int)(w << 10) >> 21;
+                    const uint32_t fa = (w >> 22) & 31u, fb = w >> 27;
+                    const int A0 = __mul24(dy, R.SP) + (rowbase + k) + dx;
+                    const uint32_t p00 = Sbytes[A0], p01 = Sbytes[A0 + 1], p10 = Sbytes[A0 + R.SP], p11 = Sbytes[A0 + R.SP + 1];
+                    const uint32_t wa = 32u - fa, wb = 32u - fb;
+                    const uint32_t top = __umul24(p00, wa) + __umul24(p01, fa), bot = __umul24(p10, wa) + __umul24(p11, fa);
+                    B |= ((__umul24(top, wb) + __umul24(bot, fb) + 512u) >> 10) << (8 * k); // == (sum of 32*w*p + 2^14) >> 15
+                }
+            } else { // the band's source rectangle outgrew the buffer (strong local distortion): taps from memory
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t w = ww[k];
+                    const int dx = (int)(w << 21) >> 21, dy = (int)(w << 10) >> 21;
+                    const uint32_t fa = (w >> 22) & 31u, fb = w >> 27;
+                    const int sx = lc.addr_x + k + dx, sy = rc + dy;
+                    const int sx0 = sx < 0 ? 0 : (sx > W - 1 ? W - 1 : sx), sx1 = sx + 1 < 0 ? 0 : (sx + 1 > W - 1 ? W - 1 : sx + 1);
+                    const int sy0 = sy < 0 ? 0 : (sy > Hm1 ? Hm1 : sy), sy1 = sy + 1 < 0 ? 0 : (sy + 1 > Hm1 ? Hm1 : sy + 1);
+                    const uint32_t o0 = (uint32_t)sy0 * (uint32_t)pitch, o1 = (uint32_t)sy1 * (uint32_t)pitch;
+                    const uint32_t t00 = img[o0 + (uint32_t)sx0], t01 = img[o0 + (uint32_t)sx1], t10 = img[o1 + (uint32_t)sx0], t11 = img[o1 + (uint32_t)sx1];
+                    const bool c0 = sx0 == sx, c1 = sx1 == sx + 1, q0 = sy0 == sy, q1 = sy1 == sy + 1;
+                    const uint32_t p00 = (c0 && q0) ? t00 : 0u, p01 = (c1 && q0) ? t01 : 0u, p10 = (c0 && q1) ? t10 : 0u, p11 = (c1 && q1) ? t11 : 0u;
+                    const uint32_t wa = 32u - fa, wb = 32u - fb;
+                    const uint32_t top = __umul24(p00, wa) + __umul24(p01, fa), bot = __umul24(p10, wa) + __umul24(p11, fa);
+                    B |= ((__umul24(top, wb) + __umul24(bot, fb) + 512u) >> 10) << (8 * k);
+                }
+            }
+            return (unsigned)row < (unsigned)H ? (B & lc.bytemask) : 0u; // rows and columns outside the image do not exist
+        };
+        // ---- the pipeline behind the remapped row: as in filter_mask_kernel ---------------------------------------------
+        auto hsum_update = [&](uint32_t B, int s_new, int s_old) __attribute__((always_inline)) {
+            uint32_t A = lane_from_prev(B), C = lane_from_next(B);
+            uint32_t sB = dot4(B, 0x01010101u, 0u);
+            uint32_t h0 = dot4(A, 0x01010000u, dot4(B, 0x00010101u, 0u));
+            uint32_t h1 = dot4(A, 0x01000000u, sB);
+            uint32_t h2 = dot4(C, 0x00000001u, sB);
+            uint32_t h3 = dot4(C, 0x00000101u, dot4(B, 0x01010100u, 0u));
+            uint32_t H01 = h0 | (h1 << 16), H23 = h2 | (h3 << 16);
+            uint2 old = hring[wv][s_old][lane];
+            hring[wv][s_new][lane] = make_uint2(H01, H23);
+            V01 += H01 - old.x; // 16-bit fields never borrow: the window sum always contains the row removed
+            V23 += H23 - old.y;
+        };
+        auto thresh_counts = [&](int kc) __attribute__((always_inline)) -> uint32_t {
+            uint32_t m = (uint32_t)(thr_mul * taps5(kc, H));
+            uint32_t T01 = __umul24(cx01, m), T23 = __umul24(cx23, m);
+            uint32_t d01 = (V01 | 0x80008000u) - T01, d23 = (V23 | 0x80008000u) - T23;
+            uint32_t t = (d01 >> 15) & 0x10001u, u = (d23 >> 15) & 0x10001u;
+            uint32_t w = t | (u << 2);
+            uint32_t nib = (w | (w >> 15)) & 0xfu;
+            if (left_edge) { // medianBlur replicates the border: columns outside the image take the edge column's bit
+                uint32_t e = __builtin_amdgcn_readlane(nib, 2) & 1u;
+                if (xl < 0) nib = e ? 0xfu : 0u;
+            }
+            if (right_edge) {
+                uint32_t e = (__builtin_amdgcn_readlane(nib, lane_r) >> bit_r) & 1u;
+                uint32_t keep = (2u << bit_r) - 1u;
+                if (lane > lane_r) nib = e ? 0xfu : 0u;
+                else if (lane == lane_r) nib = (nib & keep) | (e ? (0xfu & ~keep) : 0u);
+            }
+            uint32_t nl = lane_from_prev(nib), nr = lane_from_next(nib);
+            uint32_t win = (nl >> 2) | (nib << 2) | ((nr & 3u) << 6);
+            return lut[win];
+        };
+        auto push_counts = [&](uint32_t c, int s_new, int s_old) __attribute__((always_inline)) {
+            uint32_t cold = cring[wv][s_old][lane];
+            cring[wv][s_new][lane] = c;
+            Cv += c - cold;
+        };
+        auto emit = [&](int row, bool on) __attribute__((always_inline)) {
+            uint32_t mm = ((Cv + 0x73737373u) >> 7) & 0x01010101u;
+            uint32_t t1 = mm | (mm >> 7);
+            uint32_t mn = (t1 | (t1 >> 14)) & colmask;
+            lacc |= (mn != 0u ? 1u : 0u) << (((on ? row : r0) - tile_r0) >> 3);
+            uint32_t odd = lane_from_next(mn);
+            uint32_t byte = (mn & 0xfu) | ((odd & 0xfu) << 4);
+            if (stores && on) mrow_base[(size_t)row * row_bytes + out_byte] = (uint8_t)byte;
+        };
+
+        // ---- band 0: the five rows y0 .. y0 + 4 of the set-up (ring slots 3 .. 7) ------------------------------------------
+        uint4 tc[8], tn[8];  // table words of the band being filtered / of the next one
+        // staging loads in flight: the first ROWS_LOADS_SHORT of every band, the rest only for a large rectangle (two arrays: one
+        // array written in full on one path and in part on the other stays in scratch memory)
+        uint32_t sv[ROWS_LOADS_SHORT], sw[ROWS_LOADS - ROWS_LOADS_SHORT];
+        BandRect Rc = rect_reduce(rect_load(y0, 5));
+        const bool short0 = Rc.n <= 64 * ROWS_LOADS_SHORT;
+        if (Rc.staged) { stage_issue(Rc, sv, IC<0>{}); if (!short0) stage_issue(Rc, sw, IC<ROWS_LOADS_SHORT>{}); }
+#pragma unroll
+        for (int j = 0; j < 5; j++) table_issue(tc[3 + j], y0 + j);
+        // band 1 = the first rows of the steady loop: y0 + 5 = ks + 2 onwards
+        int nr_next = ke - ks + 1 < 8 ? ke - ks + 1 : 8;
+        ushort4 part = rect_load(ks + 2, nr_next > 0 ? nr_next : 1);
+        if (Rc.staged) { stage_write(Rc, sv, IC<0>{}); if (!short0) stage_write(Rc, sw, IC<ROWS_LOADS_SHORT>{}); }
+        // the next band's loads are issued before the current one is filtered, and land in LDS after it
+        BandRect Rn = Rc;
+        bool short_n = true;
+        auto prefetch = [&](int first_row, int nr) __attribute__((always_inline)) { // rows first_row .. first_row + nr - 1 -> tn / sv
+            Rn = rect_reduce(part);
+            short_n = Rn.n <= 64 * ROWS_LOADS_SHORT;
+            if (Rn.staged) { stage_issue(Rn, sv, IC<0>{}); if (!short_n) stage_issue(Rn, sw, IC<ROWS_LOADS_SHORT>{}); }
+#pragma unroll
+            for (int j = 0; j < 8; j++) table_issue(tn[j], first_row + (j < nr ? j : nr - 1));
+        };
+        auto commit = [&]() __attribute__((always_inline)) { // the band just filtered has read its last tap: the next one moves in
+            if (Rn.staged) { stage_write(Rn, sv, IC<0>{}); if (!short_n) stage_write(Rn, sw, IC<ROWS_LOADS_SHORT>{}); }
+#pragma unroll
+            for (int j = 0; j < 8; j++) tc[j] = tn[j];
+            Rc = Rn;
+        };
+        if (nr_next > 0) {
+            prefetch(ks + 2, nr_next);
+            const int n2 = ke - (ks + 8) + 1 < 8 ? ke - (ks + 8) + 1 : 8;
+            part = rect_load(ks + 10, n2 > 0 ? n2 : 1); // (the band after that one: its box loads have a whole band's time)
+        }
+        hsum_update(blend_row(tc[3], y0, Rc), 3, 6);
+        hsum_update(blend_row(tc[4], y0 + 1, Rc), 4, 7);
+        hsum_update(blend_row(tc[5], y0 + 2, Rc), 5, 0);
+        hsum_update(blend_row(tc[6], y0 + 3, Rc), 6, 1);
+        hsum_update(blend_row(tc[7], y0 + 4, Rc), 7, 2);
+        uint32_t c_cur = thresh_counts(kfirst);
+        int cj = (r0 == 0) ? 5 : 7; // count-ring phase chosen so that the steady loop starts at slot 0
+        push_counts(c_cur, cj & 7, (cj + 3) & 7);
+        cj++;
+        for (int kk = r0 - 1; kk < ks; ++kk) { // rows above the image replicate row 0 (only the top chunk gets here)
+            push_counts(c_cur, cj & 7, (cj + 3) & 7);
+            cj++;
+            if (kk >= r0 + 2) emit(kk - 2, true);
+        }
+        // ---- steady state: bands of 8 rows; one source row in, one threshold row, one output row per step -------------------
+        auto step = [&](auto Jc, int k) __attribute__((always_inline)) {
+            constexpr int J = decltype(Jc)::value;
+            const uint32_t B = blend_row(tc[J], k + 2, Rc);
+            hsum_update(B, J, (J + 3) & 7);
+            c_cur = thresh_counts(k);
+            push_counts(c_cur, J, (J + 3) & 7);
+            emit(k - 2, k >= r0 + 2);
+        };
+        for (int k = ks; k <= ke; k += 8) {
+            if (nr_next > 0) commit(); // (the band of this iteration)
+            const int nst = ke - k + 1 < 8 ? ke - k + 1 : 8;
+            nr_next = ke - (k + 8) + 1 < 8 ? ke - (k + 8) + 1 : 8;
+            if (nr_next > 0) {
+                const int n2 = ke - (k + 16) + 1 < 8 ? ke - (k + 16) + 1 : 8;
+                const ushort4 part2 = rect_load(k + 18, n2 > 0 ? n2 : 1);
+                prefetch(k + 10, nr_next);
+                part = part2;
+            }
+            if (nst == 8) {
+                step(IC<0>{}, k); step(IC<1>{}, k + 1); step(IC<2>{}, k + 2); step(IC<3>{}, k + 3);
+                step(IC<4>{}, k + 4); step(IC<5>{}, k + 5); step(IC<6>{}, k + 6); step(IC<7>{}, k + 7);
+            } else {
+                step(IC<0>{}, k);
+                if (nst > 1) step(IC<1>{}, k + 1);
+                if (nst > 2) step(IC<2>{}, k + 2);
+                if (nst > 3) step(IC<3>{}, k + 3);
+                if (nst > 4) step(IC<4>{}, k + 4);
+                if (nst > 5) step(IC<5>{}, k + 5);
+                if (nst > 6) step(IC<6>{}, k + 6);
+            }
+        }
+        // ---- rows below the image replicate the last row (only the bottom chunk gets here) ----
+        {
+            int n_steady = ke >= ks ? ke - ks + 1 : 0;
+            cj = n_steady; // slot of the next push (the steady loop started at slot 0)
+            int kb = ke + 1 > ks ? ke + 1 : ks;
+            for (int kk = kb; kk <= r1 + 1; ++kk) {
+                push_counts(c_cur, cj & 7, (cj + 3) & 7);
+                cj++;
+                if (kk >= r0 + 2) emit(kk - 2, true);
+            }
+        }
+        {   // occupancy word of this (strip, chunk): OR of the output lanes' bits
+            uint32_t cellmask = 0;
+            const int groups = (tile_r1 - tile_r0 + 7) >> 3;
+            for (int g = 0; g < groups; g++)
+                if (__ballot(out_lane && ((lacc >> g) & 1u)) != 0ull) cellmask |= 1u << g;
+            if (lane == 0) { if (LIST) atomicOr(&a_cells[cell_index], cellmask | 0x80000000u); else a_cells[cell_index] = cellmask | 0x80000000u; }
+        }
+    } // strips / list entries
+}
+
 // ---- map construction: cv::initUndistortRectifyMap as called by cv::undistort (stripe by stripe) -------------
 // One thread per image row; the _x accumulation along the row is sequential exactly as in OpenCV.
 __global__ void undistort_map_kernel(MapArgs m)
@@ -858,9 +1376,15 @@ void launch_remap_stats(const StatArgs& a, hipStream_t s)
     hipLaunchKernelGGL(remap_stats_kernel, grid2d(a.W, a.H), dim3(64, 4), 0, s, a);
 }
 
+int rows_stage_dwords() { return ROWS_STAGE_DW; }
+
 void launch_filter_mask(const FilterArgs& a, bool remap, hipStream_t s)
 {
     const int blocks = a.cam_mod * a.n_cgroups * a.n_steps;
+    if (remap && a.staged) {
+        hipLaunchKernelGGL(filter_rows_staged_kernel<false>, dim3(blocks), dim3(256), 0, s, a);
+        return;
+    }
     if (remap && a.pipelined)
         hipLaunchKernelGGL((filter_mask_kernel<true, false, true, false>), dim3(blocks), dim3(256), 0, s, a);
     else if (remap)
@@ -874,6 +1398,10 @@ void launch_filter_mask(const FilterArgs& a, bool remap, hipStream_t s)
 // the same row pipeline over the list of wide tiles (a.tiles / a.n_tiles): a fixed grid, four entries per workgroup at a time
 void launch_filter_tiles(const FilterArgs& a, bool remap, int blocks, hipStream_t s)
 {
+    if (remap && a.staged) {
+        hipLaunchKernelGGL(filter_rows_staged_kernel<true>, dim3(blocks), dim3(256), 0, s, a);
+        return;
+    }
     if (remap && a.pipelined)
         hipLaunchKernelGGL((filter_mask_kernel<true, false, true, true>), dim3(blocks), dim3(256), 0, s, a);
     else if (remap)
@@ -905,10 +1433,27 @@ void launch_bright_cells(const BrightArgs& a_, hipStream_t s)
             a.block_ctr = ctr ? ctr + (i0 / per) : nullptr; // one counter per slice (zeroed by the caller)
         }
         if (grid > 0x7fffffffLL) grid = 0x7fffffffLL;
-        if (a.wide && a.H % 8 == 0) hipLaunchKernelGGL((bright_cells_kernel<true, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
-        else if (a.wide) hipLaunchKernelGGL(bright_cells_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(bright_cells_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, a);
+        const dim3 g((unsigned)grid), b(256);
+        if (a.hotmap) {
+            if (a.wide && a.H % 8 == 0) hipLaunchKernelGGL((bright_cells_kernel<true, true, true>), g, b, 0, s, a);
+            else if (a.wide) hipLaunchKernelGGL((bright_cells_kernel<true, false, true>), g, b, 0, s, a);
+            else hipLaunchKernelGGL((bright_cells_kernel<false, false, true>), g, b, 0, s, a);
+        } else {
+            if (a.wide && a.H % 8 == 0) hipLaunchKernelGGL((bright_cells_kernel<true, true, false>), g, b, 0, s, a);
+            else if (a.wide) hipLaunchKernelGGL((bright_cells_kernel<true, false, false>), g, b, 0, s, a);
+            else hipLaunchKernelGGL((bright_cells_kernel<false, false, false>), g, b, 0, s, a);
+        }
     }
+}
+int hot_map_words(int H, int W, int wide)
+{ // whole waves of the scan write the map: 32 words per block of 256 threads (128 cells per wave either way)
+    const int n = ((W + 7) >> 3) * ((H + 7) >> 3);
+    return 32 * (wide ? (n / 2 + 255) / 256 : (n + 511) / 512);
+}
+void launch_mark_tiles(const BrightArgs& a, hipStream_t s)
+{
+    const long long grid = (long long)((a.hot_words + 255) >> 8) * a.n_images;
+    hipLaunchKernelGGL(mark_tiles_kernel, dim3((unsigned)grid), dim3(256), 0, s, a);
 }
 void launch_undistort_map(const MapArgs& m, hipStream_t s)
 {

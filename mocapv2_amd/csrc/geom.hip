@@ -20,7 +20,7 @@ namespace {
 
 constexpr int MAXM = 16; // candidate matches kept per (root, camera)
 
-__device__ double np_block_sum(const double* a, int n)
+__device__ __forceinline__ double np_block_sum(const double* a, int n)
 { // numpy pairwise_sum for n <= 128
     if (n < 8) {
         double r = 0.;
@@ -38,36 +38,81 @@ __device__ double np_block_sum(const double* a, int n)
     return res;
 }
 
-__device__ double np_pairwise_sum(const double* a, int n)
-{ // the recursion of numpy's pairwise_sum, unrolled onto an explicit stack
+// numpy's pairwise_sum for any n, without recursion and without a stack: the leaves (runs of <= 128 values) are visited
+// in order -- the leaf holding offset o is found by walking down from the root, which also yields the path (bit d set =
+// right child at depth d) --, and a finished subtree's sum is parked IN the array, at the subtree's first offset (those
+// values are consumed by then).  A node's left child starts at the node's own offset, so "left + right" of a node whose
+// right child has just been finished reads a[offset of the node].  The array is overwritten.  Same additions in the same
+// order as numpy's recursion: n2 = (n / 2) rounded down to a multiple of 8, left = [0, n2), right = [n2, n).
+__device__ double np_pairwise_sum(double* a, int n)
+{
     if (n <= 128) return np_block_sum(a, n);
-    int off[32], len[32], stage[32];
-    double left[32];
-    int sp = 0;
+    int o = 0;
     double ret = 0.;
-    off[0] = 0; len[0] = n; stage[0] = 0; sp = 1;
-    while (sp > 0) {
-        int t = sp - 1;
-        if (stage[t] == 0) {
-            if (len[t] <= 128) { ret = np_block_sum(a + off[t], len[t]); sp--; continue; }
-            int n2 = len[t] / 2; n2 -= n2 % 8;
-            stage[t] = 1;
-            off[sp] = off[t]; len[sp] = n2; stage[sp] = 0; sp++;
-        } else if (stage[t] == 1) {
-            int n2 = len[t] / 2; n2 -= n2 % 8;
-            left[t] = ret;
-            stage[t] = 2;
-            off[sp] = off[t] + n2; len[sp] = len[t] - n2; stage[sp] = 0; sp++;
-        } else {
-            ret = left[t] + ret;
-            sp--;
+    while (o < n) {
+        int off = 0, len = n, depth = 0;
+        uint32_t path = 0;
+        while (len > 128) {
+            int n2 = len / 2; n2 -= n2 % 8;
+            if (o < off + n2) len = n2;
+            else { off += n2; len -= n2; path |= 1u << depth; }
+            depth++;
+        }
+        ret = np_block_sum(a + off, len);
+        o = off + len;
+        // every ancestor this leaf completes as the last leaf of its right subtree: deepest first
+        while (depth > 0 && ((path >> (depth - 1)) & 1u)) {
+            depth--;
+            int poff = 0, plen = n; // the ancestor at `depth`: walk down the same path
+            for (int d = 0; d < depth; d++) {
+                int n2 = plen / 2; n2 -= n2 % 8;
+                if ((path >> d) & 1u) { poff += n2; plen -= n2; } else plen = n2;
+            }
+            ret = a[poff] + ret;
+        }
+        if (depth > 0) { // a left child is complete: park its sum where its parent will look for it
+            int poff = 0, plen = n;
+            for (int d = 0; d < depth - 1; d++) {
+                int n2 = plen / 2; n2 -= n2 % 8;
+                if ((path >> d) & 1u) { poff += n2; plen -= n2; } else plen = n2;
+            }
+            a[poff] = ret;
         }
     }
     return ret;
 }
 
+// numpy's pairwise_sum of n <= 128 values that arrive two at a time, in order, without keeping them (np_block_sum above on
+// the fly; n even).  The values are squares (>= +0), so starting the eight partial sums at +0 instead of a[0..7] adds nothing.
+struct NpPairStream {
+    double r0, r1, r2, r3, r4, r5, r6, r7, res;
+    int nfull, i;
+    __device__ __forceinline__ void begin(int n)
+    {
+        nfull = n < 8 ? 0 : n - (n % 8);
+        i = 0;
+        r0 = r1 = r2 = r3 = r4 = r5 = r6 = r7 = 0.; res = 0.;
+    }
+    __device__ __forceinline__ void push2(double a, double b)
+    {
+        if (i < nfull) {
+            // value i goes to partial sum i % 8.  The eight sums are rotated by two after every pair instead of being selected by
+            // index (a register cannot be indexed; the compiler would move them to scratch memory): the next pair again lands in
+            // r0 / r1, and after nfull values -- a multiple of 8 -- every sum is back in its own place
+            r0 += a; r1 += b;
+            const double t0 = r0, t1 = r1;
+            r0 = r2; r1 = r3; r2 = r4; r3 = r5; r4 = r6; r5 = r7; r6 = t0; r7 = t1;
+            i += 2;
+            if (i == nfull) res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+        } else {
+            res += a; res += b;
+            i += 2;
+        }
+    }
+};
+
 // cv.computeCorrespondEpilines for one float32 point
-__device__ void epiline(const double* F, float xf, float yf, float line[3])
+__device__ __forceinline__ void epiline(const double* F, float xf, float yf, float line[3])
 {
     double x = xf, y = yf;
     double a = F[0] * x + F[1] * y + F[2];
@@ -79,14 +124,14 @@ __device__ void epiline(const double* F, float xf, float yf, float line[3])
     line[0] = (float)a; line[1] = (float)b; line[2] = (float)c;
 }
 
-__device__ double epi_distance(const float line[3], double x, double y)
+__device__ __forceinline__ double epi_distance(const float line[3], double x, double y)
 { // reference lib/Helpers.py:217
     double a = line[0], b = line[1], c = line[2];
     return fabs(a * x + b * y + c) / sqrt(a * a + b * b);
 }
 
 // eigenvector of the smallest eigenvalue of a symmetric 4x4 (cyclic Jacobi); same rotations as the oracle
-__device__ void smallest_eigvec4(double B[4][4], double v[4])
+__device__ __forceinline__ void smallest_eigvec4(double B[4][4], double v[4])
 {
     double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
     for (int sweep = 0; sweep < 60; sweep++) {
@@ -138,7 +183,7 @@ __device__ void smallest_eigvec4(double B[4][4], double v[4])
 
 struct DltAcc {
     double B[4][4];
-    __device__ void clear()
+    __device__ __forceinline__ void clear()
     {
 #pragma unroll
         for (int j = 0; j < 4; j++)
@@ -146,7 +191,7 @@ struct DltAcc {
             for (int k = 0; k < 4; k++) B[j][k] = 0.;
     }
     // rows  y*P[2]-P[1]  and  P[0]-x*P[2]  of the DLT system, P = K @ [R|t]  (reference lib/Helpers.py:58-73)
-    __device__ void add(const double* K, const double* R, const double* t, double x, double y)
+    __device__ __forceinline__ void add(const double* K, const double* R, const double* t, double x, double y)
     {
         double P[12];
 #pragma unroll
@@ -170,7 +215,7 @@ struct DltAcc {
             for (int k = 0; k < 4; k++) B[j][k] += r0[j] * r0[k] + r1[j] * r1[k];
     }
     // the same two rows from a projection matrix formed beforehand (the identical sums, formed once per camera)
-    __device__ void add_rows(const double* P, double x, double y)
+    __device__ __forceinline__ void add_rows(const double* P, double x, double y)
     {
         double r0[4], r1[4];
 #pragma unroll
@@ -183,7 +228,7 @@ struct DltAcc {
 #pragma unroll
             for (int k = 0; k < 4; k++) B[j][k] += r0[j] * r0[k] + r1[j] * r1[k];
     }
-    __device__ void solve(double X[3])
+    __device__ __forceinline__ void solve(double X[3])
     {
         double v[4];
         smallest_eigvec4(B, v);
@@ -192,7 +237,7 @@ struct DltAcc {
 };
 
 // cv.projectPoints for one float32 object point; squared pixel errors against (px,py)
-__device__ void reproj_sq(const double* K, const double* d, const double* R, const double* t, const float Xf[3],
+__device__ __forceinline__ void reproj_sq(const double* K, const double* d, const double* R, const double* t, const float Xf[3],
                           double px, double py, double& ex, double& ey)
 {
     double X = Xf[0], Y = Xf[1], Z = Xf[2];
@@ -220,25 +265,29 @@ __device__ __forceinline__ void load_pt(const void* base, size_t idx, double& x,
 
 } // namespace
 
-// LDS plan of correspond_kernel (dynamic shared memory), the same on host and device
+// LDS plan of correspond_kernel (dynamic shared memory), the same on host and device.  What the kernel cannot do without
+// comes first (camera block, counts, candidate lists); the staged points and the per-group errors take what `budget` leaves
+// (both have a fallback: points from global memory, errors in the context's scratch array).
 struct CorrLds {
     int cam, F, pts, errs, rerr, ints, nm, midx, total; // byte offsets
     int stage_pts, err_cap;
 };
-__host__ __device__ inline CorrLds corr_lds_plan(int P, int C)
+__host__ __device__ inline CorrLds corr_lds_plan(int P, int C, int budget)
 {
     CorrLds L;
     int o = 0;
     L.cam = o; o += C * 38 * 8;                 // per camera: projection matrix P = K [R|t] (12), K (9), dist (5), R (9), t (3)
     L.F = o; o += (C > 1 ? C - 1 : 0) * 9 * 8;
-    L.stage_pts = C * P <= 2048;                // all image points of the time step in LDS (32 KB at most)
-    L.pts = o; o += L.stage_pts ? C * P * 16 : 0;
-    L.err_cap = 1024;                           // per-group errors in LDS when the time step has no more groups than this
-    L.errs = o; o += L.err_cap * 8;
     L.rerr = o; o += P * 8;
     L.ints = o; o += (3 * P + 2 + 32) * 4;      // G[P], goff[P + 1], slot[P], counts[32]
     L.nm = o; o += P * C;
     L.midx = o; o += P * C * MAXM;
+    o = (o + 15) & ~15;
+    L.stage_pts = C * P <= 2048 && o + C * P * 16 + 128 * 8 <= budget; // all image points of the time step in LDS (32 KB at most)
+    L.pts = o; o += L.stage_pts ? C * P * 16 : 0;
+    int cap = (budget - o) / 8;                 // per-group errors in LDS when the time step has no more groups than this
+    L.err_cap = cap > 1024 ? 1024 : (cap < 0 ? 0 : cap);
+    L.errs = o; o += L.err_cap * 8;
     L.total = (o + 15) & ~15;
     return L;
 }
@@ -257,7 +306,7 @@ __global__ __launch_bounds__(256) void correspond_kernel(CorrArgs a)
     else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
     else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
     const int C = a.C, P = a.P, t = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
-    const CorrLds L = corr_lds_plan(P, C);
+    const CorrLds L = corr_lds_plan(P, C, a.lds_budget);
     double (*cam)[38] = (double (*)[38])(smem + L.cam);
     double (*Fm)[9] = (double (*)[9])(smem + L.F);
     double* spts = (double*)(smem + L.pts);
@@ -323,23 +372,33 @@ __global__ __launch_bounds__(256) void correspond_kernel(CorrArgs a)
         getp(0, j, rx, ry);
         float line[3];
         epiline(Fm[i - 1], (float)rx, (float)ry, line);
-        double md[MAXM];
-        int mi[MAXM], k = 0, ni = scnt[i];
+        // the candidates of (root j, camera i), kept sorted by distance (stable) in their LDS row.  No per-lane arrays: the
+        // distance of an entry that has to be compared again is computed again from its point (a handful of operations, the
+        // same value), so nothing here lives in scratch memory
+        uint8_t* const mrow = midx + ((size_t)j * C + i) * MAXM;
+        int k = 0;
+        const int ni = scnt[i];
         bool over = false;
         for (int p = 0; p < ni; p++) {
             double x, y;
             getp(i, p, x, y);
-            double d = epi_distance(line, x, y);
+            const double d = epi_distance(line, x, y);
             if (d < a.cutoff) {
                 if (k == MAXM) { over = true; break; }
                 int q = k++; // stable insertion by distance
-                while (q > 0 && md[q - 1] > d) { md[q] = md[q - 1]; mi[q] = mi[q - 1]; q--; }
-                md[q] = d; mi[q] = p;
+                while (q > 0) {
+                    const int pq = mrow[q - 1];
+                    double xq, yq;
+                    getp(i, pq, xq, yq);
+                    if (!(epi_distance(line, xq, yq) > d)) break;
+                    mrow[q] = (uint8_t)pq;
+                    q--;
+                }
+                mrow[q] = (uint8_t)p;
             }
         }
         if (over) atomicMax(&s_err, 1);
         nm[j * C + i] = (uint8_t)k;
-        for (int q = 0; q < k; q++) midx[((size_t)j * C + i) * MAXM + q] = (uint8_t)mi[q];
     }
     __syncthreads();
     // ---- group counts and offsets ---------------------------------------------------------------------------
@@ -378,31 +437,48 @@ __global__ __launch_bounds__(256) void correspond_kernel(CorrArgs a)
             if (goff[mid] <= w) lo = mid; else hi = mid - 1;
         }
         while (G[lo] == 0) lo++; // skip dead roots sharing the offset
-        int j = lo, g = w - goff[j], rem = g;
-        double gx[32], gy[32];
-        getp(0, j, gx[0], gy[0]);
+        const int j = lo, g = w - goff[j];
+        // pass 1 over the cameras: the group's points (camera 1 is the fastest-varying digit, reference lib/Helpers.py:239-245)
+        // into the DLT system.  The points are looked up again in pass 2 instead of being kept in per-lane arrays.
+        double x0, y0;
+        getp(0, j, x0, y0);
         DltAcc acc;
         acc.clear();
-        acc.add_rows(cam[0], gx[0], gy[0]);
-        for (int i = 1; i < C; i++) { // camera 1 is the fastest-varying digit (reference lib/Helpers.py:239-245)
-            int n_i = nm[j * C + i], dgt = rem % n_i;
+        acc.add_rows(cam[0], x0, y0);
+        const uint8_t* const nmj = nm + j * C;
+        const uint8_t* const mj = midx + (size_t)j * C * MAXM;
+        int rem = g;
+        for (int i = 1; i < C; i++) {
+            const int n_i = nmj[i], dgt = rem % n_i;
             rem /= n_i;
-            int p = midx[((size_t)j * C + i) * MAXM + dgt];
-            getp(i, p, gx[i], gy[i]);
-            acc.add_rows(cam[i], gx[i], gy[i]);
+            double x, y;
+            getp(i, mj[i * MAXM + dgt], x, y);
+            acc.add_rows(cam[i], x, y);
         }
         double X[3];
         acc.solve(X);
-        float Xf[3] = {(float)X[0], (float)X[1], (float)X[2]};
-        double e[64];
-        for (int i = 0; i < C; i++) reproj_sq(&cam[i][12], &cam[i][21], &cam[i][26], &cam[i][35], Xf, gx[i], gy[i], e[2 * i], e[2 * i + 1]);
-        double mse = np_block_sum(e, 2 * C) / (double)(2 * C);
-        errs[goff[j] + g] = mse;
-        if (g == 0) {
-            int o = slot[j];
-            size_t ro = (size_t)t * P + o;
+        const float Xf[3] = {(float)X[0], (float)X[1], (float)X[2]};
+        // pass 2: squared reprojection errors, summed in numpy's order as they come
+        const bool first = g == 0;
+        const size_t ro = (size_t)t * P + (first ? slot[j] : 0);
+        NpPairStream sum;
+        sum.begin(2 * C);
+        rem = g;
+        for (int i = 0; i < C; i++) {
+            double x = x0, y = y0;
+            if (i > 0) {
+                const int n_i = nmj[i], dgt = rem % n_i;
+                rem /= n_i;
+                getp(i, mj[i * MAXM + dgt], x, y);
+            }
+            double ex, ey;
+            reproj_sq(&cam[i][12], &cam[i][21], &cam[i][26], &cam[i][35], Xf, x, y, ex, ey);
+            sum.push2(ex, ey);
+            if (first) { a.root_grp[(ro * C + i) * 2] = x; a.root_grp[(ro * C + i) * 2 + 1] = y; }
+        }
+        errs[goff[j] + g] = sum.res / (double)(2 * C);
+        if (first) {
             a.root_xyz[ro * 3] = X[0]; a.root_xyz[ro * 3 + 1] = X[1]; a.root_xyz[ro * 3 + 2] = X[2];
-            for (int i = 0; i < C; i++) { a.root_grp[(ro * C + i) * 2] = gx[i]; a.root_grp[(ro * C + i) * 2 + 1] = gy[i]; }
             a.root_idx[ro] = j;
         }
     }
@@ -459,17 +535,22 @@ __global__ void reproject_kernel(ReprojArgs a)
     if (n >= a.N) return;
     const CameraTable* cams = a.cams;
     float Xf[3] = {(float)a.xyz[3 * n], (float)a.xyz[3 * n + 1], (float)a.xyz[3 * n + 2]};
-    double e[64];
+    int nv = 0;
+    for (int c = 0; c < a.C; c++) nv += a.valid[(size_t)n * a.C + c] != 0;
+    if (nv <= 1) { a.ok[n] = 0; return; }
+    NpPairStream sum; // the errors of the valid cameras, summed in numpy's order as they come (no per-lane array)
+    sum.begin(2 * nv);
     int m = 0;
     for (int c = 0; c < a.C; c++) {
         if (!a.valid[(size_t)n * a.C + c]) continue;
         int ki = a.compact_k ? m : c;
+        double ex, ey;
         reproj_sq(cams->K[ki], cams->dist[ki], cams->R[c], cams->t[c], Xf, a.pts[((size_t)n * a.C + c) * 2],
-                  a.pts[((size_t)n * a.C + c) * 2 + 1], e[2 * m], e[2 * m + 1]);
+                  a.pts[((size_t)n * a.C + c) * 2 + 1], ex, ey);
+        sum.push2(ex, ey);
         m++;
     }
-    if (m <= 1) { a.ok[n] = 0; return; }
-    a.mse[n] = np_block_sum(e, 2 * m) / (double)(2 * m);
+    a.mse[n] = sum.res / (double)(2 * nv);
     a.ok[n] = 1;
 }
 
@@ -492,7 +573,7 @@ __global__ __launch_bounds__(256) void epipolar_scores_kernel(EpiArgs a)
 }
 
 // scipy Rotation.from_rotvec(v).as_matrix() (reference lib/Helpers.py:152): rotation vector -> unit quaternion -> matrix
-__device__ void rotvec_to_matrix(const double v[3], double Rm[9])
+__device__ __forceinline__ void rotvec_to_matrix(const double v[3], double Rm[9])
 {
     const double angle = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
     double scale;
@@ -578,16 +659,23 @@ __global__ __launch_bounds__(256) void ba_residuals_kernel(BaArgs a)
         double mse = 0.0;
         if (has) {
             const float Xf[3] = {(float)obj[3 * n], (float)obj[3 * n + 1], (float)obj[3 * n + 2]};
-            double e[64];
-            int m = 0;
-            for (int c = 0; c < C; c++) {
-                if (!a.valid[(size_t)n * C + c]) continue;
-                reproj_sq(cams->K[m], cams->dist[m], sR[c], sT[c], Xf, a.pts[((size_t)n * C + c) * 2], a.pts[((size_t)n * C + c) * 2 + 1],
-                          e[2 * m], e[2 * m + 1]); // intrinsics by position after the None entries are dropped (:121-123,137-138)
-                m++;
+            int nv = 0;
+            for (int c = 0; c < C; c++) nv += a.valid[(size_t)n * C + c] != 0;
+            has = nv > 1;
+            if (has) {
+                NpPairStream sum;
+                sum.begin(2 * nv);
+                int m = 0;
+                for (int c = 0; c < C; c++) {
+                    if (!a.valid[(size_t)n * C + c]) continue;
+                    double ex, ey;
+                    reproj_sq(cams->K[m], cams->dist[m], sR[c], sT[c], Xf, a.pts[((size_t)n * C + c) * 2], a.pts[((size_t)n * C + c) * 2 + 1],
+                              ex, ey); // intrinsics by position after the None entries are dropped (:121-123,137-138)
+                    sum.push2(ex, ey);
+                    m++;
+                }
+                mse = sum.res / (double)(2 * nv);
             }
-            has = m > 1;
-            if (has) mse = np_block_sum(e, 2 * m) / (double)(2 * m);
         }
         int total;
         const int o = place(has, total);
@@ -599,11 +687,35 @@ __global__ __launch_bounds__(256) void ba_residuals_kernel(BaArgs a)
     if (tid == 0) a.counts[b] = s_base;
 }
 
-size_t correspond_smem_bytes(int P, int C) { return (size_t)corr_lds_plan(P, C).total; }
-
-void launch_correspond(const CorrArgs& a, hipStream_t s)
+// Dynamic LDS a workgroup of correspond_kernel may use: 64 KiB without asking; the first call asks the runtime for gfx950's
+// whole 160 KiB per workgroup (large P x C: the candidate lists alone are P * C * 16 bytes) and remembers the answer.
+static int correspond_lds_limit()
 {
-    size_t sm = correspond_smem_bytes(a.P, a.C);
+    static const int limit = [] {
+        const int want = 160 * 1024 - 64; // minus the kernel's static words
+        const bool ok = hipFuncSetAttribute((const void*)correspond_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess &&
+                        hipFuncSetAttribute((const void*)correspond_kernel<int32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        return ok ? want : 64 * 1024 - 64;
+    }();
+    return limit;
+}
+// the budget the plan is made for: 64 KiB when that holds everything (four workgroups per CU stay possible), else the limit
+int correspond_lds_budget(int P, int C)
+{
+    const int small = 64 * 1024 - 64;
+    const CorrLds L = corr_lds_plan(P, C, small);
+    if (L.total <= small && L.stage_pts == (C * P <= 2048) && L.err_cap == 1024) return small;
+    return correspond_lds_limit();
+}
+size_t correspond_smem_bytes(int P, int C) { return (size_t)corr_lds_plan(P, C, correspond_lds_budget(P, C)).total; }
+bool correspond_fits(int P, int C) { return correspond_smem_bytes(P, C) <= (size_t)correspond_lds_budget(P, C); }
+
+void launch_correspond(const CorrArgs& a_, hipStream_t s)
+{
+    CorrArgs a = a_;
+    a.lds_budget = correspond_lds_budget(a.P, a.C);
+    size_t sm = (size_t)corr_lds_plan(a.P, a.C, a.lds_budget).total;
     // threads per time step (MOCAP_CORR_THREADS: A/B switch; one wave per step measured 0.064 against 0.051 ms alone and the
     // same in the three-batch pipeline)
     const int threads = (a.threads == 64 || a.threads == 128) ? a.threads : 256;

@@ -26,7 +26,14 @@ struct FilterArgs {
     int n_images, n_steps; // n_steps = ceil(n_images / cam_mod)
     int thr_mul;          // floor(thresh)+1: blurred > thresh  <=>  S >= thr_mul * taps
     int rows_per_chunk, n_strips, n_cgroups;
+    // the staged form of the row pipeline (filter_rows_staged_kernel): compact table, source pixels through LDS
+    int staged = 0;       // 1 = use it (remap variant; W % 4 == 0, H >= 2, every slot's table compact)
+    const uint32_t* map4 = nullptr; // compact table of the first slot used (see BoxArgs)
+    const ushort4* rowbox = nullptr; // [cam_mod][H][n_strips]: per row and strip, the box of tap coordinates the strip's pixels read, + 2
+    int stage_dw = 0;         // dwords of LDS a band's source rectangle may take (ROWS_STAGE_DW; smaller values are a test switch)
 };
+void launch_rowbox(const uint32_t* map4, ushort4* rowbox, int H, int W, int n_strips, hipStream_t s);
+int rows_stage_dwords();
 
 // The sparse half of the filter stage (blob_boxes.hip): tiles, boxes, work items.
 // A tile = 240 mask columns x rows_per_chunk rows.  The scan kernel leaves per tile the box of mask rows / columns that
@@ -155,7 +162,13 @@ struct BrightArgs {
     int blocks_x;                 // blocks of 256 threads per image (set by launch_bright_cells)
     int slices;                   // > 1: the pass goes out as that many launches over consecutive runs of images
     int image0, slice_images;     // set by launch_bright_cells: the images of this launch
+    uint32_t* hotmap;             // [n_images][hot_words]: two bits per source cell, cell i of an image at bits 2 (i % 16) of word i / 16: how
+                                  //   many of the thresholds hot_corner <= hot_edge <= hot its sum exceeds.  Every word is written by the
+                                  //   scan (plain stores); mark_tiles_kernel reads it.  null = the scan marks the tiles itself
+    int hot_words;                // words per image: hot_map_words(H, W, wide)
 };
+int hot_map_words(int H, int W, int wide);
+void launch_mark_tiles(const BrightArgs& a, hipStream_t s); // hot map -> tile boxes (tile_rows), behind launch_bright_cells
 void launch_bright_cells(const BrightArgs& a, hipStream_t s);
 // set-up statistics of an undistort table, for the dark-tile bound: stats[0] = largest total blend weight any source
 // pixel carries over all output pixels (1024 = one full pixel), stats[1] / stats[2] = largest x / y extent (in source
@@ -218,6 +231,7 @@ struct CorrArgs {
     int threads;               // threads per time step: 64 / 128 / 256 (A/B switch; one wave per step measured 0.064 against 0.051 ms)
     double* scratch;           // [T][step_budget] per-group errors, the groups of a time step back to back in root order
     int step_budget;           // groups per time step the scratch holds
+    int lds_budget;            // set by launch_correspond: bytes of dynamic LDS the kernel's plan is made for
 };
 
 struct TriArgs {
@@ -264,6 +278,7 @@ enum { CORR_ERR_GROUPS = -2, CORR_ERR_TRUNCATED = -3, CORR_ERR_BLOB = -4 };
 
 void launch_correspond(const CorrArgs& a, hipStream_t s);
 size_t correspond_smem_bytes(int P, int C);
+bool correspond_fits(int P, int C); // the kernel's LDS plan for P points x C cameras fits a workgroup
 void launch_epipolar_scores(const EpiArgs& a, hipStream_t s);
 void launch_ba_residuals(const BaArgs& a, hipStream_t s);
 void launch_triangulate(const TriArgs& a, hipStream_t s);

@@ -53,6 +53,7 @@ class MocapContext:
         self._cam_key = None
         self._f_key = None
         self._und_key = {}
+        self._warned_dense = set()  # causes set_undistort has warned about
         self.identity = {}
 
     def close(self):
@@ -85,11 +86,17 @@ class MocapContext:
         _abi.check(self.lib.mocap_set_undistort(self._h, slot, Kp, dp, C.byref(ident)))
         self._und_key[slot] = key
         self.identity[slot] = bool(ident.value)
-        if warn_dense and not self.undistort_info(slot)["sparse_path"]:
-            import warnings
-            warnings.warn(f"mocapv2_amd: undistort slot {slot}: the lens table is outside the bounds of the sparse path "
-                          f"({self.undistort_info(slot)}); its images are filtered by the dense kernel: same results, several times "
-                          "slower on dark scenes", RuntimeWarning, stacklevel=2)
+        if warn_dense:
+            # Only a table that cannot take the sparse road is worth a warning: sparse_path is also False when a tuning switch
+            # (general_filter, skip_dark=0) sends everything down the dense kernel on purpose.  Once per cause and context.
+            info = self.undistort_info(slot)
+            causes = tuple(k for k in ("compact_table", "early_out_provable") if not info["identity"] and not info[k])
+            if causes and causes not in self._warned_dense:
+                self._warned_dense.add(causes)
+                import warnings
+                warnings.warn(f"mocapv2_amd: undistort slot {slot}: the lens table is outside the bounds of the sparse path "
+                              f"({', '.join(c + ' = False' for c in causes)}; {info}); its images are filtered by the dense kernel: "
+                              "same results, several times slower on dark scenes", RuntimeWarning, stacklevel=2)
         return self.identity[slot]
 
     def undistort_info(self, slot=0):

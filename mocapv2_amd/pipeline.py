@@ -209,10 +209,10 @@ class BatchTracker:
             ctx = MocapContext(width, height, n_slots, device)
             if world == 1:
                 for c in range(self.n_cam):
-                    ctx.set_undistort(c, K[c], dist[c])
+                    ctx.set_undistort(c, K[c], dist[c], warn_dense=d == 0)  # the lanes hold the same tables: one warning
             else:
                 for c in local_cams:
-                    ctx.set_undistort(self.slot_of[c], K[c], dist[c])
+                    ctx.set_undistort(self.slot_of[c], K[c], dist[c], warn_dense=d == 0)
             ctx.set_cameras(K, dist, R, t)
             ctx.set_fundamentals(F)
             records = torch.zeros((self.per, self.rec_ints), dtype=torch.int32, device=ctx.device)

@@ -59,48 +59,94 @@ class ReplayTracker:
             idx = idx[: self.obj_count + 1]
         return xyz[idx]
 
-    def run(self, frames, send=None):
-        """Generator over time steps.  frames: uint8 [T, C, H, W] NumPy array or torch tensor (host or device).
-        Yields dicts: object_points [<= obj_count+1, 3] (or shape (0,)), image_points [roots, C, 2] (or (0,)),
-        message (bytes).  `send(bytes)` is called per time step when given."""
+    def _submit(self, frames):
+        """Generator over the batches of `frames`, each submitted to the GPU: (first time step, time steps, outputs), at most
+        `depth` of them in flight, oldest first."""
         T = frames.shape[0]
         assert frames.shape[1:] == (self.n_cam, self.height, self.width), frames.shape
         dev = self.tracker.ctx.device
-        pending = []  # batches submitted and not yet read back: (first time step, time steps, outputs); at most depth - 1 wait here
+        pending = []  # batches submitted and not yet read back; at most depth - 1 wait here
         for b0 in range(0, T, self.batch):
             chunk = frames[b0:b0 + self.batch]
             nb = chunk.shape[0]
             if isinstance(chunk, np.ndarray):
                 chunk = torch.from_numpy(np.ascontiguousarray(chunk))
-            chunk = chunk.to(dev, non_blocking=True)
+            # depth 1: the plain blocking copy.  Deeper pipelines upload asynchronously (a pinned caller tensor is then read later:
+            # the caller must leave frames[b0:b0 + batch] untouched until that batch's results have been yielded)
+            chunk = chunk.to(dev, non_blocking=self.depth > 1)
             if nb < self.batch:  # pad the last batch with black frames (they produce no points)
                 pad = torch.zeros((self.batch - nb,) + tuple(chunk.shape[1:]), dtype=torch.uint8, device=dev)
                 chunk = torch.cat([chunk, pad], dim=0)
             out = self.tracker.step(chunk.reshape(self.batch * self.n_cam, self.height, self.width).contiguous())
             pending.append((b0, nb, out))
             if len(pending) >= self.depth:  # the oldest batch's lane is the next one to be reused: read it back first
-                yield from self._emit(*pending.pop(0), send)
+                yield pending.pop(0)
         while pending:
-            yield from self._emit(*pending.pop(0), send)
+            yield pending.pop(0)
 
-    def _emit(self, b0, nb, out, send):
-        n = self.tracker.finish(out, first_step=b0)  # raises CapacityError: no time step is answered from shortened lists
-        xyz = out["xyz"].cpu().numpy()
-        grp = out["grp"].cpu().numpy()
-        order = out["order"].cpu().numpy()
-        for s in range(nb):
-            k = int(n[s])
-            if k == 0:
-                obj, img = np.array([]), np.array([])
-            else:
-                obj = self._select(xyz[s], order[s], k)
-                img = grp[s, :k].astype(np.int64)
-            if len(obj) > 0:
-                self.point = [0, 0, 0, 0] + list(obj[0])  # :184-185
-            msg = tracker_message(self.point)
-            if send is not None:
-                send(msg)
-            yield {"object_points": obj, "image_points": img, "message": msg}
+    def _collect(self, b0, nb, out):
+        """One batch read back (one device-to-host copy per output) and turned into what `track` produces, for all of its time
+        steps at once: the `obj_count + 1` selection of lib/Helpers.py:274-279, the image points, and the message bytes -- built
+        in bulk (batch_messages), the previous message repeated for time steps without a point (RealtimeTracking_FLIR.py:181-188)."""
+        n = self.tracker.finish(out, first_step=b0)[:nb]  # raises CapacityError: no time step is answered from shortened lists
+        xyz = out["xyz"].cpu().numpy()[:nb]
+        grp = out["grp"].cpu().numpy()[:nb].astype(np.int64)
+        order = out["order"].cpu().numpy()[:nb]
+        oc = self.obj_count
+        kept = np.where(n >= oc, np.minimum(n, oc + 1), n)  # `if not obj_count > len(...)`: lib/Helpers.py:275-278
+        width = min(oc + 1, xyz.shape[1])
+        sel = np.clip(order[:, :width], 0, xyz.shape[1] - 1)
+        obj = xyz[np.arange(nb)[:, None], sel]  # [nb, <= obj_count + 1, 3]; rows beyond kept[s] are not results
+        has = kept > 0
+        msgs = batch_messages(obj[:, 0] if width else np.zeros((nb, 3)), has, tracker_message(self.point))
+        if has.any():
+            self.point = [0, 0, 0, 0] + list(obj[np.flatnonzero(has)[-1], 0])  # :184-185
+        return {"first_step": b0, "n_steps": nb, "n_roots": n, "kept": kept, "object_points": obj, "image_points": grp, "messages": msgs}
+
+    def run_batches(self, frames, send_many=None):
+        """Generator over BATCHES of time steps: dicts with first_step, n_steps, n_roots [n], kept [n] (object points per time
+        step), object_points [n, <= obj_count + 1, 3] (rows beyond kept[s] unused), image_points [n, P, C, 2] int64 (rows
+        beyond n_roots[s] unused), messages (list of n bytes objects).  `send_many(list_of_bytes)` is called once per batch when
+        given.  The bulk form of run(): no Python work per time step."""
+        for b0, nb, out in self._submit(frames):
+            res = self._collect(b0, nb, out)
+            if send_many is not None:
+                send_many(res["messages"])
+            yield res
+
+    def run(self, frames, send=None):
+        """Generator over time steps.  frames: uint8 [T, C, H, W] NumPy array or torch tensor (host or device).
+        Yields dicts: object_points [<= obj_count+1, 3] (or shape (0,)), image_points [roots, C, 2] (or (0,)),
+        message (bytes).  `send(bytes)` is called per time step when given."""
+        empty = np.array([])
+        for res in self.run_batches(frames):
+            n, kept, obj, img, msgs = res["n_roots"], res["kept"], res["object_points"], res["image_points"], res["messages"]
+            for s in range(res["n_steps"]):
+                if send is not None:
+                    send(msgs[s])
+                k = int(n[s])
+                yield {"object_points": obj[s, :kept[s]] if k else empty, "image_points": img[s, :k] if k else empty, "message": msgs[s]}
 
 
-__all__ = ["ReplayTracker", "tracker_message", "unpack_tracker_message", "OBJ_COUNT", "MocapContext"]
+_MSG_HEAD = bytes([0x81, 0xa8]) + b"tracker1" + bytes([0x97, 0, 0, 0, 0])  # map of 1, fixstr(8), array of 7, four zero ints
+
+
+def batch_messages(first_points, has, carry):
+    """The tracker messages of a run of time steps, built without a Python loop over them.  first_points [n, 3] float64 (the
+    first object point of each time step), has [n] bool (the time step produced a point), carry: the message in force before
+    the run.  Returns a list of n bytes objects: msgpack.packb({"tracker1": [0, 0, 0, 0, x, y, z]}, use_bin_type=True) for a
+    time step with a point (a map of one entry, fixstr key, array of seven: four zero fixints and three float64, big endian),
+    else the message of the last time step that had one (`point` keeps its value, RealtimeTracking_FLIR.py:181-188)."""
+    n = len(has)
+    L = len(_MSG_HEAD) + 27
+    buf = np.empty((n, L), np.uint8)
+    buf[:, :len(_MSG_HEAD)] = np.frombuffer(_MSG_HEAD, np.uint8)
+    body = buf[:, len(_MSG_HEAD):].reshape(n, 3, 9)
+    body[:, :, 0] = 0xcb
+    body[:, :, 1:] = np.ascontiguousarray(first_points, np.float64).astype(">f8").view(np.uint8).reshape(n, 3, 8)
+    src = np.maximum.accumulate(np.where(has, np.arange(n), -1))  # the time step whose message is in force
+    raw = buf[np.maximum(src, 0)].tobytes()
+    return [raw[i * L:(i + 1) * L] if src[i] >= 0 else carry for i in range(n)]
+
+
+__all__ = ["ReplayTracker", "batch_messages", "tracker_message", "unpack_tracker_message", "OBJ_COUNT", "MocapContext"]

@@ -194,3 +194,55 @@ def test_epipolar_scores_k2_bundled_pairs():
             line = oracle.epiline(g["F"][0], p0[r, 0], p0[r, 1])
             assert np.array_equal(lines[r], line)
             assert np.array_equal(d[r], [oracle.epi_distance(line, x, y) for x, y in p1])
+
+
+def test_configs4_sixteen_4k_cameras_64_markers_joined_with_ba_residuals():
+    """BASELINE.json configs[4] as ONE path: 16 cameras x 3840x2160 x 64 markers, 2 time steps, through
+    BatchTracker(max_points=128, max_groups=1 << 22) -- 16 undistort slots at 4K, records of 128 points, the LDS plan of the
+    correspondence kernel at P = 128 x C = 16 -- every record and every time step against oracle.find_dot + oracle.correspond,
+    including the rule for time steps the reference's cartesian expansion (lib/Helpers.py:239-245) gives up on; then the
+    bundle-adjustment residual vector (mocap_ba_residuals, lib/Helpers.py:161-167) on the groups the tracker matched.
+    The markers are spread over a 2.4 m cube seen from a 4 m ring, as bench.py --cameras 16 --markers 64 does (config.rig_note)."""
+    import torch
+    from scipy.spatial.transform import Rotation
+    from mocapv2_amd.pipeline import BatchTracker, scene_arrays
+    C, T, M, W, H = 16, 2, 64, 3840, 2160
+    sc = Scene(C, W, H, dist=MILD_DIST, radius=4.0)
+    K, dist, R, t, F = scene_arrays(sc)
+    frames = np.empty((T, C, H, W), np.uint8)
+    for s in range(T):
+        mk = sc.markers(np.random.default_rng(9100 + s), M, extent=1.2)
+        for c in range(C):
+            frames[s, c] = sc.render(np.random.default_rng((9100 + s) * 64 + c), mk, c, radius_range=(16.0, 22.0), salt=0.001)
+    max_groups = 1 << 22
+    trk = BatchTracker(K, dist, R, t, F, W, H, T, max_points=2 * M, max_groups=max_groups)
+    dev = torch.from_numpy(frames.reshape(T * C, H, W)).cuda()
+    out_dev = trk.step(dev)
+    torch.cuda.synchronize()
+    rec = trk.records.cpu().numpy()
+    out = {k: v.cpu().numpy() for k, v in out_dev.items()}
+    points, gave_up, groups = 0, 0, None
+    for s in range(T):
+        lists, ref = oracle_step(frames[s], K, dist, R, t, F, max_groups=max_groups)
+        for c in range(C):
+            assert_records_equal(rec, s * C + c, lists[c], (s, c))
+        if ref is None:  # both give the time step up: MOCAP_CORR_E_GROUPS, never a shortened answer
+            assert out["n"][s] == -2, s
+            gave_up += 1
+            continue
+        k = assert_step_equal(out, s, ref, s)
+        points += k
+        if k and groups is None:
+            groups = ref["groups"]
+    assert points >= 16, (points, gave_up)  # a root needs a match in all 15 other cameras (lib/Helpers.py:93)
+    # the residual vector of bundle_adjustment on the matched groups: camera 0 at the origin, cameras 1.. as (rotvec, t)
+    params = []
+    for c in range(1, C):
+        Rrel = R[c] @ R[0].T
+        params += list(Rotation.from_matrix(Rrel).as_rotvec()) + list(t[c] - Rrel @ t[0])
+    params = np.array(params) + np.random.default_rng(3).normal(0, 1e-3, 6 * (C - 1))
+    valid = np.ones(groups.shape[:2], np.uint8)
+    exp = oracle.ba_residuals(params, C, groups, valid, K, dist)
+    trk.ctx.set_cameras(K, dist, R, t)
+    got = trk.ctx.ba_problem(groups, valid).residuals(params)
+    assert got.shape == exp.shape and np.allclose(got, exp, rtol=2e-5, atol=1e-6)

@@ -190,3 +190,24 @@ def test_tracker_wire_format():
     exp = b"\x81\xa8tracker1\x97" + b"\x00" * 4 + b"".join(b"\xcb" + struct.pack(">d", float(v)) for v in p[4:])
     assert tracker_message(p) == exp
     assert unpack_tracker_message(exp) == [0, 0, 0, 0, 0.25, -1.5, 3.0000001]
+
+
+def test_bulk_messages_equal_msgpack_per_time_step():
+    """replay.batch_messages builds the tracker messages of a whole batch with NumPy; every one of them must be byte for byte what
+    msgpack.packb({"tracker1": [0, 0, 0, 0, x, y, z]}, use_bin_type=True) gives (RealtimeTracking_FLIR.py:186-187), time steps
+    without a point repeat the message in force (:181-188), and before the first detection that is the eight-zeros list (:171)."""
+    from mocapv2_amd.replay import batch_messages, tracker_message
+    rng = np.random.default_rng(0)
+    pts = rng.normal(0, 5, (64, 3))
+    pts[3] = [np.nan, -0.0, np.inf]
+    pts[7] = [1e-310, -1e308, 0.0]
+    has = rng.random(64) < 0.6
+    has[:2] = False
+    carry = tracker_message([0] * 8)
+    got = batch_messages(pts, has, carry)
+    point = [0] * 8
+    for i in range(64):
+        if has[i]:
+            point = [0, 0, 0, 0] + list(pts[i])
+        assert got[i] == tracker_message(point), i
+    assert batch_messages(np.zeros((0, 3)), np.zeros(0, bool), carry) == []
