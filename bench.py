@@ -282,7 +282,7 @@ def batch_index(i, depth, n_batches):
     return (i % n_batches) if depth % n_batches else ((i + i // depth) % n_batches)
 
 
-KERNELS = (("scan", "bright_cells_kernel"), ("settle", "settle_tiles_kernel"), ("filter", "box_filter_kernel + filter_mask_kernel (wide tiles)"))
+KERNELS = (("scan", "bright_cells_kernel"), ("settle", "mark_tiles_kernel + settle_tiles_kernel"), ("filter", "box_filter_kernel + filter_rows_staged_kernel (wide tiles)"))
 
 
 def roofline_of(prof, wl, n_images, n_launch_groups, traffic_key):
@@ -301,12 +301,12 @@ def roofline_of(prof, wl, n_images, n_launch_groups, traffic_key):
     else:  # HBM bytes per launch from the builder's PMC passes (profiles/README.md)
         with open(tpath) as f:
             tj = json.load(f)
-        if tj.get("workload_key") == traffic_key and tj.get("images_per_launch") == per_launch:
+        tj = tj.get("workloads", {}).get(traffic_key) or (tj if tj.get("workload_key") == traffic_key else None)
+        if tj and tj.get("images_per_launch") == per_launch:
             traffic = tj.get("hbm_bytes_per_launch", {})
             source = "profiles/hbm_traffic.json (builder's rocprofv3 PMC passes on this workload; not re-measured in this run)"
         else:
-            source = (f"none: profiles/hbm_traffic.json holds {tj.get('workload_key')} at {tj.get('images_per_launch')} images per launch, "
-                      f"this run is {traffic_key} at {per_launch}")
+            source = f"none: profiles/hbm_traffic.json holds no PMC passes for {traffic_key} at {per_launch} images per launch"
     ent = {}
     for key, name in KERNELS:
         n = prof[key + "_launches"]
@@ -485,12 +485,12 @@ def main():
                 ok = False
         return ok, m["out"]["n"].cpu().numpy()
 
-    def section(wl, m, steps):
+    def section(wl, m, steps, traffic_key=None):
         ok, n_roots = status_of(m)
         el, prof, T = m["elapsed"], m["prof"], m["T"]
         return {"workload": wl.name(world), "value": round(T * world * steps / el, 2), "unit": "frames/s", "ms_per_step": round(1e3 * el / steps, 4),
                 "time_steps_per_step": T, "steps": steps, "images_per_step": len(m["images"]),
-                "roofline": roofline_of(prof, wl, len(m["images"]), 1 if world == 1 else len(m["tracker"].segs), None),
+                "roofline": roofline_of(prof, wl, len(m["images"]), 1 if world == 1 else len(m["tracker"].segs), traffic_key),
                 "kernel_ms_per_step": kernel_ms(prof), "kernel_ms_per_step_in_timed_region": kernel_ms(prof, True), "status_ok": ok, "points_per_frame": float(np.maximum(n_roots, 0).mean()),
                 "dark_tile_early_out": {"tiles_per_step": prof["tiles"], "tiles_resolved_without_filtering": prof["tiles_skipped"]}}
 
@@ -794,7 +794,7 @@ def main():
                             ("frame_4k", Workload(6, 3840, 2160, 8, args.dist))):
                 Tx = wl.default_time_steps()
                 mx = measure(wl, Tx, args.steps, args.warmup)
-                extra[key] = section(wl, mx, args.steps)
+                extra[key] = section(wl, mx, args.steps, f"6x1920x1080-m32-{args.dist}" if key == "markers32_configs2" else None)
                 mx.clear()
                 torch.cuda.empty_cache()
             extra["ba_residual_eval_configs4"] = ba_residual_section()

@@ -74,7 +74,8 @@ struct Tuning {
     int dense_boxes = 0;         // 1 = with skip_dark = 0: the box kernel on whole tiles instead of the dense kernel
     int remap_pipeline = 1;      // 0 = the dense kernel's per-pixel gather
     int cluster = 1;             // 0 = no 2x2-tile cluster items
-    int wide_quads_remap = 40, wide_quads_identity = 40; // routing threshold box kernel / row pipeline (1000 = never)
+    int wide_quads_remap = 34, wide_quads_identity = 34; // routing threshold box kernel / row pipeline (1000 = never); round 4: 40 -> 34 with three
+                                 //   workgroups of the row pipeline per CU (filters 0.49 -> 0.47 ms at 8 markers, 1.25 -> 1.19 at 32)
     int wide_bands = 1;          // row bands of a wide tile, 1..4
     int wide_fork = 0;           // 1 = the wide tiles on a side stream beside the box kernel
     int box_prio = 0, scan_prio = 0, contour_prio = 0, corr_prio = 0; // wave priorities
@@ -82,9 +83,13 @@ struct Tuning {
     int box_blocks_per_cu = 0;   // 0 = box_filter_blocks_per_cu()
     int box_timing = 0, contour_timing = 0, follow_timing = 0; // phase clocks on stderr (synchronous debugging aids)
     int scan_wide = 1;           // 0 = the scan's 8-byte loads
-    int rows_staged = 1;         // 0 = the row pipeline (dense path, wide tiles) on the general 8-byte tables with tap gathers instead of the compact table + LDS
+    int rows_staged = 0;         // 1 = the row pipeline (dense path, wide tiles) on the compact table with its source pixels staged in LDS instead of the
+                                 //   general 8-byte tables with tap gathers (measured: 0.35 against 0.18 ms for the wide tiles of the benchmark batch -- the
+                                 //   4-byte table costs ~24 instead of ~14 VALU instructions per pixel and the stage is issue-bound: not the default)
+    int wide_blocks_per_cu = 3;  // workgroups (4 waves) of the wide-tile kernel per CU (137 registers: three waves per SIMD)
     int rows_stage_dw = -1;      // dwords of LDS a band's source rectangle may take (-1 = all of the buffer; 0 = taps from memory: a test switch)
-    int scan_serial = 0;         // 1 = one streaming scan at a time on the device: a context's scan waits for the scan launched before it (event chain across contexts)
+    int scan_serial = 1;         // 1 = one streaming scan at a time on the device: a context's scan waits for the scan launched before it (event chain across
+                                 //   contexts).  A scan alone saturates HBM; two at once only stretch each other and the chains behind them (round 4: +5..9 %)
     int scan_hotmap = 1;         // 0 = the scan marks the tiles itself (reach lookup + atomics behind its loads) instead of leaving a hot map
     int scan_blocks_per_cu = 0;  // > 0: the scan as a persistent pass of that many workgroups per CU (0 = one workgroup per block)
     int scan_slices = 1;         // the scan goes out as that many launches over consecutive runs of images
@@ -105,7 +110,7 @@ static const TuneName kTuneNames[] = {
     {"box_prio", &Tuning::box_prio, 0, 1}, {"scan_prio", &Tuning::scan_prio, 0, 3}, {"contour_prio", &Tuning::contour_prio, 0, 3},
     {"corr_prio", &Tuning::corr_prio, 0, 3}, {"box_stage_bytes", &Tuning::box_stage_bytes, 0, BOX_SCAP},
     {"box_blocks_per_cu", &Tuning::box_blocks_per_cu, 0, 32}, {"box_timing", &Tuning::box_timing, 0, 1},
-    {"contour_timing", &Tuning::contour_timing, 0, 1}, {"follow_timing", &Tuning::follow_timing, 0, 2}, {"scan_wide", &Tuning::scan_wide, 0, 1}, {"scan_hotmap", &Tuning::scan_hotmap, 0, 1}, {"scan_serial", &Tuning::scan_serial, 0, 1}, {"rows_staged", &Tuning::rows_staged, 0, 1}, {"rows_stage_dw", &Tuning::rows_stage_dw, -1, 1 << 20}, {"scan_blocks_per_cu", &Tuning::scan_blocks_per_cu, 0, 64}, {"scan_slices", &Tuning::scan_slices, 1, 64}, {"excess_base", &Tuning::excess_base, -1, 254},
+    {"contour_timing", &Tuning::contour_timing, 0, 1}, {"follow_timing", &Tuning::follow_timing, 0, 2}, {"scan_wide", &Tuning::scan_wide, 0, 1}, {"scan_hotmap", &Tuning::scan_hotmap, 0, 1}, {"scan_serial", &Tuning::scan_serial, 0, 1}, {"rows_staged", &Tuning::rows_staged, 0, 1}, {"wide_blocks_per_cu", &Tuning::wide_blocks_per_cu, 1, 8}, {"rows_stage_dw", &Tuning::rows_stage_dw, -1, 1 << 20}, {"scan_blocks_per_cu", &Tuning::scan_blocks_per_cu, 0, 64}, {"scan_slices", &Tuning::scan_slices, 1, 64}, {"excess_base", &Tuning::excess_base, -1, 254},
     {"base_sel", &Tuning::base_sel, 0, 1}, {"probe_debug", &Tuning::probe_debug, 0, 1}, {"contour_boxes", &Tuning::contour_boxes, 0, 1},
     {"contours_split", &Tuning::contours_split, 0, 1}, {"corr_threads", &Tuning::corr_threads, 64, 256},
     {"corr_step_groups", &Tuning::corr_step_groups, 0, 0x7fffffff},
@@ -290,7 +295,8 @@ int mocap_ctx_create(int device_id, int width, int height, int n_slots, mocap_ct
     if (e == hipSuccess) e = hipMalloc(&c->probe_dev, PROBE_BYTES);
     if (e == hipSuccess) e = hipHostMalloc(&c->probe_host, PROBE_BYTES);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->probe_ev, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    // (the side stream of wide_fork is created on first use: every stream a process holds is dealt onto one of a few hardware
+    // queues, and a stream nobody uses can end up sharing a queue with a batch's own stream)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(&c->cams, sizeof(CameraTable));
@@ -607,7 +613,7 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
     }
     if (c->tune.general_filter) compact = false; // test switch: the general kernel
     // the row pipeline's staged form (compact table, source pixels through LDS) serves the dense path and the wide tiles alike
-    bool rows_staged = remap && c->tune.rows_staged && c->map4 && c->rowbox && (c->W & 3) == 0 && c->W >= 8 && c->H >= 2;
+    bool rows_staged = remap && c->tune.rows_staged && c->map4 && c->rowbox && (c->W & 15) == 0 && c->H >= 2; // (16-byte staging units)
     for (int sl = slot_base; sl < slot_base + cam_mod; sl++)
         if (!c->slot_compact[sl]) rows_staged = false;
     const int rows_dw = c->tune.rows_stage_dw < 0 || c->tune.rows_stage_dw > rows_stage_dwords() ? rows_stage_dwords() : c->tune.rows_stage_dw;
@@ -716,6 +722,7 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
     a.ext_mask = own_mask ? 0 : 1;
     if ((size_t)n_images * cells_per_image(c) * BOX_MAX_PARTS > (size_t)c->cap_items) return fail(MOCAP_E_STATE, "work list smaller than the batch");
     HIP_TRY(hipMemsetAsync(c->n_items, 0, 1024, s));
+    BrightArgs mark_args{}; bool mark_after_scan = false;
     if (!a.dense) { // one streaming pass over the frames marks the tiles (and their boxes) that can hold set pixels
         // floor(i / ncx) = umulhi(i, ceil(2^32 / ncx)) is exact while i * ncx < 2^32
         uint64_t ncx64 = (uint64_t)((c->W + 7) / 8);
@@ -765,10 +772,7 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
             turn->have = true;
             turn_lock.unlock();
         }
-        if (two_step) {
-            launch_mark_tiles(b, s);
-            HIP_TRY(hipGetLastError());
-        }
+        mark_args = b; mark_after_scan = two_step; // (launched with settle, inside its timer: both turn the scan's output into work lists)
         if (probe) {
             HIP_TRY(hipMemcpyAsync(c->probe_host, c->probe_dev, PROBE_BYTES, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipEventRecord(c->probe_ev, s));
@@ -780,6 +784,10 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
         HIP_TRY(hipGetLastError());
     }
     prof_begin(c, 4, s, p, on);
+    if (mark_after_scan) {
+        launch_mark_tiles(mark_args, s);
+        HIP_TRY(hipGetLastError());
+    }
     launch_settle_tiles(a, s);
     prof_end(c, 4, s, p, on);
     HIP_TRY(hipGetLastError());
@@ -814,10 +822,11 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
         hipStream_t ws = s;
         if (fork_wide) {
             HIP_TRY(hipEventRecord(c->ev_fork, s));
+            if (!c->side) HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
             HIP_TRY(hipStreamWaitEvent(c->side, c->ev_fork, 0));
             ws = c->side;
         }
-        launch_filter_tiles(f, remap, c->box_grid / 4 > 0 ? c->box_grid / 4 : 1, ws);
+        launch_filter_tiles(f, remap, c->tune.wide_blocks_per_cu * c->n_cu, ws);
         HIP_TRY(hipGetLastError());
         if (fork_wide) HIP_TRY(hipEventRecord(c->ev_join, c->side));
     }
@@ -977,9 +986,10 @@ static int ensure_mask(mocap_ctx* c, int n_images)
         HIP_TRY(hipMemcpy(c->tile_rows, init.data(), sizeof(uint32_t) * init.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->tile_rows + init.size(), init.data(), sizeof(uint32_t) * init.size(), hipMemcpyHostToDevice));
         c->tile_rows_flip = 0; c->tile_rows_hold[0] = c->tile_rows_hold[1] = 0;
-        // the hot map needs no initial contents (the scan writes every word of the images it looks at); sized for either scan form
+        // the hot map, sized for either scan form
         const int hw0 = hot_map_words(c->H, c->W, 0), hw1 = hot_map_words(c->H, c->W, 1);
         HIP_TRY(hipMalloc(&c->hotmap, sizeof(uint32_t) * (size_t)n_images * (hw0 > hw1 ? hw0 : hw1)));
+        HIP_TRY(hipMemset(c->hotmap, 0, sizeof(uint32_t) * (size_t)n_images * (hw0 > hw1 ? hw0 : hw1))); // all zeros between batches: the scan stores hot words only, mark_tiles_kernel clears them
         for (size_t i = 0; i < init.size(); i++) init[i] = 1u;
         HIP_TRY(hipMalloc(&c->cur_box, sizeof(uint32_t) * init.size()));
         HIP_TRY(hipMemcpy(c->cur_box, init.data(), sizeof(uint32_t) * init.size(), hipMemcpyHostToDevice));

@@ -276,13 +276,13 @@ __global__ __launch_bounds__(256) void settle_tiles_kernel(BoxArgs a)
 // are fetched while the current item is filtered, all staging loads of an item are in flight together, and the table
 // words of the next group of trips are requested before the current group is blended.
 #ifndef MOCAP_BOX_GROUP      // (build-time knobs for A/B builds: scratch/build_variant.sh)
-#define MOCAP_BOX_GROUP 6
+#define MOCAP_BOX_GROUP 3
 #endif
 #ifndef MOCAP_BOX_SU
-#define MOCAP_BOX_SU 14
+#define MOCAP_BOX_SU 7
 #endif
 #ifndef MOCAP_BOX_WAVES
-#define MOCAP_BOX_WAVES 2
+#define MOCAP_BOX_WAVES 4
 #endif
 constexpr int BOX_GROUP = MOCAP_BOX_GROUP; // trips whose table / frame loads are issued together
 
@@ -330,10 +330,11 @@ __device__ __forceinline__ SrcBounds source_bounds_partial(const ushort4* __rest
     return b;
 }
 
-// LDS as a dynamic allocation and an explicit two waves per SIMD: with the 20 KB declared statically the compiler knows that no more
-// than two waves per SIMD can ever be resident and takes 242 registers; told to aim at two, it takes 214 (3 % slower alone).  The
-// difference decides whether a box wave finds room while another batch's scan is running (the cliff lies
-// between ~200 and ~240 registers).
+// Registers.  The kernel's 20 KB of LDS per wave allow two waves per SIMD, and left to itself the compiler takes every register
+// two waves can have (242; 214 when told to aim at two).  What it does with them is keep loads in flight -- six trips' table words
+// twice over, 28 staging dwords -- and a wave that size shuts the other batches' kernels out of its SIMD.
+// Round 4: groups of 3 trips and 14 staging loads, compiled for four waves per SIMD: 128 registers, no spills, the same duration
+// alone (0.49 ms for the benchmark batch's filters) and +3..7 % for the three-batch pipeline (profiles/history/r4_*.log).
 constexpr size_t BOX_LDS_BYTES = 1024 + (size_t)(BOX_HCAP + 64) * 8 + BOX_SCAP;
 __global__ __attribute__((amdgpu_waves_per_eu(MOCAP_BOX_WAVES, MOCAP_BOX_WAVES))) __launch_bounds__(64) void box_filter_kernel(BoxArgs a)
 {

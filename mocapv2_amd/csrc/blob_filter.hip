@@ -17,6 +17,7 @@
 //   the set-up kernels of the undistort tables and the single-image convenience kernels.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "kernels.h"
 #include "scan_mark.h"
 
@@ -310,8 +311,9 @@ __device__ __forceinline__ void bright_cells_block(const BrightArgs& a, const in
     if (MAP) {
         // The hot map: two bits per cell in cell order, so the 128 cells of a wave are 8 whole words (WIDE: consecutive lanes hold
         // consecutive cell pairs) or two runs of 4 (lanes hold cells i and i + 256).  The lanes sharing a word OR their fields
-        // together with DPP moves and one of them stores it: every word of the map is written exactly once per pass -- no atomics,
-        // no clearing, and nothing the wave has to wait for behind its frame loads.
+        // together with DPP moves and one of them stores it if it is not zero (the map is all zeros between batches: mark_tiles_kernel
+        // clears what it reads) -- no atomics, and a wave without a hot cell, the usual one, issues no memory operation behind its
+        // frame loads at all (a store per wave, tried first, made every wave wait for it at its end: 0.99 against 0.95 ms).
         const int lane = threadIdx.x & 63;
         uint32_t* __restrict__ hm = a.hotmap + (size_t)image * a.hot_words;
         if (WIDE) {
@@ -319,7 +321,7 @@ __device__ __forceinline__ void bright_cells_block(const BrightArgs& a, const in
             w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1 /*quad_perm 1,0,3,2*/, 0xf, 0xf, true);
             w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x4E /*quad_perm 2,3,0,1*/, 0xf, 0xf, true);
             w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x141 /*row_half_mirror*/, 0xf, 0xf, true);
-            if ((lane & 7) == 0) hm[(bx * 256 + (int)threadIdx.x) >> 3] = w;
+            if ((lane & 7) == 0 && w != 0u) hm[(bx * 256 + (int)threadIdx.x) >> 3] = w;
         } else {
 #pragma unroll
             for (int u = 0; u < 2; u++) {
@@ -328,7 +330,7 @@ __device__ __forceinline__ void bright_cells_block(const BrightArgs& a, const in
                 w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x4E, 0xf, 0xf, true);
                 w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x141, 0xf, 0xf, true);
                 w |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x140 /*row_mirror*/, 0xf, 0xf, true);
-                if ((lane & 15) == 0) hm[(bx * 512 + (int)threadIdx.x + 256 * u) >> 4] = w;
+                if ((lane & 15) == 0 && w != 0u) hm[(bx * 512 + (int)threadIdx.x + 256 * u) >> 4] = w;
             }
         }
     }
@@ -348,30 +350,22 @@ __global__ __launch_bounds__(256) void mark_tiles_kernel(BrightArgs a)
     __shared__ uint16_t s_list[4][1024];
     __shared__ uint32_t s_tab[4][32][5]; // tile | first row | last row | first column | last column
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int wb = (a.hot_words + 255) >> 8; // workgroups per image
-    const int image = blockIdx.x / wb, word0 = (blockIdx.x - image * wb) * 256 + wv * 64;
+    const int wb = (a.hot_words + 1023) >> 10; // workgroups per image: a wave takes 256 consecutive words (4 per lane)
+    const int image = blockIdx.x / wb, wave_word0 = (blockIdx.x - image * wb) * 1024 + wv * 256;
     const int n_cells = ((a.W + 7) >> 3) * ((a.H + 7) >> 3);
-    const int wi = word0 + lane;
-    const uint32_t w = wi < a.hot_words ? a.hotmap[(size_t)image * a.hot_words + wi] : 0u;
-    const uint32_t nz = (w | (w >> 1)) & 0x55555555u; // bit 2j: cell j of the word exceeds at least the lowest threshold
-    const int cnt = __popc(nz);
-    if (__ballot(cnt != 0) == 0ull) return;
+    uint32_t* __restrict__ hm = a.hotmap + (size_t)image * a.hot_words;
+    uint32_t wk[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int wi = wave_word0 + 64 * k + lane;
+        wk[k] = wi < a.hot_words ? hm[wi] : 0u;
+    }
+    if (__ballot((wk[0] | wk[1] | wk[2] | wk[3]) != 0u) == 0ull) return;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (wk[k] != 0u) hm[wave_word0 + 64 * k + lane] = 0u; // the map is all zeros again for the next batch's scan
     uint32_t (*tab)[5] = s_tab[wv];
     if (lane < 32) { tab[lane][0] = 0xffffffffu; tab[lane][1] = 0xffffffffu; tab[lane][2] = 0u; tab[lane][3] = 0xffffffffu; tab[lane][4] = 0u; }
-    int incl = cnt; // inclusive prefix sum over the wave
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(incl, d);
-        if (lane >= d) incl += o;
-    }
-    const int total = __builtin_amdgcn_readlane(incl, 63);
-    int at = incl - cnt;
-    for (uint32_t m = nz; m; m &= m - 1) {
-        const int j2 = __ffs((int)m) - 1; // = 2 j
-        s_list[wv][at++] = (uint16_t)((lane << 6) | (j2 << 1) | ((w >> j2) & 3u)); // lane | cell of the word | level
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): list and table are written (one wave: no barrier needed)
-    __builtin_amdgcn_wave_barrier();
     const int slot = image % a.cam_mod;
     const uint2* __restrict__ reach = a.reach + (size_t)slot * n_cells;
     const uint8_t* __restrict__ cflags = a.cflags + (size_t)slot * n_cells;
@@ -385,36 +379,58 @@ __global__ __launch_bounds__(256) void mark_tiles_kernel(BrightArgs a)
         atomicMin(&rows[4 * t + 2], xa);
         atomicMax(&rows[4 * t + 3], xb);
     };
-    for (int e0 = 0; e0 < total; e0 += 64) {
-        const int e = e0 + lane;
-        if (e < total) {
-            const uint32_t v = s_list[wv][e];
-            const int ci = 16 * (word0 + (int)(v >> 6)) + (int)((v >> 2) & 15u);
-            if (ci < n_cells) {
-                const uint2 rc = reach[ci];
-                const int x0 = (int)(rc.x & 0xffffu), x1 = (int)(rc.x >> 16), y0 = (int)(rc.y & 0xffffu), y1 = (int)(rc.y >> 16);
-                if (x0 <= x1 && level_is_hot(v & 3u, cflags[ci])) {
-                    // (the rectangle and the tiles it overlaps: as widen_tile_boxes, scan_mark.h)
-                    const int xa = x0 - 4 > 0 ? x0 - 4 : 0, xb = x1 + 4 < a.W - 1 ? x1 + 4 : a.W - 1;
-                    const int ya = y0 - 4 > 0 ? y0 - 4 : 0, yb = y1 + 4 < a.H - 1 ? y1 + 4 : a.H - 1;
-                    const int ch0 = (int)(((uint32_t)ya * a.rows_magic) >> 23), ch1 = (int)(((uint32_t)yb * a.rows_magic) >> 23);
-                    const int st0 = (int)(((uint32_t)xa * 34953u) >> 23), st1 = (int)(((uint32_t)xb * 34953u) >> 23);
-                    for (int ch = ch0; ch <= ch1; ch++)
-                        for (int st = st0; st <= st1; st++) {
-                            const int t = ch * a.n_strips + st, k = t & 31;
-                            const uint32_t old = atomicCAS(&tab[k][0], 0xffffffffu, (uint32_t)t);
-                            if (old == 0xffffffffu || old == (uint32_t)t) {
-                                atomicMin(&tab[k][1], (uint32_t)ya); atomicMax(&tab[k][2], (uint32_t)yb);
-                                atomicMin(&tab[k][3], (uint32_t)xa); atomicMax(&tab[k][4], (uint32_t)xb);
-                            } else
-                                widen(t, (uint32_t)ya, (uint32_t)yb, (uint32_t)xa, (uint32_t)xb);
-                        }
+#pragma unroll 1
+    for (int k = 0; k < 4; k++) {
+        const uint32_t w = k == 0 ? wk[0] : (k == 1 ? wk[1] : (k == 2 ? wk[2] : wk[3]));
+        const uint32_t nz = (w | (w >> 1)) & 0x55555555u; // bit 2j: cell j of the word exceeds at least the lowest threshold
+        const int cnt = __popc(nz);
+        if (__ballot(cnt != 0) == 0ull) continue;
+        const int word0 = wave_word0 + 64 * k;
+        int incl = cnt; // inclusive prefix sum over the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        int at = incl - cnt;
+        for (uint32_t m = nz; m; m &= m - 1) {
+            const int j2 = __ffs((int)m) - 1; // = 2 j
+            s_list[wv][at++] = (uint16_t)((lane << 6) | (j2 << 1) | ((w >> j2) & 3u)); // lane | cell of the word | level
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): list and table are written (one wave: no barrier needed)
+        __builtin_amdgcn_wave_barrier();
+        for (int e0 = 0; e0 < total; e0 += 64) {
+            const int e = e0 + lane;
+            if (e < total) {
+                const uint32_t v = s_list[wv][e];
+                const int ci = 16 * (word0 + (int)(v >> 6)) + (int)((v >> 2) & 15u);
+                if (ci < n_cells) {
+                    const uint2 rc = reach[ci];
+                    const int x0 = (int)(rc.x & 0xffffu), x1 = (int)(rc.x >> 16), y0 = (int)(rc.y & 0xffffu), y1 = (int)(rc.y >> 16);
+                    if (x0 <= x1 && level_is_hot(v & 3u, cflags[ci])) {
+                        // (the rectangle and the tiles it overlaps: as widen_tile_boxes, scan_mark.h)
+                        const int xa = x0 - 4 > 0 ? x0 - 4 : 0, xb = x1 + 4 < a.W - 1 ? x1 + 4 : a.W - 1;
+                        const int ya = y0 - 4 > 0 ? y0 - 4 : 0, yb = y1 + 4 < a.H - 1 ? y1 + 4 : a.H - 1;
+                        const int ch0 = (int)(((uint32_t)ya * a.rows_magic) >> 23), ch1 = (int)(((uint32_t)yb * a.rows_magic) >> 23);
+                        const int st0 = (int)(((uint32_t)xa * 34953u) >> 23), st1 = (int)(((uint32_t)xb * 34953u) >> 23);
+                        for (int ch = ch0; ch <= ch1; ch++)
+                            for (int st = st0; st <= st1; st++) {
+                                const int t = ch * a.n_strips + st, q = t & 31;
+                                const uint32_t old = atomicCAS(&tab[q][0], 0xffffffffu, (uint32_t)t);
+                                if (old == 0xffffffffu || old == (uint32_t)t) {
+                                    atomicMin(&tab[q][1], (uint32_t)ya); atomicMax(&tab[q][2], (uint32_t)yb);
+                                    atomicMin(&tab[q][3], (uint32_t)xa); atomicMax(&tab[q][4], (uint32_t)xb);
+                                } else
+                                    widen(t, (uint32_t)ya, (uint32_t)yb, (uint32_t)xa, (uint32_t)xb);
+                            }
+                    }
                 }
             }
         }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier(); // (the list is rewritten by the next k)
     }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
     if (lane < 32 && tab[lane][0] != 0xffffffffu) widen((int)tab[lane][0], tab[lane][1], tab[lane][2], tab[lane][3], tab[lane][4]);
 }
 
@@ -493,8 +509,11 @@ __device__ __forceinline__ TileId decode_tile(const FilterArgs& a, int b)
 
 // LIST: instead of every tile of every image, the waves work through a list of (image, tile, first row, last row)
 // entries -- the tiles whose boxes settle_tiles_kernel found too wide for the box kernel to be the cheaper way.
+#ifndef MOCAP_ROWS_WAVES      // (build-time knob for A/B builds: registers of the row pipeline, scratch/build_variant.sh)
+#define MOCAP_ROWS_WAVES 1
+#endif
 template <bool REMAP, bool TINY, bool PIPE, bool LIST>
-__global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
+__global__ __attribute__((amdgpu_waves_per_eu(MOCAP_ROWS_WAVES))) __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
 {
     __shared__ uint32_t lut[256];
     __shared__ uint2 hring[4][8][64];
@@ -762,10 +781,10 @@ __global__ __launch_bounds__(256) void filter_mask_kernel(FilterArgs a)
 // rectangle of source pixels a band reads is known from a per-(row, strip) table made at set-up (rowbox), it is staged with
 // coalesced dword loads, zeros outside the image (cv::remap's BORDER_CONSTANT), while the previous band is being filtered.
 // Everything behind the remapped row -- horizontal sums, running vertical sums, threshold, window counts, majority -- is the
-// same arithmetic as above.  Requires W % 4 == 0, H >= 2, every slot's table in the compact format.
-constexpr int ROWS_STAGE_DW = 2304;              // dwords of source pixels per wave and band (9 KB; 61 KB of LDS per workgroup in all)
-constexpr int ROWS_LOADS = ROWS_STAGE_DW / 64;   // staging loads per lane at most
-constexpr int ROWS_LOADS_SHORT = 16;             // ... of a band whose rectangle is small (the usual one away from the corners)
+// same arithmetic as above.  Requires W % 16 == 0 (16-byte staging units), H >= 2, every slot's table in the compact format.
+constexpr int ROWS_LOADS = 9;                    // 16-byte staging loads per lane and band (always all of them: see stage_issue)
+constexpr int ROWS_STAGE_U = 64 * ROWS_LOADS;    // 16-byte units of source pixels per wave and band (9 KB; 61 KB of LDS per workgroup in all)
+constexpr int ROWS_STAGE_DW = 4 * ROWS_STAGE_U;
 
 // per (row, strip): box of the tap coordinates the row's pixels of the strip (columns 240 strip - 8 .. + 255) read, + 2
 __global__ void rowbox_kernel(const uint32_t* __restrict__ map4, ushort4* __restrict__ rowbox, int H, int W, int n_strips)
@@ -788,7 +807,11 @@ void launch_rowbox(const uint32_t* map4, ushort4* rowbox, int H, int W, int n_st
     hipLaunchKernelGGL(rowbox_kernel, dim3((n + 63) / 64), dim3(64), 0, s, map4, rowbox, H, W, n_strips);
 }
 
-struct BandRect { int sxa, sya, SP, SR, dpr, n; bool staged, interior; }; // source rectangle of a band: origin, pitch (bytes), rows, dwords per row, dwords
+// source rectangle of a band in 16-byte units: origin (sxa a multiple of 16), pitch SP bytes = q units, SR rows, n units; its part
+// inside the image: origin (ux0, iy0), iq units x iSR rows, first / last unit at li0 / llast of the rectangle
+typedef uint32_t rows_u32x4 __attribute__((ext_vector_type(4))); // (a native vector: an array of HIP's uint4 filled by memcpy stays in scratch memory)
+typedef rows_u32x4 rows_u32x4_any __attribute__((aligned(1)));   // ... at any address (unaligned access is enabled on amdhsa: one global_load_dwordx4)
+struct BandRect { int sxa, sya, SP, SR, q, n; int ux0, iy0, iq, in, li0, llast; bool staged, interior; }; // source rectangle of a band: origin, pitch (bytes), rows, dwords per row, dwords
 
 template <bool LIST>
 __global__ __launch_bounds__(256) void filter_rows_staged_kernel(FilterArgs a)
@@ -796,7 +819,7 @@ __global__ __launch_bounds__(256) void filter_rows_staged_kernel(FilterArgs a)
     __shared__ uint32_t lut[256];
     __shared__ uint2 hring[4][8][64];
     __shared__ uint32_t cring[4][8][64];
-    __shared__ uint32_t sbuf[4][ROWS_STAGE_DW];
+    __shared__ rows_u32x4 sbuf[4][ROWS_STAGE_U];
 
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform: keeps the row loop scalar
@@ -821,10 +844,10 @@ __global__ __launch_bounds__(256) void filter_rows_staged_kernel(FilterArgs a)
         for (int k = 0; k < 4; k++) v |= (uint32_t)__popc((i >> k) & 0x1fu) << (8 * k);
         lut[i] = v;
     }
-    uint32_t* const Sb = sbuf[wv];
+    rows_u32x4* const Sb = sbuf[wv];
     const uint8_t* const Sbytes = (const uint8_t*)Sb;
     // kernel arguments as plain scalars (a struct captured by the lambdas below would be kept in scratch memory)
-    const int H = a.H, W = a.W, Hm1 = a.H - 1, pitch = a.pitch, stage_dw = a.stage_dw, n_strips = a.n_strips, thr_mul = a.thr_mul;
+    const int H = a.H, W = a.W, Hm1 = a.H - 1, pitch = a.pitch, stage_units = a.stage_dw >> 2, n_strips = a.n_strips, thr_mul = a.thr_mul;
     const int rows_per_chunk = a.rows_per_chunk, n_cgroups = a.n_cgroups, cam_mod = a.cam_mod, words_per_row = a.words_per_row;
     const uint8_t* __restrict__ const a_src = a.src; const size_t a_image_stride = a.image_stride;
     const uint32_t* __restrict__ const a_map4 = a.map4; const ushort4* __restrict__ const a_rowbox = a.rowbox;
@@ -899,68 +922,69 @@ __global__ __launch_bounds__(256) void filter_rows_staged_kernel(FilterArgs a)
                 xa = oxa < xa ? oxa : xa; xb = oxb > xb ? oxb : xb; ya = oya < ya ? oya : ya; yb = oyb > yb ? oyb : yb;
             }
             BandRect R;
-            R.sxa = (__builtin_amdgcn_readfirstlane(xa) - 2) & ~3;
+            R.sxa = (__builtin_amdgcn_readfirstlane(xa) - 2) & ~15;
             const int sxb = __builtin_amdgcn_readfirstlane(xb) - 2;
             R.sya = __builtin_amdgcn_readfirstlane(ya) - 2;
             const int syb = __builtin_amdgcn_readfirstlane(yb) - 2;
-            R.SP = (sxb - R.sxa + 4) & ~3; R.SR = syb - R.sya + 1; R.dpr = R.SP >> 2; R.n = R.SR * R.dpr;
-            R.staged = R.n <= stage_dw;
-            R.interior = R.sxa >= 0 && R.sya >= 0 && R.sxa + R.SP <= W && R.sya + R.SR <= H; // no dword of it outside the image
+            R.SP = (sxb - R.sxa + 16) & ~15; R.SR = syb - R.sya + 1; R.q = R.SP >> 4; R.n = R.SR * R.q;
+            R.staged = R.n < stage_units; // (one unit is kept free: where the loads of a rectangle wholly outside the image end up)
+            // the part inside the image: W % 16 == 0 and an origin that is a multiple of 16 put every unit entirely inside or outside
+            const int ux1 = R.sxa + R.SP < W ? R.sxa + R.SP : W, iy1 = R.sya + R.SR < H ? R.sya + R.SR : H;
+            R.ux0 = R.sxa > 0 ? R.sxa : 0; R.iy0 = R.sya > 0 ? R.sya : 0;
+            R.iq = (ux1 - R.ux0) >> 4;
+            const int iSR = iy1 - R.iy0;
+            R.interior = R.iq == R.q && iSR == R.SR;
+            if (R.iq <= 0 || iSR <= 0) { // nothing of it inside the image: one unit from somewhere valid, parked behind the rectangle
+                R.iq = 1; R.in = 1; R.ux0 = 0; R.iy0 = 0; R.li0 = R.n; R.llast = R.n;
+            } else {
+                R.in = R.iq * iSR;
+                R.li0 = (R.iy0 - R.sya) * R.q + ((R.ux0 - R.sxa) >> 4);
+                R.llast = R.li0 + (iSR - 1) * R.q + R.iq - 1;
+            }
             return R;
         };
-        // the staging loads of a band, all in flight: lane -> dwords lane, lane + 64, ... of the rectangle (row-major), which is
-        // also where they go in LDS (the buffer holds 64 dwords per load, so every lane stores every load: no tests).  W % 4 == 0
-        // and an origin that is a multiple of 4 make every dword lie entirely inside or entirely outside the image.
-        // Interior rectangle (the usual case): the address walks on by a wave-uniform step with a carry into the next row --
-        // no division, no clamps; dwords past the rectangle re-read its last dword.
-        auto stage_issue = [&](const BandRect& R, auto& v, auto first_c) __attribute__((always_inline)) { // loads first .. first + size of v
-            constexpr int U0 = decltype(first_c)::value, NL = (int)(sizeof(v) / sizeof(v[0]));
-            const float rcpd = __builtin_amdgcn_rcpf((float)R.dpr);
-            if (R.interior) {
-                const int qr = (int)(64.5f * rcpd), rem = 64 - qr * R.dpr;      // 64 = qr * dpr + rem
-                int idx = lane + 64 * U0;
-                idx = idx < R.n ? idx : R.n - 1;
-                const int r0_ = (int)(((float)idx + 0.5f) * rcpd);
-                int c = idx - r0_ * R.dpr;
-                uint32_t goff = (uint32_t)(R.sya + r0_) * (uint32_t)pitch + (uint32_t)(R.sxa + 4 * c);
-                const uint32_t glast = (uint32_t)(R.sya + R.SR - 1) * (uint32_t)pitch + (uint32_t)(R.sxa + R.SP - 4);
-                const uint32_t step = (uint32_t)qr * (uint32_t)pitch + 4u * (uint32_t)rem, carry = (uint32_t)pitch - (uint32_t)R.SP;
+        // The staging loads of a band: ROWS_LOADS 16-byte loads per lane, ALWAYS all of them and never inside a branch (the
+        // counter that orders vector memory operations is counted at compile time: loads inside a branch make every later
+        // wait a wait for all of them), all in flight while the previous band is filtered.  Lane -> units lane, lane + 64, ... of
+        // the rectangle's part inside the image, row-major; the address and the place in LDS walk on by wave-uniform steps with a
+        // carry into the next row (no division, no clamps); units past the end repeat the last one (same address, same place).
+        struct StageWalk { int c; uint32_t goff; int li; };
+        auto stage_walk = [&](const BandRect& R, StageWalk& w, int& rem, uint32_t& gstep, uint32_t& gcarry, int& lstep, int& lcarry, uint32_t& glast) __attribute__((always_inline)) {
+            const float rcpd = __builtin_amdgcn_rcpf((float)R.iq);
+            const int qr = (int)(64.5f * rcpd); // 64 = qr * iq + rem
+            rem = 64 - qr * R.iq;
+            const int r0_ = (int)(((float)lane + 0.5f) * rcpd);
+            w.c = lane - r0_ * R.iq;
+            w.goff = (uint32_t)(R.iy0 + r0_) * (uint32_t)pitch + (uint32_t)(R.ux0 + 16 * w.c);
+            w.li = R.li0 + r0_ * R.q + w.c;
+            gstep = (uint32_t)qr * (uint32_t)pitch + 16u * (uint32_t)rem; gcarry = (uint32_t)pitch - 16u * (uint32_t)R.iq;
+            lstep = qr * R.q + rem; lcarry = R.q - R.iq;
+            const int rl = (R.in - 1) / R.iq; // (scalar)
+            glast = (uint32_t)(R.iy0 + rl) * (uint32_t)pitch + (uint32_t)(R.ux0 + 16 * (R.in - 1 - rl * R.iq));
+        };
+        auto stage_issue = [&](const BandRect& R, rows_u32x4 (&v)[ROWS_LOADS]) __attribute__((always_inline)) {
+            StageWalk w; int rem, lstep, lcarry; uint32_t gstep, gcarry, glast;
+            stage_walk(R, w, rem, gstep, gcarry, lstep, lcarry, glast);
 #pragma unroll
-                for (int u = 0; u < NL; u++) {
-                    __builtin_memcpy(&v[u], img + goff, 4);
-                    c += rem;
-                    goff += step;
-                    if (c >= R.dpr) { c -= R.dpr; goff += carry; }
-                    goff = goff < glast ? goff : glast;
-                }
-            } else {
-#pragma unroll
-                for (int u = 0; u < NL; u++) {
-                    int idx = lane + 64 * (U0 + u);
-                    idx = idx < R.n ? idx : R.n - 1;
-                    const int r = (int)(((float)idx + 0.5f) * rcpd), c = idx - r * R.dpr;
-                    const int gy = R.sya + r, gx = R.sxa + 4 * c;
-                    const int gyc = gy < 0 ? 0 : (gy > Hm1 ? Hm1 : gy), gxc = gx < 0 ? 0 : (gx > W - 4 ? W - 4 : gx);
-                    __builtin_memcpy(&v[u], img + ((uint32_t)gyc * (uint32_t)pitch + (uint32_t)gxc), 4);
-                }
+            for (int u = 0; u < ROWS_LOADS; u++) {
+                const uint32_t g = w.goff < glast ? w.goff : glast;
+                v[u] = *(const rows_u32x4_any*)(img + g);
+                w.c += rem; w.goff += gstep;
+                if (w.c >= R.iq) { w.c -= R.iq; w.goff += gcarry; }
             }
         };
-        auto stage_write = [&](const BandRect& R, const auto& v, auto first_c) __attribute__((always_inline)) {
-            constexpr int U0 = decltype(first_c)::value, NL = (int)(sizeof(v) / sizeof(v[0]));
-            if (R.interior) {
+        auto stage_write = [&](const BandRect& R, const rows_u32x4 (&v)[ROWS_LOADS]) __attribute__((always_inline)) {
+            if (!R.interior) { // units outside the image read 0 (cv::remap's BORDER_CONSTANT): clear, then the inside part on top
 #pragma unroll
-                for (int u = 0; u < NL; u++) Sb[lane + 64 * (U0 + u)] = v[u];
-            } else {
-                const float rcpd = __builtin_amdgcn_rcpf((float)R.dpr);
+                for (int u = 0; u < ROWS_LOADS; u++) Sb[lane + 64 * u] = rows_u32x4{0u, 0u, 0u, 0u};
+            }
+            StageWalk w; int rem, lstep, lcarry; uint32_t gstep, gcarry, glast;
+            stage_walk(R, w, rem, gstep, gcarry, lstep, lcarry, glast);
 #pragma unroll
-                for (int u = 0; u < NL; u++) {
-                    const int idx = lane + 64 * (U0 + u);
-                    const int ic = idx < R.n ? idx : R.n - 1;
-                    const int r = (int)(((float)ic + 0.5f) * rcpd), c = ic - r * R.dpr;
-                    const int gy = R.sya + r, gx = R.sxa + 4 * c;
-                    const bool inside = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-                    Sb[idx] = inside ? v[u] : 0u;
-                }
+            for (int u = 0; u < ROWS_LOADS; u++) {
+                Sb[w.li < R.llast ? w.li : R.llast] = v[u];
+                w.c += rem; w.li += lstep;
+                if (w.c >= R.iq) { w.c -= R.iq; w.li += lcarry; }
             }
         };
         auto table_issue = [&](uint4& tw, int row) __attribute__((always_inline)) {
@@ -968,11 +992,14 @@ __global__ __launch_bounds__(256) void filter_rows_staged_kernel(FilterArgs a)
             __builtin_memcpy(&tw, map4 + ((uint32_t)rc * (uint32_t)W + (uint32_t)lc.addr_x), 16);
         };
         // one remapped row of the strip: the lane's four pixels, blended exactly as cv::remap's fixed point does
-        auto blend_row = [&](const uint4& tw, int row, const BandRect& R) __attribute__((always_inline)) -> uint32_t {
+        // (STAGED is a compile-time flag chosen once per band: a branch inside every row would cut the unrolled rows into separate
+        // basic blocks, and the tap reads of one row could no longer be scheduled under the arithmetic of the previous one)
+        auto blend_row = [&](auto staged_c, const uint4& tw, int row, const BandRect& R) __attribute__((always_inline)) -> uint32_t {
+            constexpr bool STAGED = decltype(staged_c)::value;
             const int rc = row < 0 ? 0 : (row > Hm1 ? Hm1 : row);
             const uint32_t ww[4] = {tw.x, tw.y, tw.z, tw.w};
             uint32_t B = 0;
-            if (R.staged) {
+            if (STAGED) {
                 const int rowbase = __mul24(rc - R.sya, R.SP) + (lc.addr_x - R.sxa);
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -1057,44 +1084,43 @@ __global__ __launch_bounds__(256) void filter_rows_staged_kernel(FilterArgs a)
 
         // ---- band 0: the five rows y0 .. y0 + 4 of the set-up (ring slots 3 .. 7) ------------------------------------------
         uint4 tc[8], tn[8];  // table words of the band being filtered / of the next one
-        // staging loads in flight: the first ROWS_LOADS_SHORT of every band, the rest only for a large rectangle (two arrays: one
-        // array written in full on one path and in part on the other stays in scratch memory)
-        uint32_t sv[ROWS_LOADS_SHORT], sw[ROWS_LOADS - ROWS_LOADS_SHORT];
+        rows_u32x4 sv[ROWS_LOADS]; // staging loads in flight
         BandRect Rc = rect_reduce(rect_load(y0, 5));
-        const bool short0 = Rc.n <= 64 * ROWS_LOADS_SHORT;
-        if (Rc.staged) { stage_issue(Rc, sv, IC<0>{}); if (!short0) stage_issue(Rc, sw, IC<ROWS_LOADS_SHORT>{}); }
+        stage_issue(Rc, sv);
 #pragma unroll
         for (int j = 0; j < 5; j++) table_issue(tc[3 + j], y0 + j);
         // band 1 = the first rows of the steady loop: y0 + 5 = ks + 2 onwards
         int nr_next = ke - ks + 1 < 8 ? ke - ks + 1 : 8;
         ushort4 part = rect_load(ks + 2, nr_next > 0 ? nr_next : 1);
-        if (Rc.staged) { stage_write(Rc, sv, IC<0>{}); if (!short0) stage_write(Rc, sw, IC<ROWS_LOADS_SHORT>{}); }
-        // the next band's loads are issued before the current one is filtered, and land in LDS after it
+        stage_write(Rc, sv);
+        // the next band's loads are issued before the current one is filtered, and land in LDS after it.  Every band does this,
+        // the last one too (its successor's rows are clamped into the image and never used): no branch around a load
         BandRect Rn = Rc;
-        bool short_n = true;
         auto prefetch = [&](int first_row, int nr) __attribute__((always_inline)) { // rows first_row .. first_row + nr - 1 -> tn / sv
             Rn = rect_reduce(part);
-            short_n = Rn.n <= 64 * ROWS_LOADS_SHORT;
-            if (Rn.staged) { stage_issue(Rn, sv, IC<0>{}); if (!short_n) stage_issue(Rn, sw, IC<ROWS_LOADS_SHORT>{}); }
+            stage_issue(Rn, sv);
 #pragma unroll
             for (int j = 0; j < 8; j++) table_issue(tn[j], first_row + (j < nr ? j : nr - 1));
         };
         auto commit = [&]() __attribute__((always_inline)) { // the band just filtered has read its last tap: the next one moves in
-            if (Rn.staged) { stage_write(Rn, sv, IC<0>{}); if (!short_n) stage_write(Rn, sw, IC<ROWS_LOADS_SHORT>{}); }
+            stage_write(Rn, sv);
 #pragma unroll
             for (int j = 0; j < 8; j++) tc[j] = tn[j];
             Rc = Rn;
         };
-        if (nr_next > 0) {
-            prefetch(ks + 2, nr_next);
+        prefetch(ks + 2, nr_next > 0 ? nr_next : 1);
+        {
             const int n2 = ke - (ks + 8) + 1 < 8 ? ke - (ks + 8) + 1 : 8;
             part = rect_load(ks + 10, n2 > 0 ? n2 : 1); // (the band after that one: its box loads have a whole band's time)
         }
-        hsum_update(blend_row(tc[3], y0, Rc), 3, 6);
-        hsum_update(blend_row(tc[4], y0 + 1, Rc), 4, 7);
-        hsum_update(blend_row(tc[5], y0 + 2, Rc), 5, 0);
-        hsum_update(blend_row(tc[6], y0 + 3, Rc), 6, 1);
-        hsum_update(blend_row(tc[7], y0 + 4, Rc), 7, 2);
+        auto setup_rows = [&](auto staged_c) __attribute__((always_inline)) {
+            hsum_update(blend_row(staged_c, tc[3], y0, Rc), 3, 6);
+            hsum_update(blend_row(staged_c, tc[4], y0 + 1, Rc), 4, 7);
+            hsum_update(blend_row(staged_c, tc[5], y0 + 2, Rc), 5, 0);
+            hsum_update(blend_row(staged_c, tc[6], y0 + 3, Rc), 6, 1);
+            hsum_update(blend_row(staged_c, tc[7], y0 + 4, Rc), 7, 2);
+        };
+        if (Rc.staged) setup_rows(std::true_type{}); else setup_rows(std::false_type{});
         uint32_t c_cur = thresh_counts(kfirst);
         int cj = (r0 == 0) ? 5 : 7; // count-ring phase chosen so that the steady loop starts at slot 0
         push_counts(c_cur, cj & 7, (cj + 3) & 7);
@@ -1105,36 +1131,37 @@ __global__ __launch_bounds__(256) void filter_rows_staged_kernel(FilterArgs a)
             if (kk >= r0 + 2) emit(kk - 2, true);
         }
         // ---- steady state: bands of 8 rows; one source row in, one threshold row, one output row per step -------------------
-        auto step = [&](auto Jc, int k) __attribute__((always_inline)) {
+        auto step = [&](auto staged_c, auto Jc, int k) __attribute__((always_inline)) {
             constexpr int J = decltype(Jc)::value;
-            const uint32_t B = blend_row(tc[J], k + 2, Rc);
+            const uint32_t B = blend_row(staged_c, tc[J], k + 2, Rc);
             hsum_update(B, J, (J + 3) & 7);
             c_cur = thresh_counts(k);
             push_counts(c_cur, J, (J + 3) & 7);
             emit(k - 2, k >= r0 + 2);
         };
-        for (int k = ks; k <= ke; k += 8) {
-            if (nr_next > 0) commit(); // (the band of this iteration)
-            const int nst = ke - k + 1 < 8 ? ke - k + 1 : 8;
-            nr_next = ke - (k + 8) + 1 < 8 ? ke - (k + 8) + 1 : 8;
-            if (nr_next > 0) {
-                const int n2 = ke - (k + 16) + 1 < 8 ? ke - (k + 16) + 1 : 8;
-                const ushort4 part2 = rect_load(k + 18, n2 > 0 ? n2 : 1);
-                prefetch(k + 10, nr_next);
-                part = part2;
-            }
-            if (nst == 8) {
-                step(IC<0>{}, k); step(IC<1>{}, k + 1); step(IC<2>{}, k + 2); step(IC<3>{}, k + 3);
-                step(IC<4>{}, k + 4); step(IC<5>{}, k + 5); step(IC<6>{}, k + 6); step(IC<7>{}, k + 7);
+        auto band_steps = [&](auto staged_c, int k, int nst) __attribute__((always_inline)) {
+            if (nst == 8) { // one basic block: the rows' LDS reads and arithmetic interleave
+                step(staged_c, IC<0>{}, k); step(staged_c, IC<1>{}, k + 1); step(staged_c, IC<2>{}, k + 2); step(staged_c, IC<3>{}, k + 3);
+                step(staged_c, IC<4>{}, k + 4); step(staged_c, IC<5>{}, k + 5); step(staged_c, IC<6>{}, k + 6); step(staged_c, IC<7>{}, k + 7);
             } else {
-                step(IC<0>{}, k);
-                if (nst > 1) step(IC<1>{}, k + 1);
-                if (nst > 2) step(IC<2>{}, k + 2);
-                if (nst > 3) step(IC<3>{}, k + 3);
-                if (nst > 4) step(IC<4>{}, k + 4);
-                if (nst > 5) step(IC<5>{}, k + 5);
-                if (nst > 6) step(IC<6>{}, k + 6);
+                step(staged_c, IC<0>{}, k);
+                if (nst > 1) step(staged_c, IC<1>{}, k + 1);
+                if (nst > 2) step(staged_c, IC<2>{}, k + 2);
+                if (nst > 3) step(staged_c, IC<3>{}, k + 3);
+                if (nst > 4) step(staged_c, IC<4>{}, k + 4);
+                if (nst > 5) step(staged_c, IC<5>{}, k + 5);
+                if (nst > 6) step(staged_c, IC<6>{}, k + 6);
             }
+        };
+        for (int k = ks; k <= ke; k += 8) {
+            commit(); // (the band of this iteration)
+            const int nst = ke - k + 1 < 8 ? ke - k + 1 : 8;
+            {
+                const int n1 = ke - (k + 8) + 1 < 8 ? ke - (k + 8) + 1 : 8, n2 = ke - (k + 16) + 1 < 8 ? ke - (k + 16) + 1 : 8;
+                prefetch(k + 10, n1 > 0 ? n1 : 1);
+                part = rect_load(k + 18, n2 > 0 ? n2 : 1);
+            }
+            if (Rc.staged) band_steps(std::true_type{}, k, nst); else band_steps(std::false_type{}, k, nst);
         }
         // ---- rows below the image replicate the last row (only the bottom chunk gets here) ----
         {
@@ -1452,7 +1479,7 @@ int hot_map_words(int H, int W, int wide)
 }
 void launch_mark_tiles(const BrightArgs& a, hipStream_t s)
 {
-    const long long grid = (long long)((a.hot_words + 255) >> 8) * a.n_images;
+    const long long grid = (long long)((a.hot_words + 1023) >> 10) * a.n_images;
     hipLaunchKernelGGL(mark_tiles_kernel, dim3((unsigned)grid), dim3(256), 0, s, a);
 }
 void launch_undistort_map(const MapArgs& m, hipStream_t s)

@@ -27,7 +27,7 @@ struct FilterArgs {
     int thr_mul;          // floor(thresh)+1: blurred > thresh  <=>  S >= thr_mul * taps
     int rows_per_chunk, n_strips, n_cgroups;
     // the staged form of the row pipeline (filter_rows_staged_kernel): compact table, source pixels through LDS
-    int staged = 0;       // 1 = use it (remap variant; W % 4 == 0, H >= 2, every slot's table compact)
+    int staged = 0;       // 1 = use it (remap variant; W % 16 == 0, H >= 2, every slot's table compact)
     const uint32_t* map4 = nullptr; // compact table of the first slot used (see BoxArgs)
     const ushort4* rowbox = nullptr; // [cam_mod][H][n_strips]: per row and strip, the box of tap coordinates the strip's pixels read, + 2
     int stage_dw = 0;         // dwords of LDS a band's source rectangle may take (ROWS_STAGE_DW; smaller values are a test switch)
@@ -163,8 +163,8 @@ struct BrightArgs {
     int slices;                   // > 1: the pass goes out as that many launches over consecutive runs of images
     int image0, slice_images;     // set by launch_bright_cells: the images of this launch
     uint32_t* hotmap;             // [n_images][hot_words]: two bits per source cell, cell i of an image at bits 2 (i % 16) of word i / 16: how
-                                  //   many of the thresholds hot_corner <= hot_edge <= hot its sum exceeds.  Every word is written by the
-                                  //   scan (plain stores); mark_tiles_kernel reads it.  null = the scan marks the tiles itself
+                                  //   many of the thresholds hot_corner <= hot_edge <= hot its sum exceeds.  All zeros between batches: the scan
+                                  //   stores the words that are not zero, mark_tiles_kernel reads and clears them.  null = the scan marks the tiles itself
     int hot_words;                // words per image: hot_map_words(H, W, wide)
 };
 int hot_map_words(int H, int W, int wide);

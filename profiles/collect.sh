@@ -11,4 +11,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_d1 -o
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_m32d1 -o m32d1 -- python3 $R/bench.py --depth 1 --markers 32 $ARGS > $R/gpurun_out/prof_m32d1.json
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_fetch -o f -- python3 $R/bench.py --depth 1 --steps 3 --warmup 2 $ARGS > $R/gpurun_out/prof_fetch.json
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_write -o w -- python3 $R/bench.py --depth 1 --steps 3 --warmup 2 $ARGS > $R/gpurun_out/prof_write.json
+# the same two passes for BASELINE.json configs[2] (32 markers)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_fetch32 -o f -- python3 $R/bench.py --depth 1 --markers 32 --steps 3 --warmup 2 $ARGS > $R/gpurun_out/prof_fetch32.json
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_write32 -o w -- python3 $R/bench.py --depth 1 --markers 32 --steps 3 --warmup 2 $ARGS > $R/gpurun_out/prof_write32.json
 find $R/gpurun_out/prof_d3 $R/gpurun_out/prof_d1 $R/gpurun_out/prof_m32d1 $R/gpurun_out/prof_fetch $R/gpurun_out/prof_write -name "*.csv" | head -30

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turns the rocprofv3 output of profiles/collect.sh (gpurun_out/prof_*) into the summaries kept under profiles/:
-r03_kernel_stats_depth3_default.csv, r03_kernel_stats_depth1.csv (copies of rocprofv3's own kernel_stats),
-r03_pmc_FETCH_SIZE.csv / r03_pmc_WRITE_SIZE.csv (per-kernel averages in KB per launch) and hbm_traffic.json
+rNN_kernel_stats_depth3_default.csv, rNN_kernel_stats_depth1(_markers32).csv (copies of rocprofv3's own kernel_stats),
+rNN_pmc_FETCH_SIZE(_markers32).csv / rNN_pmc_WRITE_SIZE(_markers32).csv (per-kernel averages in KB per launch) and hbm_traffic.json
 (= (2 * FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch; FETCH_SIZE doubled per the MI355X guide's gfx950 rule)."""
 import csv
 import json
@@ -29,15 +29,18 @@ def pmc(path, counter, dst):
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
-def main():
-    shutil.copy(os.path.join(SRC, "prof_d3", "d3_kernel_stats.csv"), os.path.join(OUT, "r03_kernel_stats_depth3_default.csv"))
-    shutil.copy(os.path.join(SRC, "prof_d1", "d1_kernel_stats.csv"), os.path.join(OUT, "r03_kernel_stats_depth1.csv"))
-    if os.path.exists(os.path.join(SRC, "prof_m32d1", "m32d1_kernel_stats.csv")):  # BASELINE.json configs[2]: 32 markers
-        shutil.copy(os.path.join(SRC, "prof_m32d1", "m32d1_kernel_stats.csv"), os.path.join(OUT, "r03_kernel_stats_depth1_markers32.csv"))
-    fetch = pmc(os.path.join(SRC, "prof_fetch", "f_counter_collection.csv"), "FETCH_SIZE", os.path.join(OUT, "r03_pmc_FETCH_SIZE.csv"))
-    write = pmc(os.path.join(SRC, "prof_write", "w_counter_collection.csv"), "WRITE_SIZE", os.path.join(OUT, "r03_pmc_WRITE_SIZE.csv"))
+ROUND = "r04"
+SHORT = ("bright_cells_kernel", "mark_tiles_kernel", "settle_tiles_kernel", "box_filter_kernel", "filter_rows_staged_kernel", "filter_mask_kernel")
+
+
+def workload(tag_fetch, tag_write, suffix, key, markers):
+    fdir, wdir = os.path.join(SRC, tag_fetch), os.path.join(SRC, tag_write)
+    if not (os.path.isdir(fdir) and os.path.isdir(wdir)):
+        return None
+    fetch = pmc(os.path.join(fdir, "f_counter_collection.csv"), "FETCH_SIZE", os.path.join(OUT, f"{ROUND}_pmc_FETCH_SIZE{suffix}.csv"))
+    write = pmc(os.path.join(wdir, "w_counter_collection.csv"), "WRITE_SIZE", os.path.join(OUT, f"{ROUND}_pmc_WRITE_SIZE{suffix}.csv"))
     per = {}
-    for short in ("bright_cells_kernel", "settle_tiles_kernel", "box_filter_kernel", "filter_mask_kernel"):
+    for short in SHORT:
         kf = [k for k in fetch if short in k]
         kw = [k for k in write if short in k]
         if not kf and not kw:
@@ -46,16 +49,30 @@ def main():
         per[short] = int(round((2 * fetch[kf[0]] + write[kw[0]]) * 1024))
     scan_fetch = fetch[[k for k in fetch if "bright_cells_kernel" in k][0]]
     algo = FRAME_BYTES * IMAGES
-    doc = {"workload_key": "6x1920x1080-m8-mild", "dist": "mild", "images_per_launch": float(IMAGES), "markers": 8, "hbm_bytes_per_launch": per,
-           "derivation": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 from profiles/r03_pmc_FETCH_SIZE.csv / r03_pmc_WRITE_SIZE.csv (separate "
-                         "--pmc passes of `python bench.py --depth 1 --steps 3 --warmup 2 --cpu-steps 0 --no-secondary --no-extra`, "
-                         "profiles/collect.sh + summarize.py); FETCH_SIZE doubled per the MI355X guide's gfx950 rule, confirmed on this "
-                         "access pattern: bright_cells_kernel reads every frame byte exactly once (%d B per launch, 16-byte loads) "
-                         "and FETCH_SIZE reports %.1f KB = %.4f of it" % (algo, scan_fetch, scan_fetch * 1024 / algo)}
-    with open(os.path.join(OUT, "hbm_traffic.json"), "w") as f:
-        json.dump(doc, f, indent=1)
     total = sum(per.values())
-    print(json.dumps(per), "total", total, "= %.3f x algorithmic" % (total / algo))
+    print(key, json.dumps(per), "total", total, "= %.3f x algorithmic" % (total / algo))
+    return {"workload_key": key, "dist": "mild", "images_per_launch": float(IMAGES), "markers": markers, "hbm_bytes_per_launch": per,
+            "total_over_algorithmic": round(total / algo, 4),
+            "derivation": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 from profiles/%s_pmc_FETCH_SIZE%s.csv / %s_pmc_WRITE_SIZE%s.csv (separate --pmc "
+                          "passes of `python bench.py --depth 1 %s--steps 3 --warmup 2 --cpu-steps 0 --no-secondary --no-extra`, "
+                          "profiles/collect.sh + summarize.py); FETCH_SIZE doubled per the MI355X guide's gfx950 rule, confirmed on this "
+                          "access pattern: bright_cells_kernel reads every frame byte exactly once (%d B per launch, 16-byte loads) and "
+                          "FETCH_SIZE reports %.1f KB = %.4f of it" % (ROUND, suffix, ROUND, suffix, "--markers 32 " if markers == 32 else "",
+                                                                     algo, scan_fetch, scan_fetch * 1024 / algo)}
+
+
+def main():
+    for tag, name in (("prof_d3", "depth3_default"), ("prof_d1", "depth1"), ("prof_m32d1", "depth1_markers32")):
+        src = os.path.join(SRC, tag, tag[5:] + "_kernel_stats.csv")
+        if os.path.exists(src):
+            shutil.copy(src, os.path.join(OUT, f"{ROUND}_kernel_stats_{name}.csv"))
+    docs = {}
+    for args in (("prof_fetch", "prof_write", "", "6x1920x1080-m8-mild", 8), ("prof_fetch32", "prof_write32", "_markers32", "6x1920x1080-m32-mild", 32)):
+        d = workload(*args)
+        if d:
+            docs[d["workload_key"]] = d
+    with open(os.path.join(OUT, "hbm_traffic.json"), "w") as f:
+        json.dump({"workloads": docs}, f, indent=1)
 
 
 if __name__ == "__main__":

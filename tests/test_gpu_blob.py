@@ -131,7 +131,7 @@ def test_borders_against_scipy_labels_and_picks_theorem(torch_cuda):
 
 @pytest.mark.parametrize("W,H", [(64, 48), (250, 130), (251, 77), (500, 300), (960, 540)])
 @pytest.mark.parametrize("scale", [1.0, 4.0, -3.0])
-@pytest.mark.parametrize("mode", ["box", "box_unstaged", "dense", "dense_smallstage", "dense_unstaged", "dense_general", "dense_gather", "dense_boxes"])
+@pytest.mark.parametrize("mode", ["box", "box_unstaged", "dense", "dense_staged", "dense_smallstage", "dense_unstaged", "dense_gather", "dense_boxes"])
 def test_filter_mask_remap(torch_cuda, monkeypatch, W, H, scale, mode):
     """The remap variants -- the box kernel with its source pixels staged in LDS (the product path), the same with the
     taps taken from memory (what it does when a box's source region outgrows the LDS buffer), the dense kernel with its
@@ -142,15 +142,15 @@ def test_filter_mask_remap(torch_cuda, monkeypatch, W, H, scale, mode):
     if mode == "box_unstaged":
         monkeypatch.setenv("MOCAP_BOX_STAGE_BYTES", "0")
     if mode.startswith("dense_") or mode == "dense":
-        monkeypatch.setenv("MOCAP_GENERAL_FILTER", "1")  # "dense": the staged row pipeline (compact table, source pixels through LDS)
+        monkeypatch.setenv("MOCAP_GENERAL_FILTER", "1")  # the dense path: the row pipeline on the general 8-byte tables (pipelined gather)
+    if mode in ("dense_staged", "dense_smallstage", "dense_unstaged"):
+        monkeypatch.setenv("MOCAP_ROWS_STAGED", "1")      # ... on the compact table, source pixels through LDS
     if mode == "dense_smallstage":
         monkeypatch.setenv("MOCAP_ROWS_STAGE_DW", "600")  # ... with a buffer some bands' source rectangles outgrow
     if mode == "dense_unstaged":
         monkeypatch.setenv("MOCAP_ROWS_STAGE_DW", "0")    # ... every band's taps from memory
-    if mode in ("dense_general", "dense_gather"):
-        monkeypatch.setenv("MOCAP_ROWS_STAGED", "0")      # the row pipeline on the general 8-byte tables
     if mode == "dense_gather":
-        monkeypatch.setenv("MOCAP_REMAP_PIPELINE", "0")
+        monkeypatch.setenv("MOCAP_REMAP_PIPELINE", "0")   # ... the general tables with the per-pixel gather
     if mode == "dense_boxes":
         monkeypatch.setenv("MOCAP_SKIP_DARK", "0")
         monkeypatch.setenv("MOCAP_DENSE_BOXES", "1")
@@ -763,8 +763,9 @@ def test_blob_centroids_from_bayer_equals_the_two_steps(torch_cuda, monkeypatch,
     {"MOCAP_WIDE_QUADS": "0,0"},                              # every marked tile through the row pipeline's list form
     {"MOCAP_WIDE_QUADS": "1000,1000"},                        # every marked tile through the box kernel
     {"MOCAP_WIDE_QUADS": "0,0", "MOCAP_WIDE_BANDS": "3"},     # ... its rows cut into bands
-    {"MOCAP_WIDE_QUADS": "0,0", "MOCAP_ROWS_STAGED": "0"},    # ... on the general tables with tap gathers
-    {"MOCAP_WIDE_QUADS": "0,0", "MOCAP_ROWS_STAGE_DW": "500"},  # ... staged, with a buffer too small for some bands
+    {"MOCAP_WIDE_QUADS": "0,0", "MOCAP_ROWS_STAGED": "1"},    # ... on the compact table, source pixels staged in LDS
+    {"MOCAP_WIDE_QUADS": "0,0", "MOCAP_ROWS_STAGED": "1", "MOCAP_ROWS_STAGE_DW": "500"},  # ... with a buffer too small for some bands
+    {"MOCAP_WIDE_QUADS": "0,0", "MOCAP_WIDE_BLOCKS_PER_CU": "4"},
     {"MOCAP_WIDE_QUADS": "0,0", "MOCAP_WIDE_FORK": "1"},      # ... on the side stream beside the box kernel
     {"MOCAP_EXCESS_BASE": "0"}, {"MOCAP_EXCESS_BASE": "100"}, {"MOCAP_EXCESS_BASE": "200"},  # pinned excess bases
     {"MOCAP_BASE_SEL": "0"},                                  # start with the tight base (then adapt)
@@ -776,6 +777,7 @@ def test_blob_centroids_from_bayer_equals_the_two_steps(torch_cuda, monkeypatch,
     {"MOCAP_SCAN_SLICES": "5"},                               # the scan in five launches over runs of images
     {"MOCAP_SCAN_SLICES": "3", "MOCAP_SCAN_BLOCKS_PER_CU": "2", "MOCAP_SCAN_WIDE": "0"},
     {"MOCAP_CORR_THREADS": "64"},
+    {"MOCAP_SCAN_SERIAL": "0"},                               # scans of different contexts may share the chip
     {"MOCAP_SCAN_HOTMAP": "0"},                               # the scan marks the tiles itself instead of leaving the hot map
     {"MOCAP_SCAN_HOTMAP": "0", "MOCAP_SCAN_WIDE": "0"},
     {"MOCAP_SCAN_WIDE": "0"},                                 # the hot map from the 8-byte-load form of the scan (16 lanes per word)
