@@ -282,7 +282,7 @@ def batch_index(i, depth, n_batches):
     return (i % n_batches) if depth % n_batches else ((i + i // depth) % n_batches)
 
 
-KERNELS = (("scan", "bright_cells_kernel"), ("settle", "mark_tiles_kernel + settle_tiles_kernel"), ("filter", "box_filter_kernel + filter_rows_staged_kernel (wide tiles)"))
+KERNELS = (("scan", "bright_cells_kernel"), ("settle", "mark_tiles_kernel + settle_tiles_kernel"), ("filter", "box_filter_kernel + filter_mask_kernel (wide tiles)"))
 
 
 def roofline_of(prof, wl, n_images, n_launch_groups, traffic_key):
@@ -337,7 +337,7 @@ def roofline_of(prof, wl, n_images, n_launch_groups, traffic_key):
         # frame -> centroid: the filter stage plus the contour kernel (north_star's 'blob-centroid kernel' as a whole)
         cms = prof["contour_ms"] / prof["contour_launches"]
         b2c = bytes_img * per_launch / ((stage_ms + cms) * 1e-3) / 1e9
-        roof["blob_to_centroid"] = {"kernel": roof["kernel"] + " + contour_candidates_kernel + contour_follow_kernel (two passes) + contours_kernel<2> (two passes)", "avg_launch_ms": round(stage_ms + cms, 4),
+        roof["blob_to_centroid"] = {"kernel": roof["kernel"] + " + contours_kernel<1> (candidates) + contour_follow_kernel (two passes) + contours_kernel<2> (tree, two passes)", "avg_launch_ms": round(stage_ms + cms, 4),
                                     "achieved": round(b2c, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b2c / HBM_PEAK_GBS, 4)}
     return roof
 
@@ -604,31 +604,31 @@ def main():
         return {"workload": f"one time step of {wl.cameras} cameras, {wl.width}x{wl.height}, frames resident, launch to synchronised result",
                 "latency_one_time_step_ms": round(ms, 4), "repetitions": n_rep, "points": n, "matches_oracle": bool(ok)}
 
-    def replay_section(wl, m, batch=128, runs=4):
+    def replay_section(wl, m, runs=4):
         """N3: the headless replay tracker (mocapv2_amd/replay.py = track_points + track, RealtimeTracking_FLIR.py:95-143,157-209)
-        over device-resident frames: batches of `batch` time steps, three in flight, INCLUDING the read-back of every batch, the
-        obj_count + 1 selection (lib/Helpers.py:274-279) and one msgpack message per time step (RealtimeTracking_FLIR.py:183-188)."""
+        over device-resident frames: the resident batches as one recording, batches of the headline size, three in flight, INCLUDING
+        the read-back of every batch, the obj_count + 1 selection (lib/Helpers.py:274-279) and one msgpack message per time step
+        (RealtimeTracking_FLIR.py:183-188)."""
         import oracle
         from mocapv2_amd.replay import OBJ_COUNT, ReplayTracker, tracker_message
         T = m["T"]
-        frames = m["batches"][0].reshape(T, wl.cameras, wl.height, wl.width)
-        rp = ReplayTracker(*m["arrays"], wl.width, wl.height, batch=batch, max_points=wl.max_points, max_groups=wl.max_groups, depth=3)
-        first = list(rp.run(frames[:batch]))  # warm-up + the results that are checked
+        shape = (T, wl.cameras, wl.height, wl.width)
+        recording = [b.reshape(shape) for b in m["batches"]] * runs
+        rp = ReplayTracker(*m["arrays"], wl.width, wl.height, batch=T, max_points=wl.max_points, max_groups=wl.max_groups, depth=3)
+        first = list(rp.run(recording[0]))  # warm-up + the results that are checked
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         n_steps = 0
-        for _ in range(runs):
-            for res in rp.run_batches(frames):
-                n_steps += res["n_steps"]
+        for res in rp.run_batches(recording):
+            n_steps += res["n_steps"]
         dt_bulk = time.perf_counter() - t0
         t0 = time.perf_counter()
         n_gen = 0
-        for _ in range(runs):
-            for _res in rp.run(frames):
-                n_gen += 1
+        for _res in rp.run(recording):
+            n_gen += 1
         dt_gen = time.perf_counter() - t0
         # the first time steps against the oracle: object points, image points, message bytes
-        frames_tc = m["frames_host"].reshape(T, wl.cameras, wl.height, wl.width)
+        frames_tc = m["frames_host"].reshape(shape)
         ok, point = True, [0] * 8
         for s in range(2):
             _, ref = oracle_time_step(wl, m["arrays"], frames_tc[s])
@@ -639,7 +639,7 @@ def main():
             ok = ok and len(got["object_points"]) == len(obj) and (len(obj) == 0 or float(np.abs(got["object_points"] - obj).max()) < 1e-7)
             ok = ok and (ref is None or len(ref["root"]) == 0 or np.array_equal(got["image_points"], ref["groups"].astype(np.int64)))
             ok = ok and got["message"][:15] == tracker_message(point)[:15] and len(got["message"]) == len(tracker_message(point))
-        return {"workload": f"ReplayTracker(batch={batch}, depth=3) over {runs} x {T} time steps of the headline frames, device-resident",
+        return {"workload": f"ReplayTracker(batch={T}, depth=3) over {len(recording)} x {T} time steps of the headline frames, device-resident",
                 "value": round(n_steps / dt_bulk, 1), "unit": "time steps/s", "form": "run_batches: results and messages per batch, built in bulk",
                 "per_time_step_generator": {"value": round(n_gen / dt_gen, 1), "unit": "time steps/s",
                                             "form": "run: one Python dict per time step (the generator itself is the bound)"},

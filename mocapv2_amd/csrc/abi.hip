@@ -98,6 +98,8 @@ struct Tuning {
     int probe_debug = 0;
     int contour_boxes = 1;       // 0 = candidates from whole strips
     int contours_split = 1;      // 0 = the contour stage as one kernel per image
+    int mark_blocks_per_cu = 0;  // > 0: mark_tiles_kernel as that many workgroups per CU whose waves loop over the hot map
+    int contour_blocks_per_cu = 0; // > 0: the per-image contour kernels (candidates, tree) as that many workgroups per CU looping over the images
     int corr_threads = 256;      // threads per time step of the correspondence kernel (64 / 128 / 256)
     int corr_step_groups = 0;    // candidate groups one time step may hold in all (error scratch per step); 0 = max(2 * max_groups, 8192)
 };
@@ -112,7 +114,7 @@ static const TuneName kTuneNames[] = {
     {"box_blocks_per_cu", &Tuning::box_blocks_per_cu, 0, 32}, {"box_timing", &Tuning::box_timing, 0, 1},
     {"contour_timing", &Tuning::contour_timing, 0, 1}, {"follow_timing", &Tuning::follow_timing, 0, 2}, {"scan_wide", &Tuning::scan_wide, 0, 1}, {"scan_hotmap", &Tuning::scan_hotmap, 0, 1}, {"scan_serial", &Tuning::scan_serial, 0, 1}, {"rows_staged", &Tuning::rows_staged, 0, 1}, {"wide_blocks_per_cu", &Tuning::wide_blocks_per_cu, 1, 8}, {"rows_stage_dw", &Tuning::rows_stage_dw, -1, 1 << 20}, {"scan_blocks_per_cu", &Tuning::scan_blocks_per_cu, 0, 64}, {"scan_slices", &Tuning::scan_slices, 1, 64}, {"excess_base", &Tuning::excess_base, -1, 254},
     {"base_sel", &Tuning::base_sel, 0, 1}, {"probe_debug", &Tuning::probe_debug, 0, 1}, {"contour_boxes", &Tuning::contour_boxes, 0, 1},
-    {"contours_split", &Tuning::contours_split, 0, 1}, {"corr_threads", &Tuning::corr_threads, 64, 256},
+    {"contours_split", &Tuning::contours_split, 0, 1}, {"contour_blocks_per_cu", &Tuning::contour_blocks_per_cu, 0, 16}, {"mark_blocks_per_cu", &Tuning::mark_blocks_per_cu, 0, 16}, {"corr_threads", &Tuning::corr_threads, 64, 256},
     {"corr_step_groups", &Tuning::corr_step_groups, 0, 0x7fffffff},
 };
 static bool tune_set(Tuning& t, const char* name, int v)
@@ -751,7 +753,7 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
         // the streaming scan leaves a hot map (two bits per cell, no table lookups or atomics behind its loads) that
         // mark_tiles_kernel turns into tile boxes; the fused Bayer pass marks the tiles itself (MOCAP_SCAN_HOTMAP=0: so does the scan)
         const bool two_step = !fused && c->tune.scan_hotmap && c->hotmap;
-        if (two_step) { b.hotmap = c->hotmap; b.hot_words = hot_map_words(c->H, c->W, wide); }
+        if (two_step) { b.hotmap = c->hotmap; b.hot_words = hot_map_words(c->H, c->W, wide); b.mark_grid = c->tune.mark_blocks_per_cu * c->n_cu; }
         ScanTurn* turn = c->tune.scan_serial && c->device >= 0 && c->device < 64 ? &g_scan_turn[c->device] : nullptr;
         std::unique_lock<std::mutex> turn_lock;
         if (turn) {
@@ -894,6 +896,7 @@ static int run_contours(mocap_ctx* c, const uint32_t* mask, const uint32_t* cell
     a.walk_list = split ? c->walk_list : nullptr; a.link_list = c->link_list; a.walk_count = c->walk_count;
     a.follow_grid = c->n_cu * 4;  // 4 one-wave workgroups per CU (33 KB of LDS each): persistent, they refill their lanes from the list
     a.follow_grid2 = c->n_cu;     // the link walks are few
+    a.image_grid = c->tune.contour_blocks_per_cu * c->n_cu;
     a.wait_list = (uint32_t*)((uint8_t*)c->link_list + contour_link_bytes() * c->cwork_images);
     a.follow_list = 0; a.tree_pass = 0; a.follow_dbg = nullptr; a.follow_dbg_list = c->tune.follow_timing == 2 ? 1 : 0;
     if (c->tune.follow_timing && split) {

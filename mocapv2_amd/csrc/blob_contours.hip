@@ -21,7 +21,7 @@
 // Tree order (parent = enclosing border, siblings in reverse discovery order, pre-order walk) is rebuilt from
 // "which border owns the crack left of my start pixel": from the bounding boxes when that is unambiguous, else by
 // following that border once -- as one more entry of a (second) walk list.
-// Five launches per batch: contour_candidates_kernel (one workgroup of 4 waves per image) -> contour_follow_kernel (persistent
+// Five launches per batch: contours_kernel<1> = the candidates kernel (one workgroup of 4 waves per image, or a fixed grid looping) -> contour_follow_kernel (persistent
 // waves, every walk of the batch whatever image it belongs to) -> contours_kernel<2> (tree and output, one workgroup per image;
 // images with an ambiguous link wait) -> contour_follow_kernel (the link walks) -> contours_kernel<2> (the images that waited);
 // the hand-over is the per-image global workspace (L2) and the two batch-wide walk lists.  contours_kernel<0> is the same work
@@ -778,18 +778,30 @@ __device__ __forceinline__ void contours_body(const ContourArgs& a, const int im
 // One workgroup per image.  The second tree pass runs over the list of the images that wait for link walks (mostly none: its
 // workgroups read one counter and leave).  (The kernels as loops over the images, fewer workgroups than images: 19 more registers for
 // the candidates kernel, 42 for the tree kernel, 8 us slower each, nothing gained in the pipeline -- profiles/README.md.)
-template <int MODE>
+// LOOP: a fixed grid (a few workgroups per CU) works through the images -- workgroup b takes b, b + grid, ... -- instead of one
+// workgroup per image.  Alone that is a few microseconds slower (more registers), but beside another batch's streaming scan, which
+// holds every wave slot of the chip, each of 3072 four-wave workgroups has to wait for a place of its own: the tree kernel, 12 us
+// alone, took 0.34-0.60 ms there, the candidates kernel 0.27-0.52 instead of 0.08 (profiles/history/r4_timeline_depth3.txt).
+template <int MODE, bool LOOP>
 __global__ __launch_bounds__(NTHREADS) void contours_kernel(ContourArgs a)
 {
-    int image = blockIdx.x;
-    if (MODE == 2 && a.tree_pass == 2) {
-        if ((uint32_t)image >= a.walk_count[4]) return;
-        image = uni((int)a.wait_list[image]);
+    if (MODE == 2 && a.tree_pass == 2) { // the images that waited for link walks (mostly none): a small grid over their list
+        const uint32_t n = a.walk_count[4];
+        for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
+            contours_body<MODE>(a, uni((int)a.wait_list[e]));
+            __syncthreads(); // (the next image reuses the workgroup's LDS)
+        }
+        return;
     }
-    contours_body<MODE>(a, image);
+    if (!LOOP) {
+        contours_body<MODE>(a, blockIdx.x);
+        return;
+    }
+    for (int image = blockIdx.x; image < a.n_images; image += gridDim.x) {
+        contours_body<MODE>(a, image);
+        __syncthreads();
+    }
 }
-// (capping the candidates kernel at 72 registers for 7 workgroups per CU instead of 5 spills 13 of them: 325 k against 337 k frames/s)
-__global__ __launch_bounds__(NTHREADS) void contour_candidates_kernel(ContourArgs a) { contours_body<1>(a, blockIdx.x); }
 
 // The walks of the whole batch, whatever image they belong to, TWO LANES PER BORDER: lane 2i follows the border forwards from
 // its start, lane 2i + 1 backwards from the same start (border following is reversible: the backward walk is the forward rule
@@ -1139,18 +1151,22 @@ void launch_contours(const ContourArgs& a_, hipStream_t s)
         // through a second, equally packed, follow pass, and the second tree pass finishes the images that waited for them
         ContourArgs a = a_;
         (void)hipMemsetAsync(a.walk_count, 0, 8 * sizeof(uint32_t), s);
-        hipLaunchKernelGGL(contour_candidates_kernel, dim3(a.n_images), dim3(NTHREADS), 0, s, a);
+        const bool loop = a.image_grid > 0 && a.image_grid < a.n_images;
+        const int pass2_grid = a.n_images < 64 ? a.n_images : 64;
+        if (loop) hipLaunchKernelGGL((contours_kernel<1, true>), dim3(a.image_grid), dim3(NTHREADS), 0, s, a);
+        else hipLaunchKernelGGL((contours_kernel<1, false>), dim3(a.n_images), dim3(NTHREADS), 0, s, a);
         a.follow_list = 0;
         hipLaunchKernelGGL(contour_follow_kernel, dim3(a.follow_grid), dim3(64), 0, s, a);
         a.tree_pass = 1;
-        hipLaunchKernelGGL(contours_kernel<2>, dim3(a.n_images), dim3(NTHREADS), 0, s, a);
+        if (loop) hipLaunchKernelGGL((contours_kernel<2, true>), dim3(a.image_grid), dim3(NTHREADS), 0, s, a);
+        else hipLaunchKernelGGL((contours_kernel<2, false>), dim3(a.n_images), dim3(NTHREADS), 0, s, a);
         a.follow_list = 1;
         hipLaunchKernelGGL(contour_follow_kernel, dim3(a.follow_grid2), dim3(64), 0, s, a);
         a.tree_pass = 2;
-        hipLaunchKernelGGL(contours_kernel<2>, dim3(a.n_images), dim3(NTHREADS), 0, s, a);
+        hipLaunchKernelGGL((contours_kernel<2, false>), dim3(pass2_grid), dim3(NTHREADS), 0, s, a);
         return;
     }
-    hipLaunchKernelGGL(contours_kernel<0>, dim3(a_.n_images), dim3(NTHREADS), 0, s, a_);
+    hipLaunchKernelGGL((contours_kernel<0, false>), dim3(a_.n_images), dim3(NTHREADS), 0, s, a_);
 }
 
 } // namespace mocap

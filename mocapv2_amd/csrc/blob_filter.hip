@@ -350,9 +350,12 @@ __global__ __launch_bounds__(256) void mark_tiles_kernel(BrightArgs a)
     __shared__ uint16_t s_list[4][1024];
     __shared__ uint32_t s_tab[4][32][5]; // tile | first row | last row | first column | last column
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int wb = (a.hot_words + 1023) >> 10; // workgroups per image: a wave takes 256 consecutive words (4 per lane)
-    const int image = blockIdx.x / wb, wave_word0 = (blockIdx.x - image * wb) * 1024 + wv * 256;
+    // a wave takes 256 consecutive words (4 per lane) of one image at a time; with a fixed grid (a few workgroups per CU) the
+    // waves go on to further pieces: few workgroups to place beside another batch's scan, which holds every wave slot of the chip
+    const int wpi = (a.hot_words + 255) >> 8; // pieces per image
     const int n_cells = ((a.W + 7) >> 3) * ((a.H + 7) >> 3);
+    for (long long piece = (long long)blockIdx.x * 4 + wv; piece < (long long)wpi * a.n_images; piece += (long long)gridDim.x * 4) {
+    const int image = (int)(piece / wpi), wave_word0 = (int)(piece - (long long)image * wpi) * 256;
     uint32_t* __restrict__ hm = a.hotmap + (size_t)image * a.hot_words;
     uint32_t wk[4];
 #pragma unroll
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(256) void mark_tiles_kernel(BrightArgs a)
         const int wi = wave_word0 + 64 * k + lane;
         wk[k] = wi < a.hot_words ? hm[wi] : 0u;
     }
-    if (__ballot((wk[0] | wk[1] | wk[2] | wk[3]) != 0u) == 0ull) return;
+    if (__ballot((wk[0] | wk[1] | wk[2] | wk[3]) != 0u) == 0ull) continue;
 #pragma unroll
     for (int k = 0; k < 4; k++)
         if (wk[k] != 0u) hm[wave_word0 + 64 * k + lane] = 0u; // the map is all zeros again for the next batch's scan
@@ -432,6 +435,9 @@ __global__ __launch_bounds__(256) void mark_tiles_kernel(BrightArgs a)
         __builtin_amdgcn_wave_barrier(); // (the list is rewritten by the next k)
     }
     if (lane < 32 && tab[lane][0] != 0xffffffffu) widen((int)tab[lane][0], tab[lane][1], tab[lane][2], tab[lane][3], tab[lane][4]);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier(); // (the table is initialised anew for the wave's next piece)
+    }
 }
 
 // The grid is one-dimensional: workgroup b takes the blocks b, b + gridDim.x, ... of the batch's blocks_x * n_images blocks
@@ -1479,7 +1485,8 @@ int hot_map_words(int H, int W, int wide)
 }
 void launch_mark_tiles(const BrightArgs& a, hipStream_t s)
 {
-    const long long grid = (long long)((a.hot_words + 1023) >> 10) * a.n_images;
+    long long grid = ((long long)((a.hot_words + 255) >> 8) * a.n_images + 3) / 4; // one piece per wave ...
+    if (a.mark_grid > 0 && a.mark_grid < grid) grid = a.mark_grid;                  // ... or a fixed grid whose waves loop
     hipLaunchKernelGGL(mark_tiles_kernel, dim3((unsigned)grid), dim3(256), 0, s, a);
 }
 void launch_undistort_map(const MapArgs& m, hipStream_t s)

@@ -129,6 +129,7 @@ struct ContourArgs {
     uint32_t* wait_list;   // split form: [n_images] the images the first tree pass left to the second one
     int follow_grid;       // split form: workgroups (waves) of the follow kernel
     int follow_grid2;      //   ... of its second pass (the link walks: few)
+    int image_grid;        // split form: > 0 = the per-image kernels (candidates, tree) as that many workgroups looping over the images
     int follow_list;       // set by launch_contours: 0 = the follow kernel works through walk_list, 1 = through link_list
     int tree_pass;         // set by launch_contours: 1 / 2 = first / second pass of the tree kernel
     uint64_t* follow_dbg;  // optional [follow_grid][8] phase clock of the follow kernel (follow_timing = 1: first pass, 2: second), else null
@@ -166,6 +167,7 @@ struct BrightArgs {
                                   //   many of the thresholds hot_corner <= hot_edge <= hot its sum exceeds.  All zeros between batches: the scan
                                   //   stores the words that are not zero, mark_tiles_kernel reads and clears them.  null = the scan marks the tiles itself
     int hot_words;                // words per image: hot_map_words(H, W, wide)
+    int mark_grid;                // > 0: workgroups of mark_tiles_kernel (its waves loop over the map); 0 = one piece per wave
 };
 int hot_map_words(int H, int W, int wide);
 void launch_mark_tiles(const BrightArgs& a, hipStream_t s); // hot map -> tile boxes (tile_rows), behind launch_bright_cells

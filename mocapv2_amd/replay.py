@@ -60,27 +60,30 @@ class ReplayTracker:
         return xyz[idx]
 
     def _submit(self, frames):
-        """Generator over the batches of `frames`, each submitted to the GPU: (first time step, time steps, outputs), at most
-        `depth` of them in flight, oldest first."""
-        T = frames.shape[0]
-        assert frames.shape[1:] == (self.n_cam, self.height, self.width), frames.shape
+        """Generator over the batches of `frames` (one array / tensor [T, C, H, W], or a list of such pieces), each submitted to the
+        GPU: (first time step, time steps, outputs), at most `depth` of them in flight, oldest first."""
         dev = self.tracker.ctx.device
         pending = []  # batches submitted and not yet read back; at most depth - 1 wait here
-        for b0 in range(0, T, self.batch):
-            chunk = frames[b0:b0 + self.batch]
-            nb = chunk.shape[0]
-            if isinstance(chunk, np.ndarray):
-                chunk = torch.from_numpy(np.ascontiguousarray(chunk))
-            # depth 1: the plain blocking copy.  Deeper pipelines upload asynchronously (a pinned caller tensor is then read later:
-            # the caller must leave frames[b0:b0 + batch] untouched until that batch's results have been yielded)
-            chunk = chunk.to(dev, non_blocking=self.depth > 1)
-            if nb < self.batch:  # pad the last batch with black frames (they produce no points)
-                pad = torch.zeros((self.batch - nb,) + tuple(chunk.shape[1:]), dtype=torch.uint8, device=dev)
-                chunk = torch.cat([chunk, pad], dim=0)
-            out = self.tracker.step(chunk.reshape(self.batch * self.n_cam, self.height, self.width).contiguous())
-            pending.append((b0, nb, out))
-            if len(pending) >= self.depth:  # the oldest batch's lane is the next one to be reused: read it back first
-                yield pending.pop(0)
+        parts = frames if isinstance(frames, (list, tuple)) else [frames]  # a recording in several pieces: one after the other
+        t_base = 0
+        for part in parts:
+            assert part.shape[1:] == (self.n_cam, self.height, self.width), part.shape
+            for p0 in range(0, part.shape[0], self.batch):
+                chunk = part[p0:p0 + self.batch]
+                nb = chunk.shape[0]
+                if isinstance(chunk, np.ndarray):
+                    chunk = torch.from_numpy(np.ascontiguousarray(chunk))
+                # depth 1: the plain blocking copy.  Deeper pipelines upload asynchronously (a pinned caller tensor is then read
+                # later: the caller must leave that piece of the frames untouched until the batch's results have been yielded)
+                chunk = chunk.to(dev, non_blocking=self.depth > 1)
+                if nb < self.batch:  # pad the last batch with black frames (they produce no points)
+                    pad = torch.zeros((self.batch - nb,) + tuple(chunk.shape[1:]), dtype=torch.uint8, device=dev)
+                    chunk = torch.cat([chunk, pad], dim=0)
+                out = self.tracker.step(chunk.reshape(self.batch * self.n_cam, self.height, self.width).contiguous())
+                pending.append((t_base + p0, nb, out))
+                if len(pending) >= self.depth:  # the oldest batch's lane is the next one to be reused: read it back first
+                    yield pending.pop(0)
+            t_base += part.shape[0]
         while pending:
             yield pending.pop(0)
 
