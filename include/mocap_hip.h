@@ -81,7 +81,7 @@ MOCAP_API int mocap_set_blob_params(mocap_ctx_t ctx, const mocap_blob_params* p)
  * size a scratch buffer.  mocap_ctx_create reads each of them ONCE from the environment (MOCAP_<NAME> in capitals; the hot
  * path never calls getenv), this call changes one for the context afterwards.  Names: skip_dark,
  * general_filter, dense_boxes, remap_pipeline, cluster, wide_quads_remap, wide_quads_identity, wide_bands, wide_fork,
- * box_prio, scan_prio, contour_prio, corr_prio, box_stage_bytes, box_timing, contour_timing, follow_timing, scan_wide, scan_hotmap, scan_serial, rows_staged, rows_stage_dw, wide_blocks_per_cu,
+ * box_prio, scan_prio, contour_prio, corr_prio, box_stage_bytes, box_timing, contour_timing, follow_timing, scan_wide, scan_hotmap, scan_serial, rows_staged, rows_stage_dw, wide_blocks_per_cu, contour_blocks_per_cu, mark_blocks_per_cu, contour_defer,
  * scan_blocks_per_cu, scan_slices, excess_base, probe_debug, contour_boxes, contours_split, corr_threads, corr_step_groups.  (rows, box_blocks_per_cu and base_sel
  * shape the context at creation: environment only.)  Must not race with a batch call on the same context. */
 MOCAP_API int mocap_set_tuning(mocap_ctx_t ctx, const char* name, int value);

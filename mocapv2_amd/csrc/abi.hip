@@ -90,7 +90,8 @@ struct Tuning {
     int rows_stage_dw = -1;      // dwords of LDS a band's source rectangle may take (-1 = all of the buffer; 0 = taps from memory: a test switch)
     int scan_serial = 1;         // 1 = one streaming scan at a time on the device: a context's scan waits for the scan launched before it (event chain across
                                  //   contexts).  A scan alone saturates HBM; two at once only stretch each other and the chains behind them (round 4: +5..9 %)
-    int scan_hotmap = 1;         // 0 = the scan marks the tiles itself (reach lookup + atomics behind its loads) instead of leaving a hot map
+    int scan_hotmap = 1;         // who turns hot cells into tile boxes: 0 = the scan itself (reach lookup + atomics behind its loads), 2 = mark_tiles_kernel
+                                 //   from the hot map the scan leaves, 1 = whichever the last probe's hot-cell count favours (crowded scenes: the map)
     int scan_blocks_per_cu = 0;  // > 0: the scan as a persistent pass of that many workgroups per CU (0 = one workgroup per block)
     int scan_slices = 1;         // the scan goes out as that many launches over consecutive runs of images
     int excess_base = -1;        // >= 0: pins the scan's excess base
@@ -98,6 +99,7 @@ struct Tuning {
     int probe_debug = 0;
     int contour_boxes = 1;       // 0 = candidates from whole strips
     int contours_split = 1;      // 0 = the contour stage as one kernel per image
+    int contour_defer = 1;       // links that need a walk: 2 = always through the second follow / tree passes, 0 = walked in place, 1 = by the scene
     int mark_blocks_per_cu = 0;  // > 0: mark_tiles_kernel as that many workgroups per CU whose waves loop over the hot map
     int contour_blocks_per_cu = 0; // > 0: the per-image contour kernels (candidates, tree) as that many workgroups per CU looping over the images
     int corr_threads = 256;      // threads per time step of the correspondence kernel (64 / 128 / 256)
@@ -112,9 +114,9 @@ static const TuneName kTuneNames[] = {
     {"box_prio", &Tuning::box_prio, 0, 1}, {"scan_prio", &Tuning::scan_prio, 0, 3}, {"contour_prio", &Tuning::contour_prio, 0, 3},
     {"corr_prio", &Tuning::corr_prio, 0, 3}, {"box_stage_bytes", &Tuning::box_stage_bytes, 0, BOX_SCAP},
     {"box_blocks_per_cu", &Tuning::box_blocks_per_cu, 0, 32}, {"box_timing", &Tuning::box_timing, 0, 1},
-    {"contour_timing", &Tuning::contour_timing, 0, 1}, {"follow_timing", &Tuning::follow_timing, 0, 2}, {"scan_wide", &Tuning::scan_wide, 0, 1}, {"scan_hotmap", &Tuning::scan_hotmap, 0, 1}, {"scan_serial", &Tuning::scan_serial, 0, 1}, {"rows_staged", &Tuning::rows_staged, 0, 1}, {"wide_blocks_per_cu", &Tuning::wide_blocks_per_cu, 1, 8}, {"rows_stage_dw", &Tuning::rows_stage_dw, -1, 1 << 20}, {"scan_blocks_per_cu", &Tuning::scan_blocks_per_cu, 0, 64}, {"scan_slices", &Tuning::scan_slices, 1, 64}, {"excess_base", &Tuning::excess_base, -1, 254},
+    {"contour_timing", &Tuning::contour_timing, 0, 1}, {"follow_timing", &Tuning::follow_timing, 0, 2}, {"scan_wide", &Tuning::scan_wide, 0, 1}, {"scan_hotmap", &Tuning::scan_hotmap, 0, 2}, {"scan_serial", &Tuning::scan_serial, 0, 1}, {"rows_staged", &Tuning::rows_staged, 0, 1}, {"wide_blocks_per_cu", &Tuning::wide_blocks_per_cu, 1, 8}, {"rows_stage_dw", &Tuning::rows_stage_dw, -1, 1 << 20}, {"scan_blocks_per_cu", &Tuning::scan_blocks_per_cu, 0, 64}, {"scan_slices", &Tuning::scan_slices, 1, 64}, {"excess_base", &Tuning::excess_base, -1, 254},
     {"base_sel", &Tuning::base_sel, 0, 1}, {"probe_debug", &Tuning::probe_debug, 0, 1}, {"contour_boxes", &Tuning::contour_boxes, 0, 1},
-    {"contours_split", &Tuning::contours_split, 0, 1}, {"contour_blocks_per_cu", &Tuning::contour_blocks_per_cu, 0, 16}, {"mark_blocks_per_cu", &Tuning::mark_blocks_per_cu, 0, 16}, {"corr_threads", &Tuning::corr_threads, 64, 256},
+    {"contours_split", &Tuning::contours_split, 0, 1}, {"contour_blocks_per_cu", &Tuning::contour_blocks_per_cu, 0, 16}, {"mark_blocks_per_cu", &Tuning::mark_blocks_per_cu, 0, 16}, {"contour_defer", &Tuning::contour_defer, 0, 2}, {"corr_threads", &Tuning::corr_threads, 64, 256},
     {"corr_step_groups", &Tuning::corr_step_groups, 0, 0x7fffffff},
 };
 static bool tune_set(Tuning& t, const char* name, int v)
@@ -173,6 +175,9 @@ struct mocap_ctx {
     // excess base of the scan, adapted between batches: two candidates (tight / tolerant of bright backgrounds), the current
     // one, and a probe now and then that counts the hot cells both would leave (BrightArgs::probe)
     int base_sel; int probe_age; bool probe_pending; uint32_t* probe_dev; uint32_t* probe_host; hipEvent_t probe_ev;
+    bool walk_count_zeroed;                // the filter stage of the current batch has zeroed walk_count (settle_tiles_kernel)
+    int probe_images;                      // images the pending probe counted on (every 16th of its batch)
+    bool hot_dense;                        // the last probe found a crowded scene (many hot cells per image): the scan leaves a hot map
     uint32_t* cells_ext; uint32_t* cur_box_ext; size_t cells_ext_images; // the same for caller-owned masks (mocap_filter_mask)
     void* cwork; size_t cwork_images;      // contour kernel workspace, contour_work_bytes() per image
     uint64_t* walk_list; uint64_t* link_list; uint32_t* walk_count; // contour stage, split form: the batch's border walks / link walks
@@ -277,7 +282,7 @@ int mocap_ctx_create(int device_id, int width, int height, int n_slots, mocap_ct
     c->comm.reset();
     c->side = nullptr; c->ev_fork = nullptr; c->ev_join = nullptr;
     c->tune = tuning_from_env();
-    c->base_sel = c->tune.base_sel; c->probe_age = 0; c->probe_pending = false; c->probe_dev = nullptr; c->probe_host = nullptr; c->probe_ev = nullptr;
+    c->base_sel = c->tune.base_sel; c->probe_age = 0; c->probe_pending = false; c->probe_images = 0; c->hot_dense = false; c->probe_dev = nullptr; c->probe_host = nullptr; c->probe_ev = nullptr;
     {
         hipDeviceProp_t prop;
         c->box_grid = 2048; c->n_cu = 256;
@@ -603,6 +608,7 @@ static int excess_base(int thr_mul, int sel)
 static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mod, int slot_base, size_t image_stride,
                       int pitch, uint32_t* mask, uint32_t* cells, hipStream_t s, const BayerArgs* bayer = nullptr)
 {
+    c->walk_count_zeroed = false;
     double ft = floor(c->prm.thresh);
     const int thr_mul = ft < -1.0 ? 0 : (ft > 255.0 ? 256 : (int)ft + 1);
     Tiling tl = tiling(c);
@@ -634,6 +640,12 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
         // explode: use it iff it leaves at most 1.25x the hot cells of the tolerant base.
         const unsigned long long n_lo = c->base_sel == 0 ? n_cur : n_alt, n_hi = c->base_sel == 0 ? n_alt : n_cur;
         c->base_sel = (n_lo * 4 <= n_hi * 5) ? 0 : 1;
+        // Who marks the tiles (scan_hotmap = 1: whichever is cheaper).  A hot cell costs the scan two dependent round trips behind
+        // its loads; the hot map moves them into mark_tiles_kernel, which costs ~0.04 ms per 3072 images whatever the scene holds.
+        // Measured (profiles/history/r4_run7_scan_wide_serial.log): scan + mark + settle 1.03 against 1.00 ms at 8 markers per frame
+        // (~190 hot cells per image), 1.07 against 1.21 at 32 (~750): the map pays above a few hundred hot cells per image.
+        const unsigned long long n_now = c->base_sel == 0 ? n_lo : n_hi;
+        c->hot_dense = c->probe_images > 0 && n_now > 400ull * (unsigned long long)c->probe_images;
         c->probe_pending = false;
     }
     const int base = fixed_base >= 0 ? fixed_base : excess_base(thr_mul, c->base_sel);
@@ -723,7 +735,12 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
     a.prio = c->tune.box_prio;
     a.ext_mask = own_mask ? 0 : 1;
     if ((size_t)n_images * cells_per_image(c) * BOX_MAX_PARTS > (size_t)c->cap_items) return fail(MOCAP_E_STATE, "work list smaller than the batch");
-    HIP_TRY(hipMemsetAsync(c->n_items, 0, 1024, s));
+    // the counter block (item counts, run heads) must be zero before settle: the scan's first workgroup does that on its way -- a fill
+    // launch of its own is one more tiny kernel that waits for a place beside the other batches' kernels -- unless no plain scan runs
+    const bool scan_zeroes = !a.dense && !bayer && c->tune.scan_blocks_per_cu == 0 && c->tune.scan_slices <= 1;
+    if (!scan_zeroes) HIP_TRY(hipMemsetAsync(c->n_items, 0, 1024, s));
+    a.zero8 = own_mask ? c->walk_count : nullptr; // (the contour stage of this batch follows on the same stream; null before its first batch)
+    c->walk_count_zeroed = a.zero8 != nullptr;
     BrightArgs mark_args{}; bool mark_after_scan = false;
     if (!a.dense) { // one streaming pass over the frames marks the tiles (and their boxes) that can hold set pixels
         // floor(i / ncx) = umulhi(i, ceil(2^32 / ncx)) is exact while i * ncx < 2^32
@@ -740,6 +757,7 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
                      mask, own_mask ? 0 : (size_t)n_images * c->H * c->wpr, ((uintptr_t)mask & 15) == 0, nullptr, base_alt, allow_alt / 4, 0};
         b.prio = c->tune.scan_prio; // A/B switch
         b.max_blocks = c->tune.scan_blocks_per_cu * c->n_cu; b.blocks_x = 0;
+        b.zero_counters = scan_zeroes ? c->n_items : nullptr;
         b.block_ctr = c->n_items + 160; // (words 160..223 of the counter block zeroed above: one per slice)
         b.slices = c->tune.scan_slices; b.image0 = 0; b.slice_images = n_images;
         const bool probe = fixed_base < 0 && !c->probe_pending && allow_alt >= 0 && base_alt != base && !bayer &&
@@ -752,7 +770,7 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
         const bool fused = bayer && own_mask && bayer_scan_fusable(*bayer);
         // the streaming scan leaves a hot map (two bits per cell, no table lookups or atomics behind its loads) that
         // mark_tiles_kernel turns into tile boxes; the fused Bayer pass marks the tiles itself (MOCAP_SCAN_HOTMAP=0: so does the scan)
-        const bool two_step = !fused && c->tune.scan_hotmap && c->hotmap;
+        const bool two_step = !fused && c->hotmap && (c->tune.scan_hotmap == 2 || (c->tune.scan_hotmap == 1 && c->hot_dense));
         if (two_step) { b.hotmap = c->hotmap; b.hot_words = hot_map_words(c->H, c->W, wide); b.mark_grid = c->tune.mark_blocks_per_cu * c->n_cu; }
         ScanTurn* turn = c->tune.scan_serial && c->device >= 0 && c->device < 64 ? &g_scan_turn[c->device] : nullptr;
         std::unique_lock<std::mutex> turn_lock;
@@ -779,6 +797,7 @@ static int run_filter(mocap_ctx* c, const void* frames, int n_images, int cam_mo
             HIP_TRY(hipMemcpyAsync(c->probe_host, c->probe_dev, PROBE_BYTES, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipEventRecord(c->probe_ev, s));
             c->probe_pending = true;
+            c->probe_images = (n_images + 15) / 16;
         }
     }
     else if (bayer) { // no early-out (not provable for this table, or MOCAP_SKIP_DARK=0): the plain gray pass
@@ -897,6 +916,13 @@ static int run_contours(mocap_ctx* c, const uint32_t* mask, const uint32_t* cell
     a.follow_grid = c->n_cu * 4;  // 4 one-wave workgroups per CU (33 KB of LDS each): persistent, they refill their lanes from the list
     a.follow_grid2 = c->n_cu;     // the link walks are few
     a.image_grid = c->tune.contour_blocks_per_cu * c->n_cu;
+    a.counters_zeroed = mask == c->mask && c->walk_count_zeroed; // (settle of this batch, same stream)
+    c->walk_count_zeroed = false;
+    // Links that only a walk can settle (nested rings, overlapping boxes): deferred to a second, packed follow pass + a second tree pass
+    // -- two more launches per batch, nearly always empty on frames of separate markers, and beside another batch's scan an empty
+    // launch costs up to 0.3 ms (profiles/history/r4_timeline_depth3.txt) -- or walked in place by the first tree pass (one wave per
+    // link: 0.1-0.2 ms when a crowded batch holds a long one).  contour_defer = 1: deferred only once a probe found the scene crowded.
+    a.defer_links = c->tune.contour_defer == 2 || (c->tune.contour_defer == 1 && c->hot_dense);
     a.wait_list = (uint32_t*)((uint8_t*)c->link_list + contour_link_bytes() * c->cwork_images);
     a.follow_list = 0; a.tree_pass = 0; a.follow_dbg = nullptr; a.follow_dbg_list = c->tune.follow_timing == 2 ? 1 : 0;
     if (c->tune.follow_timing && split) {

@@ -98,6 +98,7 @@ __device__ __forceinline__ void choose_split(int nb, int h, int& nx, int& ny)
 __global__ __launch_bounds__(256) void settle_tiles_kernel(BoxArgs a)
 {
     const int lane = threadIdx.x & 63;
+    if (a.zero8 && blockIdx.x == 0 && threadIdx.x < 8) a.zero8[threadIdx.x] = 0u; // the contour stage's walk counters
     const int tiles = a.n_chunks * a.n_strips;
     // the grid also covers the images beyond this batch whose boxes an earlier, larger batch may have left in the array the next
     // batch's scan will widen (n_clear): they are emptied, nothing else happens for them

@@ -665,7 +665,7 @@ __device__ __forceinline__ void contours_body(const ContourArgs& a, const int im
             }
             if (hits == 1) found = which;
         }
-        if (MODE == 2 && found == -2) {
+        if (MODE == 2 && found == -2 && a.defer_links) {
             // split form: the walk joins the batch's second packed follow pass (one lane there, not a whole wave here)
             int slot = 0;
             if (lane == 0) slot = atomicAdd(&n_amb, 1);
@@ -1150,7 +1150,7 @@ void launch_contours(const ContourArgs& a_, hipStream_t s)
         // candidates per image -> every walk of the batch -> tree per image; the (few) links whose owner only a walk can tell go
         // through a second, equally packed, follow pass, and the second tree pass finishes the images that waited for them
         ContourArgs a = a_;
-        (void)hipMemsetAsync(a.walk_count, 0, 8 * sizeof(uint32_t), s);
+        if (!a.counters_zeroed) (void)hipMemsetAsync(a.walk_count, 0, 8 * sizeof(uint32_t), s);
         const bool loop = a.image_grid > 0 && a.image_grid < a.n_images;
         const int pass2_grid = a.n_images < 64 ? a.n_images : 64;
         if (loop) hipLaunchKernelGGL((contours_kernel<1, true>), dim3(a.image_grid), dim3(NTHREADS), 0, s, a);
@@ -1160,6 +1160,7 @@ void launch_contours(const ContourArgs& a_, hipStream_t s)
         a.tree_pass = 1;
         if (loop) hipLaunchKernelGGL((contours_kernel<2, true>), dim3(a.image_grid), dim3(NTHREADS), 0, s, a);
         else hipLaunchKernelGGL((contours_kernel<2, false>), dim3(a.n_images), dim3(NTHREADS), 0, s, a);
+        if (!a.defer_links) return; // every link was settled in the first tree pass (walked in place where the boxes did not decide)
         a.follow_list = 1;
         hipLaunchKernelGGL(contour_follow_kernel, dim3(a.follow_grid2), dim3(64), 0, s, a);
         a.tree_pass = 2;

@@ -452,6 +452,7 @@ __global__ __launch_bounds__(256) void bright_cells_kernel(BrightArgs a)
     else if (a.prio == 2) __builtin_amdgcn_s_setprio(2);
     else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
     const uint32_t total = (uint32_t)a.blocks_x * (uint32_t)a.slice_images;
+    if (a.zero_counters && blockIdx.x == 0) a.zero_counters[threadIdx.x] = 0u; // the counter block of the kernels behind this one
     if (a.block_ctr == nullptr) {
         for (uint32_t vb = blockIdx.x; vb < total; vb += gridDim.x) {
             const uint32_t image = vb / (uint32_t)a.blocks_x;

@@ -71,6 +71,7 @@ struct BoxArgs {
                                 //   last row; counted in n_items[8]) and through the sliding row pipeline of filter_mask_kernel, which
                                 //   does less work per pixel on wide regions than the box kernel
     uint32_t cap_wide; int wide_quads_remap, wide_quads_identity, wide_bands;
+    uint32_t* zero8;            // not null: 8 words (the contour stage's walk counters) that settle zeroes -- in place of a fill launch
     int dense;                  // 1 = no early-out: every tile is filtered whole
     int ext_mask;               // 1 = caller-owned mask (cleared by the scan kernel, or written whole when dense)
 };
@@ -129,6 +130,9 @@ struct ContourArgs {
     uint32_t* wait_list;   // split form: [n_images] the images the first tree pass left to the second one
     int follow_grid;       // split form: workgroups (waves) of the follow kernel
     int follow_grid2;      //   ... of its second pass (the link walks: few)
+    int counters_zeroed;   // split form: 1 = walk_count was zeroed by an earlier kernel of the stream (settle): no fill launch
+    int defer_links;       // split form: 1 = links only a walk can settle go through a second follow + tree pass (two more launches);
+                           //   0 = the first tree pass walks them in place (one wave per link) and the second passes are not launched
     int image_grid;        // split form: > 0 = the per-image kernels (candidates, tree) as that many workgroups looping over the images
     int follow_list;       // set by launch_contours: 0 = the follow kernel works through walk_list, 1 = through link_list
     int tree_pass;         // set by launch_contours: 1 / 2 = first / second pass of the tree kernel
@@ -167,6 +171,7 @@ struct BrightArgs {
                                   //   many of the thresholds hot_corner <= hot_edge <= hot its sum exceeds.  All zeros between batches: the scan
                                   //   stores the words that are not zero, mark_tiles_kernel reads and clears them.  null = the scan marks the tiles itself
     int hot_words;                // words per image: hot_map_words(H, W, wide)
+    uint32_t* zero_counters;      // not null: 256 words (the context's counter block) that workgroup 0 of the scan zeroes -- in place of a fill launch
     int mark_grid;                // > 0: workgroups of mark_tiles_kernel (its waves loop over the map); 0 = one piece per wave
 };
 int hot_map_words(int H, int W, int wide);

@@ -254,8 +254,9 @@ def test_contours_match_oracle(torch_cuda, seed):
     assert seen > 0
 
 
+@pytest.mark.parametrize("defer", [0, 2], ids=["links_in_place", "links_deferred"])
 @pytest.mark.parametrize("seed", range(int(os.environ.get("MOCAP_FUZZ_CONTOUR_SEEDS", "6"))))
-def test_contours_match_oracle_large_masks(torch_cuda, seed):
+def test_contours_match_oracle_large_masks(torch_cuda, seed, defer):
     """The same comparison on masks several mask windows wide and tall (the follow kernel's lanes pause at the rim of their
     64 x 64 window and have it staged anew; the forward and the backward lane of a border leave their shared window at
     different times): rings within rings, long thin bars (borders walked out and back), blobs touching the image border,
@@ -278,6 +279,7 @@ def test_contours_match_oracle_large_masks(torch_cuda, seed):
         masks.append((m * 255).astype(np.uint8))
     ctx = MocapContext(W, H)
     ctx.set_blob_params(min_area=20.0, min_circ=0.05)
+    ctx.set_tuning("contour_defer", defer)  # nested rings: links only a walk settles -- in the first tree pass, or through the second passes
     xy, cnt, recs = ctx.contours_from_mask(pack_mask(np.stack(masks)), max_blobs=128, debug_cap=384)
     xy, cnt = xy.cpu().numpy(), cnt.cpu().numpy()
     seen = longest = 0
@@ -780,7 +782,12 @@ def test_blob_centroids_from_bayer_equals_the_two_steps(torch_cuda, monkeypatch,
     {"MOCAP_SCAN_SERIAL": "0"},                               # scans of different contexts may share the chip
     {"MOCAP_SCAN_HOTMAP": "0"},                               # the scan marks the tiles itself instead of leaving the hot map
     {"MOCAP_SCAN_HOTMAP": "0", "MOCAP_SCAN_WIDE": "0"},
-    {"MOCAP_SCAN_WIDE": "0"},                                 # the hot map from the 8-byte-load form of the scan (16 lanes per word)
+    {"MOCAP_SCAN_HOTMAP": "2"},                               # the scan always leaves the hot map (default: only for crowded scenes)
+    {"MOCAP_SCAN_HOTMAP": "2", "MOCAP_SCAN_WIDE": "0"},       # ... from the 8-byte-load form of the scan (16 lanes per word)
+    {"MOCAP_SCAN_HOTMAP": "2", "MOCAP_MARK_BLOCKS_PER_CU": "1"},  # ... read by a fixed grid of looping waves
+    {"MOCAP_CONTOUR_BLOCKS_PER_CU": "1"},                     # the per-image contour kernels as a fixed grid looping over the images
+    {"MOCAP_CONTOUR_DEFER": "2"},                             # links that need a walk always through the second follow / tree passes
+    {"MOCAP_CONTOUR_DEFER": "0"},                             # ... always walked in place by the first tree pass
 ], ids=lambda e: ",".join(f"{k[6:]}={v}" for k, v in e.items()))
 def test_tuning_switches_do_not_change_results(torch_cuda, monkeypatch, env):
     """Routing thresholds, row bands, the side stream, the scan's excess base (pinned or adapting), the grid size and the
@@ -856,3 +863,36 @@ def test_translation_invariance_identity_lens(torch_cuda):
         xs, xd = (slice(0, W - dx), slice(dx, W)) if dx >= 0 else (slice(-dx, W), slice(0, W + dx))
         moved[yd, xd] = masks[0][ys, xs]
         assert np.array_equal(masks[i][inner], moved[inner]), (dx, dy)
+
+
+def test_crowded_scenes_switch_the_marking_to_the_hot_map_and_back(torch_cuda):
+    """scan_hotmap = 1 (the default): who turns hot cells into tile boxes follows the scene -- the scan itself on sparse frames, the hot
+    map + mark_tiles_kernel once a probe has counted more than ~400 hot cells per image.  One context sees sparse batches, crowded
+    ones and sparse ones again; the probe runs on the first batch and on every 32nd after it and flips the mode in between.  Masks
+    and centroids equal the oracle's on the batches around the switches, whatever marked the tiles: nothing of one mode's state (hot
+    map words, tile boxes of either alternating array) leaks into the other's batches."""
+    torch = torch_cuda
+    from gpu_util import unpack_mask
+    from mocapv2_amd.engine import MocapContext
+    W, H = 640, 360
+    sc = Scene(2, width=W, height=H, dist=np.array(MILD_DIST))
+    ctx = MocapContext(W, H, n_slots=2)
+    for sl in range(2):
+        ctx.set_undistort(sl, sc.K, sc.dist)
+    rng = np.random.default_rng(23)
+    sparse = [dark_frames(rng, 34, H, W, n_discs=3, salt=0.001) for _ in range(3)]
+    crowded = [dark_frames(rng, 34, H, W, n_discs=30, salt=0.001) for _ in range(3)]
+    # 74 batches: probes on batch 0 (sparse), 32 (crowded: the map takes over) and 64 (sparse again: back to the scan)
+    plan = [sparse] * 4 + [crowded] * 56 + [sparse] * 14
+    checked = set(range(0, 4)) | {32, 33, 34, 35, 59, 60, 61, 64, 65, 66, 67, 73}
+    for b, pool in enumerate(plan):
+        frames = pool[b % 3]
+        dev = torch.from_numpy(frames).cuda()
+        rec = ctx.blob_centroids(dev, cam_mod=2).cpu().numpy()
+        if b in checked:
+            got, _ = unpack_mask(ctx.filter_mask(dev, cam_mod=2), W)
+            for i in range(b % 5, len(frames), 5):
+                exp, m = oracle.find_dot(frames[i], sc.K, sc.dist, return_mask=True)
+                n = rec[i, 0]
+                assert n == len(exp) and rec[i, 2:2 + 2 * n].reshape(-1, 2).tolist() == exp, (b, i)
+                assert np.array_equal(got[i], m != 0), (b, i)
