@@ -896,3 +896,35 @@ def test_crowded_scenes_switch_the_marking_to_the_hot_map_and_back(torch_cuda):
                 n = rec[i, 0]
                 assert n == len(exp) and rec[i, 2:2 + 2 * n].reshape(-1, 2).tolist() == exp, (b, i)
                 assert np.array_equal(got[i], m != 0), (b, i)
+
+
+@pytest.mark.parametrize("W,H", [(64, 48), (250, 130), (251, 77), (500, 300), (961, 541), (1920, 1080)])
+@pytest.mark.parametrize("scale", [0.0, 1.0])
+def test_hot_map_marking_at_any_size(torch_cuda, W, H, scale):
+    """The hot map (two bits per 8x8 source cell, written by whole waves of the scan, read 256 words per wave by mark_tiles_kernel) on
+    frame sizes that end in part-cells, part-words and part-waves, in both forms of the scan (16-byte loads where the width allows,
+    8-byte loads otherwise), with and without a lens table: masks and centroids equal the oracle's, and equal what the scan's own
+    marking gives on the same context right afterwards."""
+    from gpu_util import unpack_mask
+    torch = torch_cuda
+    from mocapv2_amd.engine import MocapContext
+    rng = np.random.default_rng(W * 3 + H)
+    sc = Scene(1, width=W, height=H, dist=np.array(MILD_DIST) * scale)
+    ctx = MocapContext(W, H, n_slots=1)
+    ctx.set_undistort(0, sc.K, sc.dist)
+    n = 5 if W < 1000 else 2
+    frames = dark_frames(rng, n, H, W, n_discs=max(2, W * H // 40000), salt=0.001)
+    dev = torch.from_numpy(frames).cuda()
+    results = {}
+    for mode in (2, 0, 2):
+        ctx.set_tuning("scan_hotmap", mode)
+        rec = ctx.blob_centroids(dev).cpu().numpy()
+        got, _ = unpack_mask(ctx.filter_mask(dev), W)
+        results.setdefault(mode, []).append((rec.copy(), got.copy()))
+    for i in range(n):
+        exp, m = oracle.find_dot(frames[i], sc.K, sc.dist, return_mask=True)
+        for mode, runs in results.items():
+            for rec, got in runs:
+                k = rec[i, 0]
+                assert k == len(exp) and rec[i, 2:2 + 2 * k].reshape(-1, 2).tolist() == exp, (mode, i)
+                assert np.array_equal(got[i], m != 0), (mode, i)
