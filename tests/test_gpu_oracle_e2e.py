@@ -133,6 +133,24 @@ def test_replay_tracker_matches_oracle_per_time_step():
     for s in range(T):
         assert piped[s]["message"] == got[s]["message"], s
         assert np.array_equal(piped[s]["object_points"], got[s]["object_points"]) and np.array_equal(piped[s]["image_points"], got[s]["image_points"]), s
+    # the bulk form over a recording in pieces (3 + 4 time steps, torch and NumPy): per batch what run() yields per time step,
+    # the carried message crossing the piece and batch boundaries
+    import torch
+    rp = ReplayTracker(K, dist, R, t, F, W, H, batch=2, obj_count=obj_count, depth=3)
+    sent = []
+    s0 = 0
+    for res in rp.run_batches([torch.from_numpy(frames[:3]), frames[3:]], send_many=sent.extend):
+        assert res["first_step"] == s0
+        for i in range(res["n_steps"]):
+            s = s0 + i
+            k = int(res["kept"][i])
+            assert k == len(got[s]["object_points"]) and int(res["n_roots"][i]) == len(got[s]["image_points"]), s
+            if k:
+                assert np.array_equal(res["object_points"][i, :k], got[s]["object_points"]), s
+                assert np.array_equal(res["image_points"][i, :int(res["n_roots"][i])], got[s]["image_points"]), s
+            assert res["messages"][i] == got[s]["message"], s
+        s0 += res["n_steps"]
+    assert s0 == T and sent == [g["message"] for g in got]
 
 
 def test_eight_cameras_one_per_rank_layout_matches_oracle():
