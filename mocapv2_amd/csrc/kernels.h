@@ -38,9 +38,14 @@ int rows_stage_dwords();
 // The sparse half of the filter stage (blob_boxes.hip): tiles, boxes, work items.
 // A tile = 240 mask columns x rows_per_chunk rows.  The scan kernel leaves per tile the box of mask rows / columns that
 // hot cells can reach (tile_rows); settle_tiles_kernel turns the boxes into items; box_filter_kernel consumes them.
-constexpr int BOX_HCAP = 1536; // quad-rows (4 pixels x 1 row) of one item's patch (halving it for twice the waves per CU: 0.63 against 0.53 ms)
-constexpr int BOX_SCAP = 6656; // bytes of source pixels staged in LDS per item (>= (BOX_HCAP + 64) * 4: the counts alias it)
-constexpr int BOX_MAX_PARTS = 4;  // items a tile is cut into at most (a whole 240 x 68 tile: 2 x 2)
+#ifndef MOCAP_BOX_HCAP         // (build-time knobs for A/B builds, scratch/build_variant.sh)
+#define MOCAP_BOX_HCAP 1536
+#define MOCAP_BOX_SCAP 6656
+#define MOCAP_BOX_MAX_PARTS 4
+#endif
+constexpr int BOX_HCAP = MOCAP_BOX_HCAP; // quad-rows (4 pixels x 1 row) of one item's patch (halving it for twice the waves per CU: 0.63 against 0.53 ms)
+constexpr int BOX_SCAP = MOCAP_BOX_SCAP; // bytes of source pixels staged in LDS per item (>= (BOX_HCAP + 64) * 4: the counts alias it)
+constexpr int BOX_MAX_PARTS = MOCAP_BOX_MAX_PARTS;  // items a tile is cut into at most (a whole 240 x 68 tile: 2 x 2)
 struct BoxItem { uint32_t image, tile, x01, y01, bx01, by01, pad0, pad1; }; // output region: columns x0 | x1 << 16, rows y0 | y1 << 16
                                                                         //   (x0 > x1: skip); the scan's box of the tile (not clipped to it)
 struct BoxArgs {
