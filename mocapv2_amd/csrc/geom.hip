@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <mutex>
 #include "kernels.h"
 
 namespace mocap {
@@ -691,14 +692,19 @@ __global__ __launch_bounds__(256) void ba_residuals_kernel(BaArgs a)
 // whole 160 KiB per workgroup (large P x C: the candidate lists alone are P * C * 16 bytes) and remembers the answer.
 static int correspond_lds_limit()
 {
-    static const int limit = [] {
+    static std::mutex mu;
+    static int limit[64] = {0}; // per device (the attribute belongs to the function on the current device); 0 = not asked yet
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 64 * 1024 - 64;
+    std::lock_guard<std::mutex> lk(mu);
+    if (limit[dev] == 0) {
         const int want = 160 * 1024 - 64; // minus the kernel's static words
         const bool ok = hipFuncSetAttribute((const void*)correspond_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess &&
                         hipFuncSetAttribute((const void*)correspond_kernel<int32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess;
         if (!ok) (void)hipGetLastError();
-        return ok ? want : 64 * 1024 - 64;
-    }();
-    return limit;
+        limit[dev] = ok ? want : 64 * 1024 - 64;
+    }
+    return limit[dev];
 }
 // the budget the plan is made for: 64 KiB when that holds everything (four workgroups per CU stay possible), else the limit
 int correspond_lds_budget(int P, int C)
