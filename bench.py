@@ -791,7 +791,9 @@ def main():
             extra = {}
             for key, wl in (("markers32_configs2", Workload(6, 1920, 1080, 32, args.dist)),
                             ("bright_background", Workload(6, 1920, 1080, 8, args.dist, (90, 110))),
-                            ("frame_4k", Workload(6, 3840, 2160, 8, args.dist))):
+                            ("frame_4k", Workload(6, 3840, 2160, 8, args.dist)),
+                            # N1: the same frames taken as raw Bayer GR sensor frames, the gray conversion fused with the scan inside every step
+                            ("bayer_input", Workload(6, 1920, 1080, 8, args.dist, bayer=True))):
                 Tx = wl.default_time_steps()
                 mx = measure(wl, Tx, args.steps, args.warmup)
                 extra[key] = section(wl, mx, args.steps, f"6x1920x1080-m32-{args.dist}" if key == "markers32_configs2" else None)
